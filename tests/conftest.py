@@ -1,0 +1,45 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_cases():
+    import numpy as np
+    return np.load(GOLDEN / "nsdiff_cases.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_schedule():
+    import numpy as np
+    return np.load(GOLDEN / "nsdiff_schedule.npz")
+
+
+def load_ckpt(tag):
+    import numpy as np
+    import torch
+    z = np.load(GOLDEN / ("ckpt_%s.npz" % tag))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def ckpt_wofx():
+    return load_ckpt("wofx")
+
+
+@pytest.fixture(scope="session")
+def ckpt_sim():
+    return load_ckpt("sim")
