@@ -1,0 +1,195 @@
+/*
+ * mpv_hip.h -- C ABI of the MI355X (gfx950) reverse-diffusion MPV sampling library.
+ *
+ * The reference (curious-child/Unsupervised-probing-Using-Generative-Diffusion-Models) is
+ * pure Python/PyTorch and has no FFI; its boundary for this path is the duck-typed model
+ * protocol consumed by evaluation_and_analysis/diffusion_model_uncertainy.py
+ * (`evaluation_step`, `cond_pred_model_g`, `scaler_transform`).
+ * This header is the thin native layer *beneath* that protocol: each entry point names
+ * the reference function(s) whose arithmetic it replaces.  The Python host mirror
+ * (package `models/Diffusion_model/NsDiff/NsDiff_model.py`) binds it with ctypes; see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative MPV_E* code on failure, and never
+ *     throws; mpv_last_error() gives the message of the last failure on that context
+ *     (or of the last context-less failure when ctx == NULL);
+ *   - the caller owns every buffer it passes.  "dev" pointers are device (HBM) pointers
+ *     on the context's device, "host" pointers are ordinary host memory;
+ *   - work is enqueued on the context's HIP stream and is asynchronous with respect to
+ *     the host; the library allocates only context-private workspace (weights, tables,
+ *     reduction scratch), freed by mpv_ctx_destroy;
+ *   - a context is not thread-safe: one context per (process, device, stream);
+ *   - all tensors are fp32, row-major, in the reference's own index order.
+ */
+#ifndef MPV_HIP_H
+#define MPV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPV_ABI_VERSION 1
+
+#define MPV_OK 0
+#define MPV_EINVAL (-1)   /* bad argument / unsupported shape            */
+#define MPV_ESTATE (-2)   /* model not loaded, wrong call order          */
+#define MPV_EHIP (-3)     /* a HIP runtime call failed                   */
+#define MPV_ENOMEM (-4)   /* workspace allocation failed                 */
+
+#define MPV_HIDDEN 128     /* ConditionalGuidedModel width, denoise.py:30-32 */
+#define MPV_MAX_NF 4       /* features per series the kernels are built for  */
+#define MPV_COEF_COLS 20   /* per-step posterior coefficient row, see below  */
+
+typedef struct mpv_ctx mpv_ctx;
+
+int mpv_abi_version(void);
+
+/* device: HIP device ordinal.  hip_stream: a hipStream_t (e.g. torch's current stream
+ * handle) or NULL for the default stream. */
+int mpv_ctx_create(int device, void* hip_stream, mpv_ctx** out);
+void mpv_ctx_destroy(mpv_ctx* ctx);
+int mpv_ctx_set_stream(mpv_ctx* ctx, void* hip_stream);
+const char* mpv_last_error(const mpv_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------
+ * NsDiff epsilon-network + reverse process
+ * replaces: ConditionalGuidedModel.forward (NsDiff/denoise.py:35-51),
+ *           NsDiff_net.forward (NsDiff/NsDiff_net.py:163-172),
+ *           p_sample / p_sample_t_1to0 / p_sample_loop (NsDiff/nsdiff_utils.py:111-158,
+ *           209-239, 271-284) and the tile/un-tile of evaluation_step
+ *           (NsDiff/NsDiff_model.py:227-262, 470-494).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t steps;  /* T = diffusion_steps = rows of the nn.Embedding tables           */
+    int32_t nf;     /* F = dataset_nf (1..MPV_MAX_NF)                                  */
+} mpv_nsdiff_desc;
+
+/* Host pointers, PyTorch layouts ([out][in] row-major weights), i.e. exactly the
+ * tensors of state_dict()["model.diffussion_model.*"]. */
+typedef struct {
+    const float* lin_w[3];   /* lin{1,2,3}.lin.weight   [128][3F], [128][128], [128][128] */
+    const float* lin_b[3];   /* lin{1,2,3}.lin.bias     [128]                              */
+    const float* embed[3];   /* lin{1,2,3}.embed.weight [T][128]                           */
+    const float* eps_w;      /* lin4.weight      [F][128]                                  */
+    const float* eps_b;      /* lin4.bias        [F]                                       */
+    const float* sig_w;      /* sigma_lin.weight [F][128]                                  */
+    const float* sig_b;      /* sigma_lin.bias   [F]                                       */
+} mpv_nsdiff_weights;
+
+/* coef: host [T][MPV_COEF_COLS] fp32, one row per timestep t, built by the host from the
+ * schedule tables of NsDiff_net.__init__ (NsDiff_net.py:92-134) with the reference's own
+ * fp32 operation order (columns, in terms of nsdiff_utils.py:131-157 names; a=alpha_t,
+ * bt/bb = betas_tilde/bar[t], bt1/bb1 = betas_tilde_m_1/bar_m_1[t]):
+ *   0 c1   = (1-a)^2*bt1 + a*(1-a)*(bb1-bt1)        lambda_1 = c1*g - sigma*c2
+ *   1 c2   = a*bt1 + a*(1-a)
+ *   2 q1   = (1-a)^2                                lambda_2 = g*g*q1*q2 - sigma*g*c4
+ *   3 q2   = bb1-bt1
+ *   4 c4   = a*bb1 - a*bt1 + (1-a)^2
+ *   5 l4   = 4*lambda_0,  lambda_0 = a*(1-a)*bt1
+ *   6 l2   = 2*lambda_0
+ *   7 n1   = bb-bt                                  noise = n1*g + bt*Sigma_y0
+ *   8 bt
+ *   9 invr = 1/sqrt(1-s^2), s = one_minus_alphas_bar_sqrt[t]
+ *  10 omr  = 1-sqrt(1-s^2)
+ *  11 aoma = a*(1-a)                                Sigma_1 = q1*g + aoma*Sigma_y0
+ *  12 bt1                                           Sigma_2 = q2*g + bt1*Sigma_y0
+ *  13 a                                             D = a*Sigma_2 + Sigma_1
+ *  14 sp   = sqrt(alphas_cumprod_prev[t])           gamma_0 = sp*Sigma_1/D
+ *  15 sa   = sqrt(a)                                gamma_1 = sa*Sigma_2/D
+ *  16 k1   = sa*(a-1)                               gamma_2 = (k1*Sigma_2 + k2*Sigma_1)/D
+ *  17 k2   = 1-sp
+ *  18,19 reserved (0)
+ */
+int mpv_nsdiff_load(mpv_ctx* ctx, const mpv_nsdiff_desc* desc, const mpv_nsdiff_weights* host_weights,
+                    const float* host_coef);
+
+typedef struct {
+    int32_t n_windows;    /* W: windows batched in this call (reference: one evaluation_step each) */
+    int32_t nodes;        /* B: rows of one window's batch (Node axis; 1 for SLBP)                 */
+    int32_t pred_len;     /* O                                                                     */
+    int32_t n_samples;    /* S = n_z_samples                                                       */
+    int32_t chunk;        /* P = parallel_sample; S % P == 0.  Only fixes the noise draw order.   */
+    int32_t reserved;
+    uint64_t seed;        /* Philox key when noise == NULL                                         */
+    uint64_t offset;      /* Philox stream offset (counter word 3) when noise == NULL              */
+} mpv_sample_shape;
+
+/* y0hat : dev [W][B][O][F] prior mean f(x) (= y_T_mean), or NULL for zeros (cond_var / Guassian).
+ * gx    : dev [W][B][O][F] prior variance g(x) (already + EPS where the variant adds it).
+ * noise : dev, or NULL.  When given it holds every normal draw of the reference in the
+ *         reference's own order: for window w, for chunk c < S/P, for draw
+ *         k < T (k = 0 is z_T, k >= 1 is the z of step t = T-k), a tensor [B*P][O][F] whose
+ *         row b*P+p is sample s = c*P+p of node b:
+ *             noise[((((w*(S/P) + c)*T + k)*(B*P) + b*P + p)*O + o)*F + f]
+ *         When NULL, normals come from Philox4x32-10 keyed by `seed`, counter
+ *         (chain_lo, chain_hi, k, offset) with chain = ((w*B+b)*O+o)*S+s, Box-Muller on
+ *         the four output words (feature f uses normal f).
+ * samples: dev [W][B][O][F][S] -- window w's slice is the reference's `outs`
+ *         [B, pred_len, F, n_z_samples] (NsDiff_model.py:262-266).
+ */
+int mpv_nsdiff_sample(mpv_ctx* ctx, const mpv_sample_shape* shape, const float* y0hat, const float* gx,
+                      const float* noise, float* samples);
+
+/* Debug/validation helper: write the Philox normals mpv_nsdiff_sample would consume, in the
+ * dense layout [n_chains][T][F] (chain-major), so a CPU checker can replay them. */
+int mpv_nsdiff_philox_normals(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out_dev);
+
+/* ------------------------------------------------------------------------------------
+ * sigma head g(x)
+ * replaces: wv_sigma_trailing (NsDiff/sigma.py:34-72) + SigmaEstimation.forward
+ *           (NsDiff/g_backbone.py:49-72), with scaler_transform (NsDiff_model.py:106-107)
+ *           and build_sliding_windows (diffusion_model_uncertainy.py:137-147) folded
+ *           into the load.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t seq_len;    /* windows (T of the head's input)                     */
+    int32_t rolling;    /* kernel_size k of the trailing variance              */
+    int32_t pred_len;   /* O                                                   */
+    int32_t nf;         /* F                                                   */
+    int32_t hidden;     /* 512                                                 */
+} mpv_sigma_desc;
+
+typedef struct {            /* host pointers: state_dict()["cond_pred_model_g.mlp.*"] */
+    const float* w0;  const float* b0;       /* mlp.0  [hidden][seq_len-rolling], [hidden] */
+    const float* ln0_w; const float* ln0_b;  /* mlp.2  [F][hidden]                         */
+    const float* w1;  const float* b1;       /* mlp.3  [hidden][hidden]                    */
+    const float* ln1_w; const float* ln1_b;  /* mlp.5  [F][hidden]                         */
+    const float* w2;  const float* b2;       /* mlp.6  [pred_len][hidden]                  */
+} mpv_sigma_weights;
+
+int mpv_sigma_load(mpv_ctx* ctx, const mpv_sigma_desc* desc, const mpv_sigma_weights* host_weights);
+
+/* series: dev [V][L][F] (already sub-sampled).  Window w covers samples
+ * [first + w*step, first + w*step + seq_len) of every node (A.2 of SURVEY.md).
+ * mean/std: dev [F] for a fused (x-mean)/std, or both NULL for an already scaled input.
+ * add_eps is added to the head's output (10e-8 in NsDiff_model_variants, 0 in NsDiff_model
+ * and in the gx-only path).  gx: dev [n_windows][V][O][F]. */
+int mpv_sigma_head(mpv_ctx* ctx, const float* series, int32_t V, int64_t L, int32_t n_windows, int64_t first,
+                   int64_t step, const float* mean, const float* std, float add_eps, float* gx);
+
+/* ------------------------------------------------------------------------------------
+ * MPV reduction
+ * replaces: summarize_pred_future_list (diffusion_model_uncertainy.py:286-303; with
+ *           _feature_inverse_transform :267-283) and the variance part of
+ *           summarize_slbp_sensitivity (:529-538).
+ * samples: dev [W][R][F][S] (R = B*O).  std/mean: dev [F] inverse scaling or NULL.
+ * mpv[w]       = mean over (r,f) of the population variance over s of x*std+mean
+ * pred_mean[w] = mean over everything of x*std+mean
+ * mpv_feat[w][f] (nullable) = mean over r of that variance, per feature
+ * ---------------------------------------------------------------------------------- */
+int mpv_reduce(mpv_ctx* ctx, const float* samples, int32_t W, int64_t R, int32_t F, int32_t S, const float* std,
+               const float* mean, float* mpv, float* pred_mean, float* mpv_feat);
+
+/* Average device time in milliseconds of the chain-sampler launches since the last call
+ * (measured with HIP events on the context's stream); also returns their count.  Used by
+ * bench.py for the roofline line.  Synchronises the stream. */
+int mpv_chain_timing(mpv_ctx* ctx, double* avg_ms, int64_t* launches);
+int mpv_chain_timing_enable(mpv_ctx* ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPV_HIP_H */

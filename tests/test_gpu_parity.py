@@ -1,0 +1,232 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (ctypes) and through
+the reference-shaped model API, against the reference's golden vectors and the CPU oracle
+on the same inputs and the same noise.  Tolerance: north_star's 1e-4 relative on fp32."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nsdiff_oracle as O
+from oracle import philox as PH
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+RTOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def rel_err(got, want):
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, dtype=np.float64)
+    want = want.detach().cpu().double().numpy() if isinstance(want, torch.Tensor) else np.asarray(want, dtype=np.float64)
+    return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+def make_ctx(sd, nf, steps, sigma=None):
+    from mpv_amd import _native
+    from mpv_amd.models.Diffusion_model.NsDiff.NsDiff_net import nsdiff_tables, posterior_coef_rows
+    ctx = _native.Context(dev())
+    pre = O.EPS_NET
+    ctx.load_nsdiff(steps, nf, [sd[pre + "lin%d.lin.weight" % i] for i in (1, 2, 3)],
+                    [sd[pre + "lin%d.lin.bias" % i] for i in (1, 2, 3)],
+                    [sd[pre + "lin%d.embed.weight" % i] for i in (1, 2, 3)],
+                    sd[pre + "lin4.weight"], sd[pre + "lin4.bias"], sd[pre + "sigma_lin.weight"], sd[pre + "sigma_lin.bias"],
+                    posterior_coef_rows(nsdiff_tables(steps, "linear", 1e-4, 0.02)))
+    if sigma is not None:
+        seq, k, O_ = sigma
+        g = O.G_NET
+        ctx.load_sigma(seq, k, O_, nf, 512, [sd[g + n] for n in ("0.weight", "0.bias", "2.weight", "2.bias", "3.weight",
+                                                                   "3.bias", "5.weight", "5.bias", "6.weight", "6.bias")])
+    return ctx
+
+
+def model_sd(tag, ckpt_wofx):
+    if tag == "wofx20":
+        return ckpt_wofx, 2, 20
+    if tag == "seed50":
+        return O.random_state_dict(1, 50, 100, 100, 50, seed=123), 1, 50
+    return O.random_state_dict(2, 10, 200, 200, 100, seed=321), 2, 10
+
+
+def test_library_loads_and_reports_device():
+    from mpv_amd import _native
+    lib = _native.load_library()
+    assert lib.mpv_abi_version() == _native.ABI_VERSION
+    ctx = _native.Context(dev())
+    with pytest.raises(_native.MpvError):
+        ctx.sample(torch.ones(1, 1, 4, 1, device=dev()), None, 4, 4)          # nothing loaded yet
+
+
+@pytest.mark.parametrize("tag", ["seed50", "wofx20", "seed10"])
+def test_chain_matches_reference_loop(golden_cases, ckpt_wofx, tag):
+    """p_sample_loop golden (reference run, recorded noise) through mpv_nsdiff_sample."""
+    sd, nf, steps = model_sd(tag, ckpt_wofx)
+    ctx = make_ctx(sd, nf, steps)
+    y0 = T(golden_cases["step_%s_y0" % tag]).to(dev())[None].contiguous()      # [1, 6, 5, F]
+    gx = T(golden_cases["step_%s_gx" % tag]).to(dev())[None].contiguous()
+    noise = T(golden_cases["loop_%s_noise" % tag]).to(dev()).contiguous()       # [T, 6, 5, F]
+    out = ctx.sample(gx, y0, 1, 1, noise=noise)[0, :, :, :, 0]
+    err = rel_err(out, golden_cases["loop_%s_out" % tag])
+    print("chain %s rel err %.3e" % (tag, err))
+    assert err < RTOL
+
+
+def test_chain_nan_on_negative_discriminant_like_reference(ckpt_wofx):
+    """gx = 0 makes lambda_0 > 0, lambda_2 = 0 and -lambda_1 +- |lambda_1| -> the reference's own
+    arithmetic (sqrt(noise) of a tiny negative, 0/0 ...) must be reproduced, not 'fixed': compare with
+    the oracle elementwise including where it is NaN."""
+    sd, nf, steps = O.random_state_dict(1, 10, 100, 100, 50, seed=5), 1, 10
+    ctx = make_ctx(sd, nf, steps)
+    tb = O.schedule_tables(steps)
+    gx = torch.tensor([0.0, 1e-12, 1e-3, 4.0]).reshape(1, 4, 1, 1)
+    g = torch.Generator().manual_seed(3)
+    noise = torch.randn(steps, 4, 1, 1, generator=g)
+    want = O.sample_loop(sd, tb, torch.zeros(4, 1, 1), gx[0], torch.zeros(4, 1, 1), steps, O.replay_noise(list(noise)))
+    got = ctx.sample(gx.to(dev()), None, 1, 1, noise=noise.to(dev()))[0, :, :, :, 0].cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    ok = ~torch.isnan(want)
+    assert rel_err(got[ok], want[ok]) < RTOL
+
+
+def test_sigma_head_matches_reference(golden_cases, ckpt_wofx):
+    ctx = make_ctx(ckpt_wofx, 2, 20, sigma=(200, 100, 200))
+    x = T(golden_cases["ghead_wofx_x"]).to(dev())
+    got = ctx.sigma_head(x, 1, 0, 1)[0]
+    err = rel_err(got, golden_cases["ghead_wofx_y"])
+    print("sigma head (real ckpt) rel err %.3e" % err)
+    assert err < 1e-5
+    sd = O.random_state_dict(1, 50, 100, 100, 50, seed=123)
+    ctx = make_ctx(sd, 1, 50, sigma=(100, 50, 100))
+    got = ctx.sigma_head(T(golden_cases["ghead_seed_x"]).to(dev()), 1, 0, 1)[0]
+    assert rel_err(got, golden_cases["ghead_seed_y"]) < 1e-5
+
+
+def test_sigma_head_fused_windows_and_scaler(golden_cases):
+    """Sliding-window gather + scaler fused into the kernel == per-window oracle (a1-a5)."""
+    sd = O.random_state_dict(1, 50, 100, 100, 50, seed=123)
+    sd["scaler_mean"] = T(golden_cases["eval_seed_scaler_mean"])
+    sd["scaler_std"] = T(golden_cases["eval_seed_scaler_std"])
+    ctx = make_ctx(sd, 1, 50, sigma=(100, 50, 100))
+    series = T(np.ascontiguousarray(golden_cases["net_series"]))                            # [3, 260, 1]
+    gx = ctx.sigma_head(series.to(dev()), 3, 0, 80, sd["scaler_mean"].to(dev()), sd["scaler_std"].to(dev()))
+    assert rel_err(gx, golden_cases["net_gx"]) < 1e-5                   # reference run_nsdiff_g_cache
+    # ragged tail: 1 window starting at an odd offset, V not a multiple of the kernel's group size
+    gx1 = ctx.sigma_head(series.to(dev()), 1, 37, 5, sd["scaler_mean"].to(dev()), sd["scaler_std"].to(dev()), add_eps=1e-7)
+    want = O.sigma_head(sd, O.scale(series[:, 37:137], sd["scaler_mean"], sd["scaler_std"]), 50, 100) + 1e-7
+    assert rel_err(gx1[0], want) < 1e-5
+    from mpv_amd._native import MpvError
+    with pytest.raises(MpvError):
+        ctx.sigma_head(series.to(dev()), 3, 0, 81)                     # last window past the end
+
+
+@pytest.mark.parametrize("S", [1, 4, 32, 33, 100])
+def test_mpv_reduce_matches_torch(S):
+    from mpv_amd import _native
+    ctx = _native.Context(dev())
+    g = torch.Generator().manual_seed(S)
+    x = torch.randn(5, 37, 2, S, generator=g) * 3 + 1
+    std, mean = torch.tensor([2.0, 0.5]), torch.tensor([-1.0, 4.0])
+    mpv, pm, feat = ctx.reduce(x.to(dev()), std.to(dev()), mean.to(dev()), per_feature=True)
+    for w in range(5):
+        m, v = O.mpv_network(x[w].double(), mean.double(), std.double())
+        assert abs(mpv[w].item() - v) <= 2e-6 * abs(v) + 1e-12
+        assert abs(pm[w].item() - m) <= 2e-6 * abs(m) + 1e-7
+    mpv2, _, feat2 = ctx.reduce(x.to(dev()), per_feature=True)            # no inverse scaling (SLBP summary)
+    want = x.double().var(dim=-1, unbiased=False).mean(dim=1)              # [W, F]
+    assert rel_err(feat2, want) < 2e-6
+
+
+def _variant_model(sd, select, nf, steps, windows, pred_len, rolling, n_z, par, noise_source="philox"):
+    from mpv_amd.models.models import diffusion_models
+    net_param = dict(device=dev(), scaler_type="StandardScaler", task_model="NsDiff_model_variants",
+                     rolling_length=rolling, diffusion_schedule="linear", diffusion_steps=steps, beta_start=1e-4,
+                     beta_end=0.02, n_z_samples=n_z, parallel_sample=par, windows=windows, pred_len=pred_len,
+                     dataset_nf=nf, noise_source=noise_source)
+    model = diffusion_models("NsDiff_model_variants", net_param, train_model_select=select).to(dev())
+    own = model.state_dict()
+    model.load_state_dict({k: sd[k] for k in own}, strict=True)
+    return model.eval()
+
+
+def test_evaluation_step_real_checkpoint(golden_cases, ckpt_wofx):
+    """C1 shape, real wo_fx checkpoint, two chunks: the reference's recorded noise injected."""
+    model = _variant_model(ckpt_wofx, "cond_var", 2, 20, 200, 200, 100, 4, 2)
+    outs, by = model.evaluation_step(T(golden_cases["eval_wofx_batch"]), noise=T(golden_cases["eval_wofx_noise"]))
+    assert by is None and outs.device.type == "cpu" and tuple(outs.shape) == (1, 200, 2, 4)
+    err = rel_err(outs, golden_cases["eval_wofx_out"])
+    print("evaluation_step wo_fx rel err %.3e" % err)
+    assert err < RTOL
+
+
+def test_evaluation_step_seeded_and_torch_cpu_noise_stream(golden_cases):
+    """Reduced C2 shape; noise_source='torch_cpu' + the reference's seed == the reference run."""
+    sd = O.random_state_dict(1, 50, 100, 100, 50, seed=123)
+    model = _variant_model(sd, "cond_var", 1, 50, 100, 100, 50, 8, 4, noise_source="torch_cpu")
+    torch.manual_seed(12)
+    outs, _ = model.evaluation_step(T(golden_cases["eval_seed_batch"]))
+    err = rel_err(outs, golden_cases["eval_seed_out"])
+    print("evaluation_step seeded rel err %.3e" % err)
+    assert err < RTOL
+    m, v = O.mpv_network(outs)
+    mw, vw = O.mpv_network(T(golden_cases["eval_seed_out"]))
+    assert abs(v - vw) <= RTOL * abs(vw)
+
+
+def test_evaluation_step_gaussian_variant(golden_cases):
+    sd = O.random_state_dict(2, 10, 200, 200, 100, seed=321)
+    model = _variant_model(sd, "Guassian", 2, 10, 200, 200, 100, 4, 4)
+    outs, _ = model.evaluation_step(T(golden_cases["eval_gauss_batch"]), noise=T(golden_cases["eval_gauss_noise"]))
+    assert rel_err(outs, golden_cases["eval_gauss_out"]) < RTOL
+
+
+def test_philox_mode_replays_through_oracle():
+    """Device Philox normals == numpy restatement, and a Philox-mode launch == the oracle fed
+    the normals the device dumped."""
+    sd, nf, steps = O.random_state_dict(2, 10, 200, 200, 100, seed=321), 2, 10
+    ctx = make_ctx(sd, nf, steps)
+    W, B, Ol, S = 2, 3, 7, 5
+    n_chains = W * B * Ol * S
+    z = ctx.philox_normals(99, 5, n_chains).cpu()                              # [n, T, F]
+    zn = PH.normals(99, 5, n_chains, steps, nf)
+    assert np.abs(z.numpy() - zn).max() < 5e-5
+    assert abs(float(z.mean())) < 0.05 and abs(float(z.std()) - 1) < 0.05
+    g = torch.Generator().manual_seed(1)
+    gx = torch.rand(W, B, Ol, nf, generator=g) + 0.05
+    y0 = torch.randn(W, B, Ol, nf, generator=g) * 0.1
+    got = ctx.sample(gx.to(dev()), y0.to(dev()), S, S, seed=99, offset=5).cpu()   # [W,B,O,F,S]
+    # oracle rows = chains in (w,b,o,s) order, horizon axis of length 1
+    rows_g = gx.reshape(-1, 1, nf).repeat_interleave(S, dim=0)
+    rows_y = y0.reshape(-1, 1, nf).repeat_interleave(S, dim=0)
+    draws = [z[:, k, :].reshape(n_chains, 1, nf) for k in range(steps)]
+    want = O.sample_loop(sd, O.schedule_tables(steps), rows_y, rows_g, rows_y, steps, O.replay_noise(draws))
+    want = want.reshape(W, B, Ol, S, nf).permute(0, 1, 2, 4, 3)
+    assert rel_err(got, want) < RTOL
+    again = ctx.sample(gx.to(dev()), y0.to(dev()), S, S, seed=99, offset=5).cpu()
+    assert torch.equal(got, again)                                            # counter-based: bitwise repeatable
+    other = ctx.sample(gx.to(dev()), y0.to(dev()), S, S, seed=100, offset=5).cpu()
+    assert not torch.equal(got, other)
+
+
+def test_ragged_and_empty_batches():
+    sd, nf, steps = O.random_state_dict(1, 10, 100, 100, 50, seed=5), 1, 10
+    ctx = make_ctx(sd, nf, steps)
+    out = ctx.sample(torch.ones(0, 3, 4, 1, device=dev()), None, 4, 4, seed=1)
+    assert tuple(out.shape) == (0, 3, 4, 1, 4)
+    # 1*1*3*5 = 15 chains: less than one 32-chain tile; 3*7*11*3 = 693: ragged last tile
+    for shape, S in (((1, 1, 3, 1), 5), ((3, 7, 11, 1), 3)):
+        g = torch.Generator().manual_seed(7)
+        gx = torch.rand(*shape, generator=g) + 0.1
+        W, B, Ol, _ = shape
+        noise = torch.randn(W, 1, steps, B * S, Ol, 1, generator=g)
+        got = ctx.sample(gx.to(dev()), None, S, S, noise=noise.to(dev())).cpu()
+        for w in range(W):
+            rows = gx[w].unsqueeze(1).expand(B, S, Ol, 1).reshape(B * S, Ol, 1)
+            want = O.sample_loop(sd, O.schedule_tables(steps), torch.zeros_like(rows), rows, torch.zeros_like(rows), steps,
+                                 O.replay_noise(list(noise[w, 0])))
+            want = want.reshape(B, S, Ol, 1).permute(0, 2, 3, 1)
+            assert rel_err(got[w], want) < RTOL
+    from mpv_amd._native import MpvError
+    with pytest.raises(MpvError):
+        ctx.sample(torch.ones(1, 1, 4, 1, device=dev()), None, 6, 4, seed=1)      # S % P != 0

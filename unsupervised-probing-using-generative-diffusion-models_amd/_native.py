@@ -1,0 +1,258 @@
+"""ctypes binding of libmpv_hip.so -- the C ABI declared in include/mpv_hip.h.
+
+There is deliberately no fallback: if the library is missing, cannot be loaded, or no
+gfx950 device is visible, every compute entry point raises.  PyTorch is used only for
+device memory (``data_ptr()``) and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional, Sequence
+
+import torch
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "libmpv_hip.so"
+ABI_VERSION = 1
+HIDDEN = 128
+MAX_NF = 4
+COEF_COLS = 20
+
+EXPORTS = (
+    "mpv_abi_version", "mpv_ctx_create", "mpv_ctx_destroy", "mpv_ctx_set_stream", "mpv_last_error",
+    "mpv_nsdiff_load", "mpv_nsdiff_sample", "mpv_nsdiff_philox_normals", "mpv_sigma_load", "mpv_sigma_head",
+    "mpv_reduce", "mpv_chain_timing", "mpv_chain_timing_enable",
+)
+
+
+class MpvError(RuntimeError):
+    pass
+
+
+_F = C.POINTER(C.c_float)
+
+
+class NsdiffDesc(C.Structure):
+    _fields_ = [("steps", C.c_int32), ("nf", C.c_int32)]
+
+
+class NsdiffWeights(C.Structure):
+    _fields_ = [("lin_w", _F * 3), ("lin_b", _F * 3), ("embed", _F * 3),
+                ("eps_w", _F), ("eps_b", _F), ("sig_w", _F), ("sig_b", _F)]
+
+
+class SampleShape(C.Structure):
+    _fields_ = [("n_windows", C.c_int32), ("nodes", C.c_int32), ("pred_len", C.c_int32), ("n_samples", C.c_int32),
+                ("chunk", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64)]
+
+
+class SigmaDesc(C.Structure):
+    _fields_ = [("seq_len", C.c_int32), ("rolling", C.c_int32), ("pred_len", C.c_int32), ("nf", C.c_int32),
+                ("hidden", C.c_int32)]
+
+
+class SigmaWeights(C.Structure):
+    _fields_ = [(n, _F) for n in ("w0", "b0", "ln0_w", "ln0_b", "w1", "b1", "ln1_w", "ln1_b", "w2", "b2")]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library and declare the prototypes.  Raises MpvError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise MpvError("{} is missing: build it with `python __graft_entry__.py` (hipcc, gfx950); "
+                       "there is no CPU fallback for this path".format(LIB_PATH))
+    try:
+        lib = C.CDLL(str(LIB_PATH))
+    except OSError as exc:
+        raise MpvError("cannot load {}: {}".format(LIB_PATH, exc)) from exc
+    vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+    protos = {
+        "mpv_abi_version": (C.c_int, []),
+        "mpv_ctx_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
+        "mpv_ctx_destroy": (None, [vp]),
+        "mpv_ctx_set_stream": (C.c_int, [vp, vp]),
+        "mpv_last_error": (C.c_char_p, [vp]),
+        "mpv_nsdiff_load": (C.c_int, [vp, C.POINTER(NsdiffDesc), C.POINTER(NsdiffWeights), _F]),
+        "mpv_nsdiff_sample": (C.c_int, [vp, C.POINTER(SampleShape), vp, vp, vp, vp]),
+        "mpv_nsdiff_philox_normals": (C.c_int, [vp, u64, u64, i64, vp]),
+        "mpv_sigma_load": (C.c_int, [vp, C.POINTER(SigmaDesc), C.POINTER(SigmaWeights)]),
+        "mpv_sigma_head": (C.c_int, [vp, vp, i32, i64, i32, i64, i64, vp, vp, f32, vp]),
+        "mpv_reduce": (C.c_int, [vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
+        "mpv_chain_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i64)]),
+        "mpv_chain_timing_enable": (C.c_int, [vp, C.c_int]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)          # AttributeError here = symbol missing from the .so
+        fn.restype, fn.argtypes = res, args
+    if lib.mpv_abi_version() != ABI_VERSION:
+        raise MpvError("libmpv_hip.so ABI {} != binding ABI {}".format(lib.mpv_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def _host_f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+
+
+def _fptr(t: torch.Tensor):
+    return C.cast(t.data_ptr(), _F)
+
+
+def _dev_ptr(t: Optional[torch.Tensor], device: torch.device, name: str):
+    if t is None:
+        return None
+    if t.device != device:
+        raise MpvError("{} is on {}, the context is on {}".format(name, t.device, device))
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise MpvError("{} must be a contiguous float32 tensor".format(name))
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One mpv_ctx: (process, device, stream).  Owns the device copies of the weights."""
+
+    def __init__(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise MpvError("the MPV sampling path runs only on a ROCm device (got {!r}); no CPU fallback".format(str(device)))
+        if not torch.cuda.is_available():
+            raise MpvError("no ROCm device is visible to PyTorch")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.lib = load_library()
+        self.device = device
+        self._h = C.c_void_p()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        rc = self.lib.mpv_ctx_create(device.index, C.c_void_p(stream), C.byref(self._h))
+        if rc != 0:
+            raise MpvError("mpv_ctx_create: {} ({})".format(rc, (self.lib.mpv_last_error(None) or b"").decode()))
+        self.nsdiff = None     # (steps, nf)
+        self.sigma = None      # SigmaDesc fields
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.mpv_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise MpvError("{} failed ({}): {}".format(what, rc, (self.lib.mpv_last_error(self._h) or b"").decode()))
+
+    def _bind_stream(self):
+        self._check(self.lib.mpv_ctx_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                    "mpv_ctx_set_stream")
+
+    # ---- weights -------------------------------------------------------------------
+    def load_nsdiff(self, steps: int, nf: int, lin_w: Sequence[torch.Tensor], lin_b: Sequence[torch.Tensor],
+                    embed: Sequence[torch.Tensor], eps_w, eps_b, sig_w, sig_b, coef: torch.Tensor):
+        keep = [_host_f32(t) for t in (*lin_w, *lin_b, *embed, eps_w, eps_b, sig_w, sig_b, coef)]
+        want = [(HIDDEN, 3 * nf), (HIDDEN, HIDDEN), (HIDDEN, HIDDEN), (HIDDEN,), (HIDDEN,), (HIDDEN,),
+                (steps, HIDDEN), (steps, HIDDEN), (steps, HIDDEN), (nf, HIDDEN), (nf,), (nf, HIDDEN), (nf,),
+                (steps, COEF_COLS)]
+        for t, shp in zip(keep, want):
+            if tuple(t.shape) != shp:
+                raise MpvError("NsDiff weight has shape {}, expected {}".format(tuple(t.shape), shp))
+        w = NsdiffWeights()
+        for i in range(3):
+            w.lin_w[i], w.lin_b[i], w.embed[i] = _fptr(keep[i]), _fptr(keep[3 + i]), _fptr(keep[6 + i])
+        w.eps_w, w.eps_b, w.sig_w, w.sig_b = (_fptr(t) for t in keep[9:13])
+        self._bind_stream()
+        self._check(self.lib.mpv_nsdiff_load(self._h, C.byref(NsdiffDesc(steps, nf)), C.byref(w), _fptr(keep[13])),
+                    "mpv_nsdiff_load")
+        self.nsdiff = (steps, nf)
+
+    def load_sigma(self, seq_len: int, rolling: int, pred_len: int, nf: int, hidden: int, tensors: Sequence[torch.Tensor]):
+        keep = [_host_f32(t) for t in tensors]
+        k0 = seq_len - rolling
+        want = [(hidden, k0), (hidden,), (nf, hidden), (nf, hidden), (hidden, hidden), (hidden,), (nf, hidden),
+                (nf, hidden), (pred_len, hidden), (pred_len,)]
+        for t, shp in zip(keep, want):
+            if tuple(t.shape) != shp:
+                raise MpvError("sigma-head weight has shape {}, expected {}".format(tuple(t.shape), shp))
+        w = SigmaWeights(*[_fptr(t) for t in keep])
+        self._bind_stream()
+        self._check(self.lib.mpv_sigma_load(self._h, C.byref(SigmaDesc(seq_len, rolling, pred_len, nf, hidden)), C.byref(w)),
+                    "mpv_sigma_load")
+        self.sigma = (seq_len, rolling, pred_len, nf, hidden)
+
+    # ---- compute (all stream-ordered, asynchronous) -------------------------------------
+    def sigma_head(self, series: torch.Tensor, n_windows: int, first: int, step: int, mean=None, std=None,
+                   add_eps: float = 0.0) -> torch.Tensor:
+        """series [V, L, F] on device -> gx [n_windows, V, O, F]."""
+        if self.sigma is None:
+            raise MpvError("sigma head weights not loaded")
+        V, L, F = series.shape
+        if F != self.sigma[3]:
+            raise MpvError("series has F={}, sigma head was loaded with F={}".format(F, self.sigma[3]))
+        gx = torch.empty((n_windows, V, self.sigma[2], F), device=self.device, dtype=torch.float32)
+        self._bind_stream()
+        self._check(self.lib.mpv_sigma_head(self._h, _dev_ptr(series, self.device, "series"), V, L, n_windows, first, step,
+                                            _dev_ptr(mean, self.device, "mean"), _dev_ptr(std, self.device, "std"),
+                                            float(add_eps), _dev_ptr(gx, self.device, "gx")), "mpv_sigma_head")
+        return gx
+
+    def sample(self, gx: torch.Tensor, y0hat: Optional[torch.Tensor], n_samples: int, chunk: int,
+               noise: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0) -> torch.Tensor:
+        """gx / y0hat [W, B, O, F] on device -> samples [W, B, O, F, S]."""
+        if self.nsdiff is None:
+            raise MpvError("NsDiff weights not loaded")
+        W, B, O, F = gx.shape
+        if F != self.nsdiff[1]:
+            raise MpvError("gx has F={}, the model was loaded with F={}".format(F, self.nsdiff[1]))
+        if y0hat is not None and tuple(y0hat.shape) != tuple(gx.shape):
+            raise MpvError("y0hat shape {} != gx shape {}".format(tuple(y0hat.shape), tuple(gx.shape)))
+        if noise is not None:
+            need = W * self.nsdiff[0] * B * n_samples * O * F
+            if noise.numel() != need:
+                raise MpvError("noise has {} elements, the draw order needs {}".format(noise.numel(), need))
+        out = torch.empty((W, B, O, F, n_samples), device=self.device, dtype=torch.float32)
+        shape = SampleShape(W, B, O, n_samples, chunk, 0, seed & (2 ** 64 - 1), offset & (2 ** 64 - 1))
+        self._bind_stream()
+        self._check(self.lib.mpv_nsdiff_sample(self._h, C.byref(shape), _dev_ptr(y0hat, self.device, "y0hat"),
+                                               _dev_ptr(gx, self.device, "gx"), _dev_ptr(noise, self.device, "noise"),
+                                               _dev_ptr(out, self.device, "samples")), "mpv_nsdiff_sample")
+        return out
+
+    def philox_normals(self, seed: int, offset: int, n_chains: int) -> torch.Tensor:
+        if self.nsdiff is None:
+            raise MpvError("NsDiff weights not loaded")
+        out = torch.empty((n_chains, self.nsdiff[0], self.nsdiff[1]), device=self.device, dtype=torch.float32)
+        self._bind_stream()
+        self._check(self.lib.mpv_nsdiff_philox_normals(self._h, seed, offset, n_chains, _dev_ptr(out, self.device, "out")),
+                    "mpv_nsdiff_philox_normals")
+        return out
+
+    def reduce(self, samples: torch.Tensor, std=None, mean=None, per_feature: bool = False):
+        """samples [W, R, F, S] (or [W, B, O, F, S]) -> (mpv [W], pred_mean [W], mpv_feat [W, F] | None)."""
+        if samples.dim() == 5:
+            samples = samples.reshape(samples.shape[0], -1, samples.shape[3], samples.shape[4])
+        W, R, F, S = samples.shape
+        mpv = torch.empty(W, device=self.device, dtype=torch.float32)
+        pm = torch.empty(W, device=self.device, dtype=torch.float32)
+        feat = torch.empty((W, F), device=self.device, dtype=torch.float32) if per_feature else None
+        self._bind_stream()
+        self._check(self.lib.mpv_reduce(self._h, _dev_ptr(samples, self.device, "samples"), W, R, F, S,
+                                        _dev_ptr(std, self.device, "std"), _dev_ptr(mean, self.device, "mean"),
+                                        _dev_ptr(mpv, self.device, "mpv"), _dev_ptr(pm, self.device, "pred_mean"),
+                                        _dev_ptr(feat, self.device, "mpv_feat")), "mpv_reduce")
+        return mpv, pm, feat
+
+    def timing_enable(self, on: bool = True):
+        self._check(self.lib.mpv_chain_timing_enable(self._h, int(on)), "mpv_chain_timing_enable")
+
+    def timing(self):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self.lib.mpv_chain_timing(self._h, C.byref(ms), C.byref(n)), "mpv_chain_timing")
+        return ms.value, n.value

@@ -1,0 +1,247 @@
+// C ABI of libmpv_hip (include/mpv_hip.h): context, weight upload, argument checks, dispatch.
+#include <cstring>
+#include <mutex>
+
+#include "mpv_common.h"
+
+namespace {
+std::mutex g_err_mu;
+std::string g_err;   // last context-less failure
+
+struct DeviceGuard {     // run on ctx->device without disturbing the caller's current device
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+size_t align4(size_t n) { return (n + 3) & ~size_t(3); }   // keep every sub-array 16-B aligned
+
+// lay out `parts` (host arrays) back to back in one device allocation; returns device sub-pointers
+int upload_blob(mpv_ctx* ctx, const std::vector<std::pair<const float*, size_t>>& parts, float** blob,
+                std::vector<const float*>* dev) {
+    size_t total = 0;
+    for (auto& p : parts) total += align4(p.second);
+    std::vector<float> host(total, 0.0f);
+    std::vector<size_t> off;
+    size_t at = 0;
+    for (auto& p : parts) {
+        std::memcpy(host.data() + at, p.first, p.second * sizeof(float));
+        off.push_back(at);
+        at += align4(p.second);
+    }
+    if (*blob) (void)hipFree(*blob);
+    *blob = nullptr;
+    if (hipMalloc(blob, total * sizeof(float)) != hipSuccess) return mpv_fail(ctx, MPV_ENOMEM, "weight blob");
+    MPV_HIP_TRY(ctx, hipMemcpy(*blob, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    dev->clear();
+    for (size_t o : off) dev->push_back(*blob + o);
+    return MPV_OK;
+}
+
+std::vector<float> transposed(const float* w, int rows, int cols) {   // [rows][cols] -> [cols][rows]
+    std::vector<float> t((size_t)rows * cols);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = w[(size_t)r * cols + c];
+    return t;
+}
+}  // namespace
+
+int mpv_fail(mpv_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) {
+        ctx->err = msg;
+    } else {
+        std::lock_guard<std::mutex> lk(g_err_mu);
+        g_err = msg;
+    }
+    return code;
+}
+
+extern "C" {
+
+int mpv_abi_version(void) { return MPV_ABI_VERSION; }
+
+int mpv_ctx_create(int device, void* hip_stream, mpv_ctx** out) {
+    if (!out) return mpv_fail(nullptr, MPV_EINVAL, "mpv_ctx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return mpv_fail(nullptr, MPV_EHIP, "mpv_ctx_create: no HIP device visible");
+    if (device < 0 || device >= count) return mpv_fail(nullptr, MPV_EINVAL, "mpv_ctx_create: bad device ordinal");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return mpv_fail(nullptr, MPV_EHIP, "mpv_ctx_create: hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return mpv_fail(nullptr, MPV_EINVAL, std::string("mpv_ctx_create: built for gfx950, device is ") + prop.gcnArchName);
+    mpv_ctx* c = new (std::nothrow) mpv_ctx();
+    if (!c) return mpv_fail(nullptr, MPV_ENOMEM, "mpv_ctx_create: out of host memory");
+    c->device = device;
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    c->cu_count = prop.multiProcessorCount;
+    c->max_lds = prop.sharedMemPerBlock > prop.maxSharedMemoryPerMultiProcessor ? prop.sharedMemPerBlock
+                                                                              : prop.maxSharedMemoryPerMultiProcessor;
+    *out = c;
+    return MPV_OK;
+}
+
+void mpv_ctx_destroy(mpv_ctx* ctx) {
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& e : ctx->events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    if (ctx->ns.blob) (void)hipFree(ctx->ns.blob);
+    if (ctx->sg.blob) (void)hipFree(ctx->sg.blob);
+    if (ctx->reduce_ws) (void)hipFree(ctx->reduce_ws);
+    delete ctx;
+}
+
+int mpv_ctx_set_stream(mpv_ctx* ctx, void* hip_stream) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_ctx_set_stream: ctx is NULL");
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return MPV_OK;
+}
+
+const char* mpv_last_error(const mpv_ctx* ctx) {
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    return g_err.c_str();
+}
+
+int mpv_nsdiff_load(mpv_ctx* ctx, const mpv_nsdiff_desc* d, const mpv_nsdiff_weights* w, const float* coef) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nsdiff_load: ctx is NULL");
+    if (!d || !w || !coef) return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_load: NULL argument");
+    if (d->steps < 1 || d->nf < 1 || d->nf > MPV_MAX_NF)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_load: need steps >= 1 and 1 <= nf <= 4");
+    for (int i = 0; i < 3; ++i)
+        if (!w->lin_w[i] || !w->lin_b[i] || !w->embed[i]) return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_load: NULL weight");
+    if (!w->eps_w || !w->eps_b || !w->sig_w || !w->sig_b) return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_load: NULL head");
+    DeviceGuard g(ctx->device);
+    MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // nothing in flight may still read the old blob
+    const int T = d->steps, F = d->nf, H = MPV_HIDDEN;
+    const std::vector<float> w1t = transposed(w->lin_w[0], H, 3 * F);   // [3F][128]
+    std::vector<const float*> dev;
+    ctx->ns.loaded = false;
+    int rc = upload_blob(ctx,
+                         {{w1t.data(), (size_t)3 * F * H}, {w->lin_w[1], (size_t)H * H}, {w->lin_w[2], (size_t)H * H},
+                          {w->lin_b[0], H}, {w->lin_b[1], H}, {w->lin_b[2], H},
+                          {w->embed[0], (size_t)T * H}, {w->embed[1], (size_t)T * H}, {w->embed[2], (size_t)T * H},
+                          {w->eps_w, (size_t)F * H}, {w->sig_w, (size_t)F * H}, {w->eps_b, (size_t)F}, {w->sig_b, (size_t)F},
+                          {coef, (size_t)T * MPV_COEF_COLS}},
+                         &ctx->ns.blob, &dev);
+    if (rc != MPV_OK) return rc;
+    NsdiffModel& m = ctx->ns;
+    m.w1t = dev[0]; m.w2 = dev[1]; m.w3 = dev[2]; m.b1 = dev[3]; m.b2 = dev[4]; m.b3 = dev[5];
+    m.e1 = dev[6]; m.e2 = dev[7]; m.e3 = dev[8]; m.w4 = dev[9]; m.ws = dev[10]; m.b4 = dev[11]; m.bs = dev[12];
+    m.coef = dev[13];
+    m.steps = T; m.nf = F; m.loaded = true;
+    return MPV_OK;
+}
+
+int mpv_nsdiff_sample(mpv_ctx* ctx, const mpv_sample_shape* s, const float* y0hat, const float* gx, const float* noise,
+                      float* samples) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nsdiff_sample: ctx is NULL");
+    if (!ctx->ns.loaded) return mpv_fail(ctx, MPV_ESTATE, "mpv_nsdiff_sample: call mpv_nsdiff_load first");
+    if (!s) return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: NULL shape");
+    if (s->n_windows < 0 || s->nodes < 0 || s->pred_len < 0 || s->n_samples < 0)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: negative extent");
+    const bool empty = s->n_windows == 0 || s->nodes == 0 || s->pred_len == 0 || s->n_samples == 0;
+    if (!empty && (!gx || !samples)) return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: NULL argument");
+    if (s->n_samples > 0 && (s->chunk < 1 || s->n_samples % s->chunk != 0))
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: n_samples must be a positive multiple of chunk");
+    DeviceGuard g(ctx->device);
+    return launch_nsdiff_chain(ctx, *s, y0hat, gx, noise, samples);
+}
+
+int mpv_nsdiff_philox_normals(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nsdiff_philox_normals: ctx is NULL");
+    if (!ctx->ns.loaded) return mpv_fail(ctx, MPV_ESTATE, "mpv_nsdiff_philox_normals: call mpv_nsdiff_load first");
+    if (!out || n_chains < 0) return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_philox_normals: bad argument");
+    DeviceGuard g(ctx->device);
+    return launch_philox_dump(ctx, seed, offset, n_chains, out);
+}
+
+int mpv_sigma_load(mpv_ctx* ctx, const mpv_sigma_desc* d, const mpv_sigma_weights* w) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_sigma_load: ctx is NULL");
+    if (!d || !w) return mpv_fail(ctx, MPV_EINVAL, "mpv_sigma_load: NULL argument");
+    if (d->nf < 1 || d->nf > MPV_MAX_NF || d->rolling < 1 || d->rolling >= d->seq_len || d->pred_len < 1 || d->hidden < 1)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_sigma_load: need 1 <= nf <= 4, 1 <= rolling < seq_len, pred_len, hidden >= 1");
+    if (!w->w0 || !w->b0 || !w->ln0_w || !w->ln0_b || !w->w1 || !w->b1 || !w->ln1_w || !w->ln1_b || !w->w2 || !w->b2)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_sigma_load: NULL weight");
+    DeviceGuard g(ctx->device);
+    MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int K0 = d->seq_len - d->rolling, H = d->hidden, O = d->pred_len, F = d->nf;
+    const std::vector<float> w0t = transposed(w->w0, H, K0), w1t = transposed(w->w1, H, H), w2t = transposed(w->w2, O, H);
+    std::vector<const float*> dev;
+    ctx->sg.loaded = false;
+    int rc = upload_blob(ctx,
+                         {{w0t.data(), (size_t)K0 * H}, {w->b0, (size_t)H}, {w->ln0_w, (size_t)F * H}, {w->ln0_b, (size_t)F * H},
+                          {w1t.data(), (size_t)H * H}, {w->b1, (size_t)H}, {w->ln1_w, (size_t)F * H}, {w->ln1_b, (size_t)F * H},
+                          {w2t.data(), (size_t)H * O}, {w->b2, (size_t)O}},
+                         &ctx->sg.blob, &dev);
+    if (rc != MPV_OK) return rc;
+    SigmaModel& m = ctx->sg;
+    m.w0t = dev[0]; m.b0 = dev[1]; m.ln0w = dev[2]; m.ln0b = dev[3]; m.w1t = dev[4]; m.b1 = dev[5];
+    m.ln1w = dev[6]; m.ln1b = dev[7]; m.w2t = dev[8]; m.b2 = dev[9];
+    m.d = *d;
+    m.loaded = true;
+    return MPV_OK;
+}
+
+int mpv_sigma_head(mpv_ctx* ctx, const float* series, int32_t V, int64_t L, int32_t n_windows, int64_t first, int64_t step,
+                   const float* mean, const float* std, float add_eps, float* gx) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_sigma_head: ctx is NULL");
+    if (!ctx->sg.loaded) return mpv_fail(ctx, MPV_ESTATE, "mpv_sigma_head: call mpv_sigma_load first");
+    if (!series || !gx) return mpv_fail(ctx, MPV_EINVAL, "mpv_sigma_head: NULL argument");
+    if ((mean == nullptr) != (std == nullptr)) return mpv_fail(ctx, MPV_EINVAL, "mpv_sigma_head: give both mean and std or neither");
+    if (V < 0 || n_windows < 0 || first < 0 || step < 0) return mpv_fail(ctx, MPV_EINVAL, "mpv_sigma_head: negative extent");
+    if (n_windows > 0 && first + (int64_t)(n_windows - 1) * step + ctx->sg.d.seq_len > L)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_sigma_head: last window runs past the series");
+    DeviceGuard g(ctx->device);
+    return launch_sigma_head(ctx, series, V, L, n_windows, first, step, mean, std, add_eps, gx);
+}
+
+int mpv_reduce(mpv_ctx* ctx, const float* samples, int32_t W, int64_t R, int32_t F, int32_t S, const float* std,
+               const float* mean, float* mpv, float* pred_mean, float* mpv_feat) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_reduce: ctx is NULL");
+    if (!samples || !mpv || !pred_mean) return mpv_fail(ctx, MPV_EINVAL, "mpv_reduce: NULL argument");
+    if (W < 0 || W > 65535 || R < 1 || F < 1 || F > MPV_MAX_NF || S < 1)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_reduce: need 0 <= W <= 65535, R >= 1, 1 <= F <= 4, S >= 1");
+    if ((mean == nullptr) != (std == nullptr)) return mpv_fail(ctx, MPV_EINVAL, "mpv_reduce: give both mean and std or neither");
+    DeviceGuard g(ctx->device);
+    return launch_mpv_reduce(ctx, samples, W, R, F, S, std, mean, mpv, pred_mean, mpv_feat);
+}
+
+int mpv_chain_timing_enable(mpv_ctx* ctx, int on) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_chain_timing_enable: ctx is NULL");
+    ctx->timing = on != 0;
+    return MPV_OK;
+}
+
+int mpv_chain_timing(mpv_ctx* ctx, double* avg_ms, int64_t* launches) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_chain_timing: ctx is NULL");
+    if (!avg_ms || !launches) return mpv_fail(ctx, MPV_EINVAL, "mpv_chain_timing: NULL argument");
+    DeviceGuard g(ctx->device);
+    MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double total = 0.0;
+    for (auto& e : ctx->events) {
+        float ms = 0.0f;
+        MPV_HIP_TRY(ctx, hipEventElapsedTime(&ms, e.first, e.second));
+        total += ms;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    *launches = (int64_t)ctx->events.size();
+    *avg_ms = ctx->events.empty() ? 0.0 : total / (double)ctx->events.size();
+    ctx->events.clear();
+    return MPV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// Shared internals of libmpv_hip (not part of the ABI; the ABI is include/mpv_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "mpv_hip.h"
+
+struct NsdiffModel {
+    bool loaded = false;
+    int steps = 0, nf = 0;
+    float* blob = nullptr;        // one device allocation, sub-pointers below
+    const float *w1t, *w2, *w3, *b1, *b2, *b3, *e1, *e2, *e3, *w4, *ws, *b4, *bs, *coef;
+};
+
+struct SigmaModel {
+    bool loaded = false;
+    mpv_sigma_desc d{};
+    float* blob = nullptr;
+    // transposed ([in][out]) weights for coalesced reads, LayerNorm affine as given
+    const float *w0t, *b0, *ln0w, *ln0b, *w1t, *b1, *ln1w, *ln1b, *w2t, *b2;
+};
+
+struct mpv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    NsdiffModel ns;
+    SigmaModel sg;
+    double* reduce_ws = nullptr;   // partial sums of mpv_reduce
+    size_t reduce_ws_bytes = 0;
+    // chain-kernel timing (HIP events on the launch stream)
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    int cu_count = 256;
+    size_t max_lds = 0;
+};
+
+int mpv_fail(mpv_ctx* ctx, int code, const std::string& msg);
+
+#define MPV_HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return mpv_fail(ctx, MPV_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// launchers implemented next to their kernels
+int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* gx,
+                        const float* noise, float* samples);
+int launch_philox_dump(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out);
+int launch_sigma_head(mpv_ctx* ctx, const float* series, int V, int64_t L, int n_windows, int64_t first, int64_t step,
+                      const float* mean, const float* std, float add_eps, float* gx);
+int launch_mpv_reduce(mpv_ctx* ctx, const float* samples, int W, int64_t R, int F, int S, const float* std,
+                      const float* mean, float* mpv, float* pred_mean, float* mpv_feat);

@@ -1,0 +1,417 @@
+// Fused NsDiff reverse-diffusion chain for gfx950 (MI355X).
+//
+// One launch runs, for every chain (window w, node b, horizon o, sample s), ALL T steps of
+// p_sample_loop (reference NsDiff/nsdiff_utils.py:271-284): per step the conditional MLP
+// (NsDiff/denoise.py:35-51), the quadratic posterior (nsdiff_utils.py:111-158) and the
+// noise injection, and writes only y_0.  The state y never leaves registers.
+//
+// Mapping to the hardware
+//   * a wave owns 32 chains (lane&31 = chain, consecutive chains = consecutive samples s of
+//     one (w,b,o) row, so the final store is a coalesced 128-B segment per feature);
+//   * the two 128x128 layers run on the exact-fp32 matrix pipe, v_mfma_f32_32x32x2_f32:
+//     D[out][chain] += W[out][k] * H[k][chain].  A = weights (lane&31 = out row of the tile,
+//     lane>>5 = k), B = activations (lane&31 = chain, lane>>5 = k).  The accumulator layout
+//     (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31) IS the B-operand layout of the
+//     next layer once k-steps are enumerated as (tile, reg): register `reg` of half-wave h holds
+//     hidden unit 32*tile + (reg&3) + 8*(reg>>2) + 4*h, and a k-step takes the same register
+//     from both halves.  So the activations never move between lanes; only the sum of squares
+//     for F.normalize crosses the two half-waves (one DPP/permute per layer);
+//   * W2 and W3 live in LDS for the lifetime of the workgroup in their native [out][in]
+//     layout with a 132-float row stride: one ds_read_b128 per lane fetches the A operands of
+//     four consecutive k-steps, bank-conflict free;
+//   * layer 1 (K = 3F), the two heads (N = F) and all elementwise work run on the VALU,
+//     which the second wave of each SIMD overlaps with the first wave's MFMA phase.
+//
+// Algorithmic work per chain-step: 2*128*(128+128) + 2*128*3F + 2*2*128*F = 256*(256+5F) flop
+// (SURVEY.md section 8d), ~98% of it in the two MFMA layers -> roofline: fp32 MFMA peak.
+#include "mpv_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int HID = MPV_HIDDEN;
+constexpr int WROW = 132;  // padded LDS row stride in floats: (33*i) mod 16 distinct over 16 lanes
+constexpr int WAVES = 8;
+constexpr int THREADS = WAVES * 64;
+constexpr int TILE = 32;   // chains per wave
+
+// LDS carve (floats); every offset is a multiple of 4 floats (16 B)
+constexpr int L_W2 = 0;
+constexpr int L_W3 = L_W2 + HID * WROW;
+constexpr int L_W1T = L_W3 + HID * WROW;              // [3F][128]
+constexpr int L_B1 = L_W1T + 3 * MPV_MAX_NF * HID;
+constexpr int L_B2 = L_B1 + HID;
+constexpr int L_B3 = L_B2 + HID;
+constexpr int L_W4 = L_B3 + HID;                      // [F][128]
+constexpr int L_WS = L_W4 + MPV_MAX_NF * HID;         // [F][128]
+constexpr int L_HB = L_WS + MPV_MAX_NF * HID;         // b4[4], bs[4]
+constexpr int L_FLOATS = L_HB + 8;
+
+struct ChainArgs {
+    const float *w1t, *w2, *w3, *b1, *b2, *b3, *e1, *e2, *e3, *w4, *ws, *b4, *bs, *coef;
+    const float* y0hat;
+    const float* gx;
+    const float* noise;
+    float* samples;
+    long long n_chains;
+    long long n_tiles;
+    long long noise_kstride;   // B*P*O*F
+    int T, B, O, S, P, C;
+    unsigned seed_lo, seed_hi, off_lo;
+};
+
+// ---- softplus(x) = x > 20 ? x : log1p(exp(x))  (torch.nn.functional.softplus defaults) ----
+// Raw v_exp_f32 / v_log_f32 (no denormal pre-scaling): exp2 underflowing to 0 gives softplus 0
+// where the true value is < 2^-126, and 1+e is always a normal number.  For e < 2^-12 the
+// series e - e^2/2 replaces log(1+e), whose argument would have lost e's low bits.
+__device__ __forceinline__ float softplus_dev(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+    float l = __builtin_amdgcn_logf(1.0f + e) * 0.693147180559945309f;
+    const float small = __builtin_fmaf(-0.5f * e, e, e);
+    l = (e < 2.44140625e-4f) ? small : l;
+    return (x > 20.0f) ? x : l;
+}
+
+// ---- Philox4x32-10 + Box-Muller -------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void philox_normals(unsigned long long chain, unsigned k, unsigned seed_lo, unsigned seed_hi,
+                                               unsigned off_lo, float (&z)[4]) {
+    unsigned x[4];
+    philox4x32_10((unsigned)chain, (unsigned)(chain >> 32), k, off_lo, seed_lo, seed_hi, x);
+    const float inv24 = 5.9604644775390625e-8f;  // 2^-24
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float u1 = ((float)(x[2 * i] >> 8) + 0.5f) * inv24;      // (0,1)
+        const float u2 = (float)(x[2 * i + 1] >> 8) * inv24;            // [0,1) revolutions
+        const float rad = sqrtf(-2.0f * logf(u1));
+        z[2 * i] = rad * __builtin_amdgcn_cosf(u2);
+        z[2 * i + 1] = rad * __builtin_amdgcn_sinf(u2);
+    }
+}
+
+// hidden-unit index of register (4q+e) of out-tile j in half-wave h is 32j + 8q + 4h + e
+__device__ __forceinline__ int hbase(int j, int q, int h) { return 32 * j + 8 * q + 4 * h; }
+
+// v <- normalize(softplus(gamma * v)) over the 128 hidden units of each chain
+__device__ __forceinline__ void activate(float (&v)[64], const float* __restrict__ gamma_row, int h) {
+    float ss = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma_row + hbase(j, q, h));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float s = softplus_dev(gm[e] * v[j * 16 + q * 4 + e]);
+                v[j * 16 + q * 4 + e] = s;
+                ss = __builtin_fmaf(s, s, ss);
+            }
+        }
+    }
+    ss += __shfl_xor(ss, 32);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize eps
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] *= inv;
+}
+
+// acc = bias + W . hin on the fp32 matrix pipe; result copied back over hin
+__device__ __forceinline__ void mfma_layer(const float* __restrict__ Ws, const float* __restrict__ bias,
+                                           float (&hv)[64], int r, int h) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + hbase(j, q, h));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j][q * 4 + e] = b[e];
+        }
+    }
+    const float* wrow = Ws + r * WROW + 4 * h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(wrow + 32 * j * WROW + 32 * jt + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], hv[jt * 16 + q * 4 + e], acc[j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) hv[j * 16 + i] = acc[j][i];
+}
+
+struct StepCoef {
+    float c1, c2, q1, q2, c4, l4, l2, n1, bt, invr, omr, aoma, bt1, a, sp, sa, k1, k2;
+};
+
+// One element of p_sample / p_sample_t_1to0 (nsdiff_utils.py:131-157, 209-239).  Contraction is
+// off so each product and sum rounds once, as the reference's eager fp32 tensor ops do.
+__device__ __forceinline__ float posterior(const StepCoef& c, float y, float mu, float g, float eps, float sig, float z,
+                                           bool last) {
+#pragma clang fp contract(off)
+    const float lam1 = c.c1 * g - sig * c.c2;
+    const float lam2 = g * g * c.q1 * c.q2 - sig * g * c.c4;
+    const float sy0 = (-lam1 + sqrtf(lam1 * lam1 - c.l4 * lam2)) / c.l2;   // NaN if disc < 0, as reference
+    const float nz = c.n1 * g + c.bt * sy0;
+    const float y0r = c.invr * (y - c.omr * mu - eps * sqrtf(nz));
+    if (last) return y0r;
+    const float s1 = c.q1 * g + c.aoma * sy0;
+    const float s2 = c.q2 * g + c.bt1 * sy0;
+    const float den = c.a * s2 + s1;
+    const float g0 = c.sp * s1 / den;
+    const float g1 = c.sa * s2 / den;
+    const float g2 = (c.k1 * s2 + c.k2 * s1) / den;
+    return g0 * y0r + g1 * y + g2 * mu + sqrtf(sig) * z;
+}
+
+template <int F, bool PHILOX>
+__global__ __launch_bounds__(THREADS, 2) void nsdiff_chain_kernel(const ChainArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    // ---- stage the weights once per workgroup -------------------------------------------
+    for (int i = threadIdx.x; i < HID * HID / 4; i += THREADS) {
+        const int row = i >> 5, c4 = (i & 31) * 4;
+        *reinterpret_cast<f32x4*>(lds + L_W2 + row * WROW + c4) = *reinterpret_cast<const f32x4*>(p.w2 + row * HID + c4);
+        *reinterpret_cast<f32x4*>(lds + L_W3 + row * WROW + c4) = *reinterpret_cast<const f32x4*>(p.w3 + row * HID + c4);
+    }
+    for (int i = threadIdx.x; i < 3 * F * HID; i += THREADS) lds[L_W1T + i] = p.w1t[i];
+    for (int i = threadIdx.x; i < HID; i += THREADS) {
+        lds[L_B1 + i] = p.b1[i];
+        lds[L_B2 + i] = p.b2[i];
+        lds[L_B3 + i] = p.b3[i];
+    }
+    for (int i = threadIdx.x; i < F * HID; i += THREADS) {
+        lds[L_W4 + i] = p.w4[i];
+        lds[L_WS + i] = p.ws[i];
+    }
+    if (threadIdx.x < F) {
+        lds[L_HB + threadIdx.x] = p.b4[threadIdx.x];
+        lds[L_HB + 4 + threadIdx.x] = p.bs[threadIdx.x];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r_lane = lane & 31, h_lane = lane >> 5;
+
+    for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < p.n_tiles; tile += (long long)gridDim.x * WAVES) {
+        const long long n_raw = tile * TILE + r_lane;
+        const bool valid = n_raw < p.n_chains;
+        const long long n = valid ? n_raw : p.n_chains - 1;
+        const int s = (int)(n % p.S);
+        const long long row = n / p.S;            // (w*B + b)*O + o
+        const int o = (int)(row % p.O);
+        const long long gi = row / p.O;           // w*B + b
+        const int b = (int)(gi % p.B);
+        const long long w = gi / p.B;
+
+        float g[F], mu[F], y[F], z[4];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            g[f] = p.gx[row * F + f];
+            mu[f] = p.y0hat ? p.y0hat[row * F + f] : 0.0f;
+        }
+        long long nbase = 0;
+        if (!PHILOX) {
+            const int c = s / p.P, pp = s - c * p.P;
+            nbase = (((w * p.C + c) * p.T) * ((long long)p.B * p.P) + (long long)b * p.P + pp) * ((long long)p.O * F) +
+                    (long long)o * F;
+        }
+        // y_T = sqrt(g) * z_T + mu       (nsdiff_utils.py:273-274)
+        if (PHILOX) {
+            philox_normals((unsigned long long)n, 0u, p.seed_lo, p.seed_hi, p.off_lo, z);
+        } else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) z[f] = p.noise[nbase + f];
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+#pragma clang fp contract(off)
+            y[f] = sqrtf(g[f]) * z[f] + mu[f];
+        }
+
+#pragma nounroll
+        for (int t = p.T - 1; t >= 0; --t) {
+            // Every LDS operand below is loop-invariant in t; left alone, LICM hoists ~600 of
+            // them out of the step loop and spills them to scratch.  Re-materialise the lane
+            // coordinates through an opaque move each step so the loads stay in the loop.
+            int h = h_lane, r = r_lane;
+            asm volatile("" : "+v"(h), "+v"(r));
+            // the step's normal draw (k = T - t); unused at t == 0
+            if (t > 0) {
+                if (PHILOX) {
+                    philox_normals((unsigned long long)n, (unsigned)(p.T - t), p.seed_lo, p.seed_hi, p.off_lo, z);
+                } else {
+#pragma unroll
+                    for (int f = 0; f < F; ++f) z[f] = p.noise[nbase + (long long)(p.T - t) * p.noise_kstride + f];
+                }
+            }
+            // ---- layer 1 on the VALU: h = b1 + W1 . [y, y0hat, g] ---------------------------
+            float hv[64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int base = hbase(j, q, h);
+                    f32x4 a = *reinterpret_cast<const f32x4*>(lds + L_B1 + base);
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        a += *reinterpret_cast<const f32x4*>(lds + L_W1T + f * HID + base) * y[f];
+                        a += *reinterpret_cast<const f32x4*>(lds + L_W1T + (F + f) * HID + base) * mu[f];
+                        a += *reinterpret_cast<const f32x4*>(lds + L_W1T + (2 * F + f) * HID + base) * g[f];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[j * 16 + q * 4 + e] = a[e];
+                }
+            }
+            activate(hv, p.e1 + (long long)t * HID, h);
+            // ---- layers 2, 3 on the fp32 matrix pipe ---------------------------------------
+            mfma_layer(lds + L_W2, lds + L_B2, hv, r, h);
+            activate(hv, p.e2 + (long long)t * HID, h);
+            mfma_layer(lds + L_W3, lds + L_B3, hv, r, h);
+            activate(hv, p.e3 + (long long)t * HID, h);
+            // ---- heads: eps = W4 h + b4 ; sigma = softplus(Ws softplus(h) + bs) --------------
+            float ea[F], sa[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) ea[f] = sa[f] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int base = hbase(j, q, h);
+                    float sp[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sp[e] = softplus_dev(hv[j * 16 + q * 4 + e]);
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(lds + L_W4 + f * HID + base);
+                        const f32x4 wsg = *reinterpret_cast<const f32x4*>(lds + L_WS + f * HID + base);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ea[f] = __builtin_fmaf(w4[e], hv[j * 16 + q * 4 + e], ea[f]);
+                            sa[f] = __builtin_fmaf(wsg[e], sp[e], sa[f]);
+                        }
+                    }
+                }
+            }
+            // ---- posterior ----------------------------------------------------------------
+            const float* cr = p.coef + t * MPV_COEF_COLS;
+            const StepCoef c = {cr[0], cr[1], cr[2],  cr[3],  cr[4],  cr[5],  cr[6],  cr[7],  cr[8],
+                                cr[9], cr[10], cr[11], cr[12], cr[13], cr[14], cr[15], cr[16], cr[17]};
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const float eps = ea[f] + __shfl_xor(ea[f], 32) + lds[L_HB + f];
+                const float sig = softplus_dev(sa[f] + __shfl_xor(sa[f], 32) + lds[L_HB + 4 + f]);
+                y[f] = posterior(c, y[f], mu[f], g[f], eps, sig, z[f], t == 0);
+            }
+        }
+        if (valid && h_lane == 0) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) p.samples[(row * F + f) * p.S + s] = y[f];
+        }
+    }
+}
+
+__global__ void philox_dump_kernel(float* out, long long n_chains, int T, int F, unsigned seed_lo, unsigned seed_hi,
+                                   unsigned off_lo) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chains * T) return;
+    const long long n = i / T;
+    const int k = (int)(i % T);
+    float z[4];
+    philox_normals((unsigned long long)n, (unsigned)k, seed_lo, seed_hi, off_lo, z);
+    for (int f = 0; f < F; ++f) out[i * F + f] = z[f];
+}
+
+template <int F>
+int launch_f(mpv_ctx* ctx, const ChainArgs& a, bool philox, int grid) {
+    const size_t lds_bytes = L_FLOATS * sizeof(float);
+    auto kp = nsdiff_chain_kernel<F, true>;
+    auto kn = nsdiff_chain_kernel<F, false>;
+    MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(philox ? kp : kn),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (philox)
+        hipLaunchKernelGGL(kp, dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(kn, dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, a);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+}  // namespace
+
+int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* gx,
+                        const float* noise, float* samples) {
+    const NsdiffModel& m = ctx->ns;
+    ChainArgs a{};
+    a.w1t = m.w1t; a.w2 = m.w2; a.w3 = m.w3; a.b1 = m.b1; a.b2 = m.b2; a.b3 = m.b3;
+    a.e1 = m.e1; a.e2 = m.e2; a.e3 = m.e3; a.w4 = m.w4; a.ws = m.ws; a.b4 = m.b4; a.bs = m.bs; a.coef = m.coef;
+    a.y0hat = y0hat; a.gx = gx; a.noise = noise; a.samples = samples;
+    a.T = m.steps; a.B = s.nodes; a.O = s.pred_len; a.S = s.n_samples; a.P = s.chunk; a.C = s.n_samples / s.chunk;
+    a.n_chains = (long long)s.n_windows * s.nodes * s.pred_len * s.n_samples;
+    a.n_tiles = (a.n_chains + TILE - 1) / TILE;
+    a.noise_kstride = (long long)s.nodes * s.chunk * s.pred_len * m.nf;
+    a.seed_lo = (unsigned)s.seed;
+    a.seed_hi = (unsigned)(s.seed >> 32) + (unsigned)(s.offset >> 32);
+    a.off_lo = (unsigned)s.offset;
+    if (a.n_chains == 0) return MPV_OK;
+    const long long wg_needed = (a.n_tiles + WAVES - 1) / WAVES;
+    const int grid = (int)(wg_needed < ctx->cu_count ? wg_needed : ctx->cu_count);   // 1 workgroup per CU (LDS-bound)
+    if ((size_t)L_FLOATS * sizeof(float) > ctx->max_lds)
+        return mpv_fail(ctx, MPV_EINVAL, "device LDS too small for the resident-weight chain kernel");
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing) {
+        MPV_HIP_TRY(ctx, hipEventCreate(&e0));
+        MPV_HIP_TRY(ctx, hipEventCreate(&e1));
+        MPV_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    }
+    int rc;
+    const bool philox = (noise == nullptr);
+    switch (m.nf) {
+        case 1: rc = launch_f<1>(ctx, a, philox, grid); break;
+        case 2: rc = launch_f<2>(ctx, a, philox, grid); break;
+        case 3: rc = launch_f<3>(ctx, a, philox, grid); break;
+        case 4: rc = launch_f<4>(ctx, a, philox, grid); break;
+        default: return mpv_fail(ctx, MPV_EINVAL, "nf must be 1..4");
+    }
+    if (rc != MPV_OK) return rc;
+    if (ctx->timing) {
+        MPV_HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        ctx->events.emplace_back(e0, e1);
+    }
+    return MPV_OK;
+}
+
+int launch_philox_dump(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out) {
+    const NsdiffModel& m = ctx->ns;
+    const long long total = (long long)n_chains * m.steps;
+    if (total == 0) return MPV_OK;
+    const int threads = 256;
+    const long long blocks = (total + threads - 1) / threads;
+    hipLaunchKernelGGL(philox_dump_kernel, dim3((unsigned)blocks), dim3(threads), 0, ctx->stream, out, (long long)n_chains,
+                       m.steps, m.nf, (unsigned)seed, (unsigned)(seed >> 32) + (unsigned)(offset >> 32), (unsigned)offset);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}

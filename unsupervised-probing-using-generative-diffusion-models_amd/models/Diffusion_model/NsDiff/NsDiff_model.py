@@ -1,0 +1,229 @@
+"""NsDiff model objects -- the reference's duck-typed "operator API" for the MPV path.
+
+Mirrors models/Diffusion_model/NsDiff/NsDiff_model.py of the reference:
+`NsDiff_model_variants` (:272-495) and the g-only / full `NsDiff_model` (:17-268).  Same
+constructor arguments, attribute names (`scaler`, `scaler_mean`, `scaler_std`, `model`,
+`cond_pred_model`, `cond_pred_model_g`, `configs`), parameter names and
+`evaluation_step(batch) -> (outs [B, pred_len, F, n_z_samples] on CPU, batch_y | None)`.
+
+What differs is where the arithmetic runs: `evaluation_step` hands the window batch to the
+HIP library (sigma head -> fused T-step chain sampler), and `sample_windows` does the same
+for many sliding windows of a resident series in ONE launch, which is what the harness
+uses.  Nothing here computes the path with torch ops.
+
+Noise: `noise_source = "philox"` (default) draws on device (Philox4x32-10, seed taken from
+torch's CPU generator so `torch.manual_seed` makes runs repeatable); `"torch_cpu"` draws
+every normal with `torch.randn` on the host in the reference's exact order
+ and uploads it, which reproduces a reference CPU run under the same
+`torch.manual_seed` to fp32 round-off.  Select with net_param / infer_params key
+`noise_source`, or pass `noise=` explicitly.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import g_backbone as G
+from .NsDiff_net import NsDiff_net
+from .native_handle import NativeHandle
+
+_F_BACKBONE_MSG = (
+    "train_model_select={!r} needs the non-stationary-transformer mean backbone f(x) "
+    "(reference NsDiff/mu_backbone.py, built on the absent torch_timeseries package); it is the next "
+    "row of the scope table (SURVEY.md 8f.1) and is not built yet.  Variants without f(x) "
+    "('cond_var', 'Guassian', 'pretrain_g') are supported, and evaluation_step accepts a "
+    "precomputed y_0_hat via `y0hat=`.")
+
+
+def _draw_seed() -> int:
+    """One 62-bit Philox key from torch's default CPU generator (repeatable under manual_seed)."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+class _NsDiffBase(nn.Module):
+    EPS = 10e-8   # (sic) reference NsDiff_model.py:39
+
+    def _init_common(self, net_param):
+        self.device = net_param["device"]
+        self.dataset_nf = net_param["dataset_nf"]
+        self.windows = net_param["windows"]
+        self.pred_len = net_param["pred_len"]
+        self.rolling_length = net_param["rolling_length"]
+        self.seq_len = net_param["seq_len"] = self.windows
+        self.label_len = net_param["label_len"] = self.windows // 2
+        self.diffusion_steps = net_param["diffusion_steps"]
+        self.configs = SimpleNamespace(**net_param)
+        self.scaler = net_param["scaler_type"]
+        self.noise_source = net_param.get("noise_source", "philox")
+        if self.noise_source not in ("philox", "torch_cpu"):
+            raise ValueError("noise_source must be 'philox' or 'torch_cpu'")
+        self.register_buffer("scaler_mean", torch.zeros(self.dataset_nf))
+        self.register_buffer("scaler_std", torch.zeros(self.dataset_nf))
+        object.__setattr__(self, "_native", NativeHandle())
+        self._native.bind(self)
+
+    # ---- scaler (reference :100-110) ------------------------------------------------
+    def scaler_fit(self, data):
+        std = data.std(axis=0)
+        std[std == 0] = 1
+        self.scaler_mean = data.mean(axis=0)
+        self.scaler_std = std
+
+    def scaler_transform(self, data):
+        return (data - self.scaler_mean) / self.scaler_std
+
+    def scaler_inverse_transform(self, data):
+        return (data * self.scaler_std) + self.scaler_mean
+
+    # ---- keep the device copy of the weights coherent ------------------------------------
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._native.mark_dirty()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._native.mark_dirty()
+        return out
+
+    def refresh_native(self):
+        """Call after editing parameters in place."""
+        self._native.mark_dirty()
+
+    def _upload_native(self, ctx):
+        if getattr(self, "model", None) is not None:
+            w = self.model.native_weights()
+            ctx.load_nsdiff(self.diffusion_steps, self.dataset_nf, w["lin_w"], w["lin_b"], w["embed"], w["eps_w"],
+                            w["eps_b"], w["sig_w"], w["sig_b"], w["coef"])
+        g = getattr(self, "cond_pred_model_g", None)
+        if g is not None:
+            ctx.load_sigma(g.seq_len, g.kernel_size, g.pred_len, g.enc_in, g.hidden_size, g.native_weights())
+
+    def native_context(self):
+        return self._native.context()
+
+    # ---- noise in the reference's draw order ---------------------------------------------
+    def host_noise(self, n_windows: int, nodes: int) -> torch.Tensor:
+        """All normals of `n_windows` evaluation_step calls, drawn with torch.randn on the CPU in
+        the reference's order: window, chunk, draw k=0..T-1, tensor [nodes*P, O, F]."""
+        P, S = int(self.configs.parallel_sample), int(self.configs.n_z_samples)
+        shape = (n_windows, S // P, self.diffusion_steps, nodes * P, self.pred_len, self.dataset_nf)
+        return torch.randn(shape)
+
+    def _prior_variance(self, ctx, series, n_windows, first, step, scaled_input: bool):
+        raise NotImplementedError
+
+    def _check_sampling_config(self):
+        P, S = int(self.configs.parallel_sample), int(self.configs.n_z_samples)
+        if P < 1 or S < 1 or S % P != 0:
+            # the reference floors n_z_samples // parallel_sample and then trips its shape assert
+            raise AssertionError("n_z_samples ({}) must be a positive multiple of parallel_sample ({})".format(S, P))
+        return S, P
+
+    def sample_windows(self, series: torch.Tensor, n_windows: int, first: int = 0, step: int = 1, *,
+                       scale_input: bool = False, y0hat: Optional[torch.Tensor] = None,
+                       noise: Optional[torch.Tensor] = None, seed: Optional[int] = None, offset: int = 0):
+        """Batched device path: series [V, L, F] (resident, sub-sampled) -> samples
+        [n_windows, V, pred_len, F, n_z_samples] on device, plus the gx it used.
+
+        Window w covers series[:, first + w*step : first + w*step + windows].  With
+        scale_input the scaler is fused into the load (raw series in); otherwise the series
+        must already be scaled.  One sigma-head launch and one chain launch in total.
+        """
+        if getattr(self, "model", None) is None:
+            raise RuntimeError("this model has no diffusion network (train_model_select={!r})".format(
+                getattr(self, "train_model_select", None)))
+        S, P = self._check_sampling_config()
+        ctx = self._native.context()
+        series = series.to(device=ctx.device, dtype=torch.float32).contiguous()
+        gx = self._prior_variance(ctx, series, n_windows, first, step, scale_input)
+        if y0hat is not None:
+            y0hat = y0hat.to(device=ctx.device, dtype=torch.float32).contiguous().reshape(gx.shape)
+        if noise is None and self.noise_source == "torch_cpu":
+            noise = self.host_noise(n_windows, series.shape[0])
+        if noise is not None:
+            noise = noise.to(device=ctx.device, dtype=torch.float32).contiguous()
+        elif seed is None:
+            seed = _draw_seed()
+        samples = ctx.sample(gx, y0hat, S, P, noise=noise, seed=seed or 0, offset=offset)
+        return samples, gx
+
+    def _evaluation_step(self, batch, y0hat, noise):
+        if batch.dim() != 3 or batch.shape[1] < self.windows:
+            raise ValueError("batch must be [B, >= windows ({}), F], got {}".format(self.windows, tuple(batch.shape)))
+        batch_y = None
+        if batch.shape[1] - self.windows >= self.pred_len:
+            batch_y = batch[:, self.windows:, :].to(self.device)
+            assert batch_y.size(1) == self.pred_len, "pred_len is not equal to the length of the prediction"
+        x = batch[:, : self.windows, :]
+        if noise is not None and noise.dim() != 6:
+            noise = noise.reshape(1, -1, self.diffusion_steps, x.shape[0] * int(self.configs.parallel_sample),
+                                  self.pred_len, self.dataset_nf)
+        samples, _ = self.sample_windows(x, 1, 0, 1, y0hat=y0hat, noise=noise)
+        outs = samples[0].cpu()                                   # [B, O, F, S], the reference's `outs`
+        assert tuple(outs.shape[1:]) == (self.pred_len, self.dataset_nf, int(self.configs.n_z_samples))
+        return outs, batch_y
+
+
+class NsDiff_model_variants(_NsDiffBase):
+    """Ablation family of the reference (:272-495).  'cond_var' (sigma head, zero mean) and
+    'Guassian' (sic: unit variance, zero mean) need no f(x) backbone and are fully native."""
+
+    def __init__(self, net_param, train_model_select):
+        super().__init__()
+        self._init_common(net_param)
+        self.train_model_select = train_model_select
+        if train_model_select not in ("Guassian", "cond_mean", "cond_var", "wo_UANS"):
+            raise ValueError("train_model_select should be in Guassian/cond_mean/cond_var")
+        if train_model_select in ("cond_mean", "wo_UANS"):
+            raise NotImplementedError(_F_BACKBONE_MSG.format(train_model_select))
+        self.model = NsDiff_net(self.configs, self.device)
+        self.cond_pred_model = None
+        self.cond_pred_model_g = None
+        if train_model_select == "cond_var":
+            self.cond_pred_model_g = G.SigmaEstimation(self.windows, self.pred_len, self.dataset_nf, 512,
+                                                       self.rolling_length, native=self._native)
+
+    def _prior_variance(self, ctx, series, n_windows, first, step, scale_input):
+        if self.cond_pred_model_g is None:                         # 'Guassian': gx = 1  (:457-458)
+            return torch.ones((n_windows, series.shape[0], self.pred_len, self.dataset_nf), device=ctx.device)
+        mean = self.scaler_mean if scale_input else None
+        std = self.scaler_std if scale_input else None
+        return ctx.sigma_head(series, n_windows, first, step, mean, std, add_eps=self.EPS)     # + EPS (:450)
+
+    def evaluation_step(self, batch, noise: Optional[torch.Tensor] = None):
+        return self._evaluation_step(batch, None, noise)
+
+
+class NsDiff_model(_NsDiffBase):
+    """Plain NsDiff (:17-268).  The g-only configuration ('pretrain_g', the shipped
+    ews_results/NsDiff_preg checkpoint) is native.  The full model needs f(x); until that
+    backbone is built, `evaluation_step(batch, y0hat=...)` samples around a supplied mean."""
+
+    def __init__(self, net_param, train_model_select, pretrain_f_path="results/pre_model_F",
+                 pretrain_g_path="results/pre_model_G"):
+        super().__init__()
+        self._init_common(net_param)
+        self.train_model_select = train_model_select
+        self.load_pretrain = net_param.get("load_pretrain", False)
+        self.freeze_pretrain = net_param.get("freeze_pretrain", False)
+        if train_model_select == "pretrain_g":
+            self.cond_pred_model_g = G.SigmaEstimation(self.windows, self.pred_len, self.dataset_nf, 512,
+                                                       self.rolling_length, native=self._native)
+        elif train_model_select in ("NsDiff_model", "pretrain_f"):
+            raise NotImplementedError(_F_BACKBONE_MSG.format(train_model_select))
+        else:
+            raise ValueError("train_model_select should be in ['NsDiff_model', 'pretrain_f', 'pretrain_g']")
+
+    def _prior_variance(self, ctx, series, n_windows, first, step, scale_input):
+        mean = self.scaler_mean if scale_input else None
+        std = self.scaler_std if scale_input else None
+        return ctx.sigma_head(series, n_windows, first, step, mean, std, add_eps=0.0)           # no EPS (:223)
+
+    def evaluation_step(self, batch, y0hat: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
+        if y0hat is None:
+            raise NotImplementedError(_F_BACKBONE_MSG.format(self.train_model_select))
+        return self._evaluation_step(batch, y0hat, noise)

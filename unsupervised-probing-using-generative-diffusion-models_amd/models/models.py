@@ -1,0 +1,17 @@
+"""Model factory -- the operator-API entry point (mirrors reference models/models.py:5-32)."""
+
+
+def diffusion_models(task_model, net_param, **kwargs):
+    if task_model == "NsDiff":
+        from .Diffusion_model.NsDiff.NsDiff_model import NsDiff_model
+        return NsDiff_model(net_param=net_param, train_model_select=kwargs["train_model_select"],
+                            pretrain_f_path=net_param.get("pretrain_f_path") or None,
+                            pretrain_g_path=net_param.get("pretrain_g_path") or None)
+    if task_model == "NsDiff_model_variants":
+        from .Diffusion_model.NsDiff.NsDiff_model import NsDiff_model_variants
+        return NsDiff_model_variants(net_param=net_param, train_model_select=kwargs["train_model_select"])
+    if task_model in ("DiffSTG", "DiffusionTS", "TMDM", "NsDiff_spatial"):
+        raise NotImplementedError(
+            "task_model {!r} is a later row of the hot-path scope table (SURVEY.md section 8): the NsDiff "
+            "pointwise sampler is built first; this model family has no HIP path yet".format(task_model))
+    raise ValueError("the definition  don't exit\n\tyou can define it before using it")
