@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the rolling-window MPV sampling path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one synthetic trajectory: for every rolling window
+(181 of them at BASELINE.json configs[1]) scaler -> sigma head -> N=32 chains x T=50 reverse
+steps -> inverse scaling + variance reduction -> MPV scalar on the host.  Inputs (sub-sampled
+series, weights) are resident in HBM before the timed region.  With N ranks every rank owns a
+trajectory of the same size (weak scaling: windows shard with no data-path collective) and one
+all-gather reassembles the curves.
+
+Prints ONE JSON line (rank 0): metric/value/unit as BASELINE.json names them, plus
+  roofline     -- the chain kernel against the fp32 matrix-pipe peak, timed live with HIP events
+  cpu_baseline -- the CPU oracle (a torch-CPU port of the reference path) on a bounded sample
+  mpv_*_err    -- MPV of the HIP path vs that CPU run on the SAME noise
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+def log(msg):
+    print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def cpu_share() -> int:
+    """Usable host cores: the cgroup CPU quota when there is one, else the affinity mask."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(cores, int(os.environ.get("MPV_CPU_THREADS", cores))))
+
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 flop/clk x 2.4 GHz
+
+CFG = dict(nodes=100, ticks=100_000, sampling_t=10, windows=100, pred_len=100, rolling=50, window_step=5,
+           steps=50, n_z=32, parallel_sample=32, nf=1)
+
+
+def build_model(device, series):
+    from mpv_amd.models.models import diffusion_models
+    from mpv_amd import synthetic
+    net_param = dict(device=device, scaler_type="StandardScaler", task_model="NsDiff_model_variants",
+                     rolling_length=CFG["rolling"], diffusion_schedule="linear", diffusion_steps=CFG["steps"],
+                     beta_start=1e-4, beta_end=0.02, n_z_samples=CFG["n_z"], parallel_sample=CFG["parallel_sample"],
+                     windows=CFG["windows"], pred_len=CFG["pred_len"], dataset_nf=CFG["nf"])
+    model = diffusion_models("NsDiff_model_variants", net_param, train_model_select="cond_var").to(device).eval()
+    return synthetic.seeded_nsdiff_state(model, series, seed=123)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-windows", type=int, default=1, help="windows of the workload timed on the CPU oracle")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus {} but WORLD_SIZE={}: launch with torch.distributed.run".format(args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device: the path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from mpv_amd import synthetic
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+
+    # ---- inputs, resident before timing -------------------------------------------------
+    log("rank %d/%d on %s: generating trajectory" % (rank, world, device))
+    record = synthetic.biomass_trajectory(CFG["nodes"], CFG["ticks"], seed=1000 + rank)
+    full = H.normalize_time_series(record["ys_dynamic"], dynamic_type="biomass")           # [V, ticks, 1]
+    sampled, _ = H.sample_time_series(full, record["ts_dynamic"], CFG["sampling_t"])        # [V, 1000, 1]
+    sampled = sampled.contiguous()
+    n_windows = H.sliding_window_count(sampled.shape[1], CFG["windows"], CFG["window_step"])
+    model = build_model(device, sampled)
+    ctx = model.native_context()
+    series_dev = sampled.to(device)
+    mean_dev, std_dev = model.scaler_mean.float().contiguous(), model.scaler_std.float().contiguous()
+    S, P = CFG["n_z"], CFG["parallel_sample"]
+
+    def step(seed):
+        gx = ctx.sigma_head(series_dev, n_windows, 0, CFG["window_step"], mean_dev, std_dev, add_eps=model.EPS)
+        samples = ctx.sample(gx, None, S, P, seed=seed)
+        mpv, pm, _ = ctx.reduce(samples, std_dev, mean_dev)
+        curve = torch.stack([mpv, pm])                                                      # [2, W]
+        if world > 1:
+            out = torch.empty(world, 2, n_windows, device=device)
+            dist.all_gather_into_tensor(out, curve)
+            curve = out
+        return curve.cpu()                                                                   # host copy = sync
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    log("%d windows resident; warmup" % n_windows)
+    for i in range(args.warmup):
+        step(i)
+        log("warmup step %d done" % i)
+    ctx.timing_enable(True)
+    ctx.timing()                                                                             # drop warmup records
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        curve = step(100 + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = ctx.timing()
+    ctx.timing_enable(False)
+    log("timed %d steps in %.3f s; chain kernel avg %.2f ms" % (args.steps, elapsed, kernel_ms))
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert bool(torch.isfinite(curve).all()), "non-finite MPV curve"
+
+    total_windows = world * n_windows * args.steps
+    value = total_windows / elapsed
+    row_steps = n_windows * CFG["nodes"] * CFG["pred_len"] * S * CFG["steps"]               # chain-steps per launch
+    flop_per_launch = row_steps * 256 * (256 + 5 * CFG["nf"])
+    achieved = flop_per_launch / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    out = {
+        "metric": "rolling windows/sec (N=32, T=50) + MPV max-abs err vs CPU ref",
+        "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "NsDiff cond_var on 100-node BA-graph biomass trajectory (BASELINE configs[1]): "
+                               "windows=100, pred_len=100, rolling=50, N=32 samples, T=50 steps, {} windows per "
+                               "trajectory, one trajectory per GPU per step".format(n_windows),
+                   "windows_per_step_per_gpu": n_windows, "noise": "on-device Philox4x32-10",
+                   "weights": "seeded default init (shipped checkpoints pin T=20)"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                     "kernel": "nsdiff_chain_kernel<1,true>", "kernel_avg_ms": kernel_ms, "launches": launches,
+                     "flop_per_launch": flop_per_launch},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out.update(cpu_baseline_and_parity(model, sampled, args.cpu_windows))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_and_parity(model, sampled, n_cpu_windows):
+    """Time the CPU oracle on the first window(s) of the same workload and compare MPV on shared noise."""
+    from oracle import nsdiff_oracle as O
+    cores = cpu_share()
+    torch.set_num_threads(cores)
+    log("cpu baseline: %d window(s) on %d threads" % (n_cpu_windows, cores))
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = O.NsDiffConfig(CFG["windows"], CFG["pred_len"], CFG["nf"], CFG["rolling"], CFG["steps"],
+                         n_z_samples=CFG["n_z"], parallel_sample=CFG["parallel_sample"])
+    wins = [sampled[:, w * CFG["window_step"]: w * CFG["window_step"] + CFG["windows"], :] for w in range(n_cpu_windows)]
+    rec, cpu_mpv, cpu_out = [], [], []
+    torch.manual_seed(2024)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for w in wins:
+            x = O.scale(w, sd["scaler_mean"], sd["scaler_std"])
+            outs = O.evaluation_step(sd, cfg, x, record=rec)
+            cpu_out.append(outs)
+            cpu_mpv.append(O.mpv_network(outs, sd["scaler_mean"], sd["scaler_std"])[1])
+    cpu_s = time.perf_counter() - t0
+    log("cpu baseline done in %.1f s" % cpu_s)
+    # same windows on the GPU with the very noise the CPU run consumed (reference draw order)
+    per = len(rec) // n_cpu_windows
+    gpu_mpv, samp_err = [], 0.0
+    ctx = model.native_context()
+    for i, w in enumerate(wins):
+        noise = torch.cat([z.reshape(-1) for z in rec[i * per:(i + 1) * per]])
+        x = O.scale(w, sd["scaler_mean"], sd["scaler_std"])
+        outs, _ = model.evaluation_step(x, noise=noise)
+        samp_err = max(samp_err, float((outs - cpu_out[i]).abs().max() / cpu_out[i].abs().max()))
+        mpv, _, _ = ctx.reduce(outs.to(ctx.device).unsqueeze(0).contiguous(), model.scaler_std.float().contiguous(),
+                               model.scaler_mean.float().contiguous())
+        gpu_mpv.append(float(mpv[0]))
+    cpu_mpv, gpu_mpv = np.array(cpu_mpv), np.array(gpu_mpv)
+    return {
+        "cpu_baseline": {"value": n_cpu_windows / cpu_s, "unit": "windows/s", "cores": cores, "kind": "port",
+                         "sample": "first {} of the 181 windows, full N=32 x T=50, oracle/nsdiff_oracle.py "
+                                   "(torch CPU fp32 port of the reference eager path), {:.1f} s".format(n_cpu_windows, cpu_s)},
+        "mpv_max_abs_err": float(np.abs(gpu_mpv - cpu_mpv).max()),
+        "mpv_max_rel_err": float((np.abs(gpu_mpv - cpu_mpv) / np.abs(cpu_mpv)).max()),
+        "samples_max_rel_err": samp_err,
+    }
+
+
+if __name__ == "__main__":
+    main()

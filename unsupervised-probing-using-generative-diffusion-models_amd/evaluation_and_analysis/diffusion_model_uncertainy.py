@@ -1,0 +1,678 @@
+"""Rolling-window MPV harness on the MI355X-native sampler.
+
+Drop-in for the reference's evaluation_and_analysis/diffusion_model_uncertainy.py (sic): the
+public functions keep their names, arguments, error messages, cache-file format (a
+`torch.save`d list of CPU tensors per window) and result-dict keys, so the paper's figure
+scripts can call `uncertainty_ews(...)` / `slbp_sensitivity_ews(...)` unchanged.
+
+What is different underneath (reference line numbers in each docstring):
+  * the reference visits windows one by one (`run_evaluation_cache:323-339`); here all
+    windows of a trajectory are gathered from the resident, sub-sampled series on device and
+    sampled in ONE chain-kernel launch (windows are independent);
+  * scaler transform, sliding-window gather, sigma head, T-step sampling, inverse scaling and
+    the variance reduction all run in HIP kernels behind include/mpv_hip.h;
+  * with torch.distributed initialised, contiguous blocks of windows are sharded over ranks
+    and the per-window scalars are all-gathered (RCCL on GPU ranks, gloo in CPU tests).
+"""
+from __future__ import annotations
+
+import os
+import sys
+from pathlib import Path
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import yaml
+
+from .. import distributed as dist_utils
+
+PROJECT_ROOT = Path(os.environ.get("MPV_PROJECT_ROOT", Path.cwd()))
+
+NETWORK_DYNAMICS = {"SIS", "neuronal", "biomass"}
+DEFAULT_SAMPLE_WINDOW_STEP = {"SIS": 50, "neuronal": 5, "biomass": 5, "SLBP": 10}
+DEFAULT_SAMPLING_T = {"SIS": 0.1, "neuronal": 10, "biomass": 10, "SLBP": 100}
+_TICK = 0.1            # spacing of the stored trajectories (reference :120)
+# windows per chain launch: bounds the [W, V, O, F, S] sample buffer (and host noise in torch_cpu mode)
+MAX_SAMPLE_BYTES = int(os.environ.get("MPV_MAX_SAMPLE_BYTES", 8 << 30))
+
+
+# ----------------------------------------------------------------------------------------
+# paths, configs, caches
+# ----------------------------------------------------------------------------------------
+def _resolve_project_path(path):
+    if path is None:
+        return None
+    path = Path(path)
+    return path if path.is_absolute() else PROJECT_ROOT / path
+
+
+def _dynamic_name(dynamic_type):
+    if dynamic_type is None:
+        return None
+    text = str(dynamic_type)
+    canon = {"sis": "SIS", "slbp": "SLBP", "neuronal": "neuronal", "biomass": "biomass"}
+    return canon.get(text.lower(), text)
+
+
+def _infer_dynamic_type(data_file=None, loaded_data=None):
+    """Record keys first, then the file name (reference :69-85)."""
+    if loaded_data is not None:
+        if "N_values" in loaded_data:
+            return "SLBP"
+        if "tp_values" in loaded_data:
+            return None
+    if data_file is None:
+        return None
+    text = str(data_file).replace("\\", "/").lower()
+    for key in ("slbp", "sis", "neuronal", "biomass"):
+        if key in text:
+            return _dynamic_name(key)
+    return None
+
+
+def normalize_time_series(torch_time_series, dynamic_type=None):
+    """-> [Node, T, F].  2-D network records are [T, Node]; other 2-D input is [T, F] (reference :106-116)."""
+    data = torch.as_tensor(torch_time_series).float()
+    if data.ndim == 3:
+        return data
+    if data.ndim != 2:
+        raise ValueError("time series must have shape [Node, T, F], [T, F], or [T, Node].")
+    if _dynamic_name(dynamic_type) in NETWORK_DYNAMICS:
+        return data.t().unsqueeze(-1)
+    return data.unsqueeze(0)
+
+
+def load_dynamic_data(data_file, dynamic_type=None, map_location="cpu"):
+    """Read a `{ys_dynamic, ts_dynamic, ...}` record (reference :88-103)."""
+    loaded = torch.load(data_file, map_location=map_location)
+    dynamic_type = _dynamic_name(dynamic_type) or _infer_dynamic_type(data_file=data_file, loaded_data=loaded)
+    if "ys_dynamic" not in loaded or "ts_dynamic" not in loaded:
+        raise KeyError("data_file must contain 'ys_dynamic' and 'ts_dynamic'.")
+    return {
+        "torch_time_series": normalize_time_series(loaded["ys_dynamic"], dynamic_type=dynamic_type),
+        "time_data": loaded["ts_dynamic"],
+        "dynamic_type": dynamic_type,
+        "loaded_data": loaded,
+    }
+
+
+def read_model_config(model_save_file):
+    config_path = Path(model_save_file) / "model_trained.yaml"
+    if not config_path.exists():
+        raise FileNotFoundError("model config not found: {}".format(config_path))
+    with open(config_path, "r", encoding="utf-8") as f:
+        return yaml.safe_load(f)
+
+
+def _train_select(method_config):
+    train = method_config.get("train") if method_config else None
+    return train.get("train_model_select") if train is not None else None
+
+
+def _default_device(device):
+    return device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+def load_model_from_dir(model_save_file, device=None, infer_params=None, method_config=None):
+    """<dir>/model_trained{,.yaml} -> (model.eval(), merged net_param) (reference :193-215)."""
+    from ..utils.utils import load_diffusion_model
+
+    model_save_file = Path(model_save_file)
+    method_config = method_config or read_model_config(model_save_file)
+    model, net_param = load_diffusion_model(str(model_save_file / "model_trained"), device=_default_device(device),
+                                            infer_para=infer_params, train_model_select=_train_select(method_config))
+    return model.eval(), net_param
+
+
+def load_sensitivity_model(model_root, model_name, device=None, infer_params=None):
+    """<root>/models/<name>{,.yaml} layout of the SLBP sensitivity sweeps (reference :425-455)."""
+    from ..utils.utils import load_diffusion_model
+
+    model_root = _resolve_project_path(model_root)
+    config_path = model_root / "models" / "{}.yaml".format(model_name)
+    model_path = model_root / "models" / model_name
+    if not config_path.exists():
+        raise FileNotFoundError("model config not found: {}".format(config_path))
+    if not model_path.exists():
+        raise FileNotFoundError("model checkpoint not found: {}".format(model_path))
+    with open(config_path, "r", encoding="utf-8") as f:
+        method_config = yaml.safe_load(f)
+    model, net_param = load_diffusion_model(str(model_path), device=_default_device(device), infer_para=infer_params,
+                                            train_model_select=_train_select(method_config))
+    return model.eval(), method_config, net_param
+
+
+def default_cache_dir(model_save_file, dynamic_type):
+    if model_save_file is not None:
+        return Path(model_save_file)
+    return PROJECT_ROOT / "ews_results" / "model_uncertainy_cache" / "model" / (_dynamic_name(dynamic_type) or "unknown")
+
+
+def data_cache_name(data_file, suffix=""):
+    if data_file is None:
+        return "data{}.pt".format(suffix)
+    data_path = Path(data_file)
+    return "{}{}{}".format(data_path.stem, suffix, data_path.suffix or ".pt")
+
+
+def resolve_cache_path(cache_path, model_save_file, data_file, dynamic_type, suffix=""):
+    if cache_path is None:
+        return default_cache_dir(model_save_file, dynamic_type) / data_cache_name(data_file, suffix=suffix)
+    cache_path = _resolve_project_path(cache_path)
+    return cache_path if cache_path.suffix == ".pt" else cache_path / data_cache_name(data_file, suffix=suffix)
+
+
+def resolve_figure_path(cache_file_path):
+    return Path(cache_file_path).with_suffix(".png")
+
+
+def slbp_sensitivity_cache_path(model_root, model_name, data_trend, sample_window_step=10):
+    return _resolve_project_path(model_root) / "datas" / "{}_pred_future_{}_{}.pt".format(
+        model_name, data_trend, sample_window_step)
+
+
+def _save_tensor_list(data_list, cache_path):
+    """The reference's cache format: one torch.save of a Python list of CPU tensors (:252-256)."""
+    cache_path = Path(cache_path)
+    cache_path.parent.mkdir(parents=True, exist_ok=True)
+    with open(cache_path, "wb") as f:
+        torch.save([t.detach().cpu() for t in data_list], f)
+
+
+def _load_tensor_list(cache_path):
+    with open(cache_path, "rb") as f:
+        data_list = torch.load(f, map_location="cpu")
+    if not isinstance(data_list, list):
+        raise TypeError("cache file must contain a list of tensors: {}".format(cache_path))
+    return data_list
+
+
+def read_sensitivity_pred_future_cache(cache_path):
+    try:
+        return _load_tensor_list(cache_path)
+    except Exception as exc:          # a corrupt cache is recomputed, as in the reference (:494-499)
+        print("warning: failed to read cache {}, recomputing ({})".format(cache_path, exc))
+        return None
+
+
+# ----------------------------------------------------------------------------------------
+# sub-sampling and window arithmetic (integer-exact)
+# ----------------------------------------------------------------------------------------
+def sampling_interval_from_t(sampling_t):
+    """stride = 1 if sampling_t <= 0.1 else max(1, int(sampling_t / 0.1)) -- float division then
+    truncation, reproduced literally (10/0.1 -> 100, 0.3/0.1 -> 2) (reference :119-125)."""
+    if sampling_t is None or sampling_t <= _TICK:
+        return 1
+    return max(1, int(sampling_t / _TICK))
+
+
+def sample_time_series(torch_time_series, time_data, sampling_t, return_numpy_time=True):
+    stride = sampling_interval_from_t(sampling_t)
+    sampled_time = torch.as_tensor(time_data)[::stride]
+    if return_numpy_time:
+        sampled_time = sampled_time.cpu().detach().numpy()
+    return torch_time_series[:, ::stride, :], sampled_time
+
+
+def torch_data_preprocessing_like_slbp(time_data, sampling_t, return_numpy=False):
+    sampled = torch.as_tensor(time_data)[:: sampling_interval_from_t(sampling_t)]
+    return sampled.cpu().detach().numpy() if return_numpy else sampled
+
+
+def sliding_window_count(sampled_length, windows, sample_window_step):
+    return 0 if sampled_length < windows else (sampled_length - windows) // sample_window_step + 1
+
+
+def build_sliding_windows(torch_time_series, time_data, windows, sample_window_step):
+    """[V, L, F] -> (tuple of W views [V, windows, F], time stamp of each window's last sample)
+    (reference :137-147).  Window w = samples [w*step, w*step + windows)."""
+    if torch_time_series.ndim != 3:
+        raise ValueError("torch_time_series must have shape [Node_num, T_obs_num, F].")
+    length = torch_time_series.shape[1]
+    if length < windows:
+        raise ValueError("T_obs_num ({}) is shorter than windows ({}).".format(length, windows))
+    count = sliding_window_count(length, windows, sample_window_step)
+    views = tuple(torch_time_series[:, w * sample_window_step: w * sample_window_step + windows, :] for w in range(count))
+    return views, np.asarray(time_data)[windows - 1:: sample_window_step]
+
+
+def build_slbp_sensitivity_windows(torch_time_series, time_data, windows, pred_len, sampling_t, sample_window_step):
+    """Single series [T, F]: input windows and the matching future windows (reference :467-483)."""
+    series = torch_data_preprocessing_like_slbp(torch_time_series, sampling_t=sampling_t)
+    sampled_time = torch_data_preprocessing_like_slbp(time_data, sampling_t=sampling_t, return_numpy=True)
+    time_points = sampled_time[windows - 1:: sample_window_step]
+    length = series.shape[0]
+    if length < windows:      # torch.unfold's error in the reference
+        raise RuntimeError("maximum size for tensor at dimension 0 is {} but size is {}".format(length, windows))
+    n_in = sliding_window_count(length, windows, sample_window_step)
+    input_datas = tuple(series[w * sample_window_step: w * sample_window_step + windows, :] for w in range(n_in))
+    future = series[windows:, :]
+    if future.shape[0] >= pred_len:
+        n_out = sliding_window_count(future.shape[0], pred_len, sample_window_step)
+        pred_datas = tuple(future[w * sample_window_step: w * sample_window_step + pred_len, :] for w in range(n_out))
+    else:
+        pred_datas = ()
+    return input_datas, pred_datas, time_points
+
+
+def default_sample_window_step(dynamic_type, task_model=None, dataset_config=None):
+    dataset_config = dataset_config or {}
+    if task_model == "DiffSTG" and dataset_config.get("interval_step") is not None:
+        return dataset_config["interval_step"]
+    return DEFAULT_SAMPLE_WINDOW_STEP.get(dynamic_type, 10)
+
+
+def infer_sample_window_step_from_cache(sampled_length, windows, cache_len, fallback_step):
+    """Recover the window step a cache was written with from its length (reference :163-182)."""
+    if cache_len <= 0 or sampled_length < windows:
+        return fallback_step
+    if cache_len == 1 or sliding_window_count(sampled_length, windows, fallback_step) == cache_len:
+        return fallback_step
+    span = sampled_length - windows
+    low = int(np.floor(span / cache_len)) + 1
+    high = int(np.floor(span / (cache_len - 1)))
+    fits = [s for s in range(max(1, low), max(1, high) + 1) if sliding_window_count(sampled_length, windows, s) == cache_len]
+    return min(fits, key=lambda s: (abs(s - fallback_step), -s)) if fits else fallback_step
+
+
+# ----------------------------------------------------------------------------------------
+# device execution
+# ----------------------------------------------------------------------------------------
+def _uses_scaler(model) -> bool:
+    # the YAML string 'None' is truthy in the reference and so is here
+    return getattr(model, "scaler", None) is not None
+
+
+def _windows_per_launch(model, nodes: int) -> int:
+    per_window = 4 * nodes * model.pred_len * model.dataset_nf * int(model.configs.n_z_samples)
+    if getattr(model, "noise_source", "philox") == "torch_cpu":
+        per_window *= 1 + model.diffusion_steps
+    return max(1, MAX_SAMPLE_BYTES // max(per_window, 1))
+
+
+def _stack_windows(window_list: Sequence[torch.Tensor]) -> torch.Tensor:
+    """W tensors [V, windows, F] -> one [W*V, windows, F] batch (windows become extra rows: the
+    sampler treats every row independently, exactly as the reference treats nodes)."""
+    return torch.stack([torch.as_tensor(w).float() for w in window_list], dim=0).flatten(0, 1)
+
+
+def _sample_stacked(model, window_list, pred_len, scale: bool):
+    """All windows in as few launches as memory allows.  Returns per-window CPU tensors
+    [V, pred_len, F, S] plus the device-side MPV / pred_mean (inverse-scaled as summarize does)."""
+    if not window_list:
+        return [], np.zeros(0, np.float32), np.zeros(0, np.float32)
+    V = int(window_list[0].shape[0])
+    ctx = model.native_context()
+    lo, hi = dist_utils.shard_bounds(len(window_list))
+    preds: List[torch.Tensor] = []
+    mpv_parts, mean_parts = [], []
+    chunk = _windows_per_launch(model, V)
+    inv_std = model.scaler_std.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
+    inv_mean = model.scaler_mean.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
+    for start in range(lo, hi, chunk):
+        part = window_list[start: min(start + chunk, hi)]
+        rows = _stack_windows(part).to(ctx.device)                        # [w*V, windows, F]
+        # one pseudo-window over w*V rows; the scaler is fused into the sigma-head load
+        samples, _ = model.sample_windows(rows, 1, 0, 1, scale_input=scale, noise=_host_noise_for(model, len(part), V))
+        samples = samples.reshape(len(part), V, model.pred_len, model.dataset_nf, -1)[:, :, -pred_len:]
+        samples = samples.contiguous()
+        mpv, pm, _ = ctx.reduce(samples, inv_std, inv_mean)
+        mpv_parts.append(mpv)
+        mean_parts.append(pm)
+        preds.extend(samples.cpu().unbind(0))
+    mpv_local = torch.cat(mpv_parts) if mpv_parts else torch.zeros(0, device=ctx.device)
+    mean_local = torch.cat(mean_parts) if mean_parts else torch.zeros(0, device=ctx.device)
+    mpv_all, mean_all = dist_utils.gather_curve(len(window_list), lo, hi, mpv_local, mean_local)
+    return preds, mpv_all, mean_all
+
+
+def _host_noise_for(model, n_windows: int, nodes: int):
+    """torch_cpu mode: the reference draws window by window, so draw [n_windows] evaluation_step
+    worth of normals and re-tile them for the stacked (1 window x n_windows*nodes rows) launch."""
+    if getattr(model, "noise_source", "philox") != "torch_cpu":
+        return None
+    z = model.host_noise(n_windows, nodes)               # [W, C, T, V*P, O, F]
+    W, C, T, VP, O, F = z.shape
+    P = VP // nodes
+    # stacked launch: rows = (w, v) pairs, so its draw tensor is [1, C, T, (W*V)*P, O, F]
+    z = z.reshape(W, C, T, nodes, P, O, F).permute(1, 2, 0, 3, 4, 5, 6).reshape(1, C, T, W * nodes * P, O, F)
+    return z.contiguous()
+
+
+class _DeviceCurve(list):
+    """pred_future_list whose MPV / pred_mean were already reduced on device (same list API)."""
+    ews: Optional[np.ndarray] = None
+    pred_mean: Optional[np.ndarray] = None
+
+
+def run_evaluation_cache(model, timeseries_datas, pred_len, cache_path, device, force_recompute=False, max_windows=None):
+    """Windows -> list of CPU tensors [V, pred_len, F, n_z_samples], cached (reference :323-339).
+
+    The reference leaves `time_series_trans` unbound when `model.scaler is None`; here an
+    unscaled model simply samples the raw window."""
+    cache_path = Path(cache_path)
+    if cache_path.exists() and not force_recompute:
+        return _load_tensor_list(cache_path)
+    windows = list(timeseries_datas[:max_windows] if max_windows is not None else timeseries_datas)
+    with torch.no_grad():
+        preds, mpv, pm = _sample_stacked(model, windows, pred_len, scale=_uses_scaler(model))
+    out = _DeviceCurve(preds)
+    out.ews, out.pred_mean = mpv, pm
+    if dist_utils.is_primary() or not dist_utils.active():
+        _save_tensor_list(list(out), cache_path)
+    return out
+
+
+def run_slbp_sensitivity_cache(model, input_datas, cache_path, device, force_recompute=False, max_windows=None):
+    """Single-series windows [windows, F] -> list of [pred_len, F, n_z_samples] (reference :502-526)."""
+    cache_path = Path(cache_path)
+    if cache_path.exists() and not force_recompute:
+        cached = read_sensitivity_pred_future_cache(cache_path)
+        if cached is not None:
+            return cached
+    windows = [torch.as_tensor(w).float().unsqueeze(0) for w in
+               (input_datas[:max_windows] if max_windows is not None else input_datas)]
+    with torch.no_grad():
+        preds, _, _ = _sample_stacked(model, windows, model.pred_len, scale=_uses_scaler(model))
+    preds = [p.squeeze(0) for p in preds]
+    if dist_utils.is_primary() or not dist_utils.active():
+        _save_tensor_list(preds, cache_path)
+    return preds
+
+
+def run_nsdiff_g_cache(model, timeseries_datas, cache_path, device, pred_dim=0, force_recompute=False, max_windows=None):
+    """sigma head only, one [V, pred_len, F] tensor per window (reference :400-422)."""
+    cache_path = Path(cache_path)
+    if cache_path.exists() and not force_recompute:
+        return _load_tensor_list(cache_path)
+    if getattr(model, "cond_pred_model_g", None) is None:
+        return None
+    windows = list(timeseries_datas[:max_windows] if max_windows is not None else timeseries_datas)
+    g_list: List[torch.Tensor] = []
+    if windows:
+        V = int(windows[0].shape[0])
+        ctx = model.native_context()
+        scale = _uses_scaler(model)
+        with torch.no_grad():
+            rows = _stack_windows(windows).to(ctx.device)
+            gx = ctx.sigma_head(rows, 1, 0, 1, model.scaler_mean if scale else None, model.scaler_std if scale else None)
+        gx = gx.reshape(len(windows), V, model.pred_len, model.dataset_nf).cpu()
+        if pred_dim >= gx.shape[-1]:
+            raise IndexError("pred_dim {} out of bounds for F={}.".format(pred_dim, gx.shape[-1]))
+        g_list = list(gx.unbind(0))
+    _save_tensor_list(g_list, cache_path)
+    return g_list
+
+
+# ----------------------------------------------------------------------------------------
+# summaries
+# ----------------------------------------------------------------------------------------
+def _feature_inverse_transform(pred_future, model=None):
+    if model is None or getattr(model, "scaler", None) is None:
+        return pred_future
+    if not hasattr(model, "scaler_mean") or not hasattr(model, "scaler_std"):
+        return model.scaler_inverse_transform(pred_future) if hasattr(model, "scaler_inverse_transform") else pred_future
+    mean = model.scaler_mean.detach().to(pred_future.device, pred_future.dtype)
+    std = model.scaler_std.detach().to(pred_future.device, pred_future.dtype)
+    if pred_future.ndim >= 3 and pred_future.shape[-2] == mean.numel():
+        shape = [1] * pred_future.ndim
+        shape[-2] = mean.numel()
+        return pred_future * std.view(*shape) + mean.view(*shape)
+    if pred_future.shape[-1] == mean.numel():
+        return pred_future * std + mean
+    return pred_future
+
+
+def _reduce_on_device(tensors: Sequence[torch.Tensor], model, per_feature=False, inverse=True):
+    """Stack same-shaped [V, O, F, S] windows and run the HIP variance reduction."""
+    from .. import _native
+    dev = None
+    if model is not None and hasattr(model, "native_context"):
+        ctx = model.native_context()
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        ctx = _native.Context(dev)
+    x = torch.stack([torch.as_tensor(t).float() for t in tensors]).to(ctx.device).contiguous()
+    std = mean = None
+    if inverse and model is not None and getattr(model, "scaler", None) is not None and hasattr(model, "scaler_mean") \
+            and x.shape[-2] == model.scaler_mean.numel():
+        std = model.scaler_std.detach().to(ctx.device).float().contiguous()
+        mean = model.scaler_mean.detach().to(ctx.device).float().contiguous()
+    mpv, pm, feat = ctx.reduce(x, std, mean, per_feature=per_feature)
+    return mpv.cpu().numpy(), pm.cpu().numpy(), None if feat is None else feat.cpu().numpy()
+
+
+def summarize_pred_future_list(pred_future_list, model=None):
+    """-> (pred_mean list, MPV list): inverse-scale, population variance over samples, mean over
+    [Node, pred_len, F] (reference :286-303)."""
+    if isinstance(pred_future_list, _DeviceCurve) and pred_future_list.ews is not None:
+        return [np.asarray(v) for v in pred_future_list.pred_mean], [np.asarray(v) for v in pred_future_list.ews]
+    items = []
+    for pred_future in pred_future_list:
+        pred_future = torch.as_tensor(pred_future).detach()
+        if pred_future.ndim == 3:
+            pred_future = pred_future.unsqueeze(0)
+        if pred_future.ndim != 4:
+            raise ValueError("pred_future must have shape [Node, pred_len, F, n_z_samples], got {}".format(
+                tuple(pred_future.shape)))
+        items.append(pred_future)
+    if not items:
+        return [], []
+    mpv, pm, _ = _reduce_on_device(items, model)
+    return [np.asarray(v) for v in pm], [np.asarray(v) for v in mpv]
+
+
+def summarize_nsdiff_g_list(g_list, pred_dim=0):
+    """gx-only signal: per window mean over nodes of the horizon-mean of one feature (reference :306-320)."""
+    ews_list, pred_mean_list = [], []
+    for gx in g_list:
+        gx = torch.as_tensor(gx).detach().cpu()
+        if gx.ndim == 2:
+            gx = gx.unsqueeze(0)
+        if gx.ndim != 3:
+            raise ValueError("NsDiff-g cache elements must have shape [Node, pred_len, F].")
+        if pred_dim >= gx.shape[-1]:
+            raise IndexError("pred_dim {} out of bounds for F={}.".format(pred_dim, gx.shape[-1]))
+        ews_list.append(gx.mean(dim=1)[:, pred_dim].mean().numpy())
+        pred_mean_list.append(gx.mean().numpy())
+    return pred_mean_list, ews_list
+
+
+def summarize_slbp_sensitivity(pred_future_list, pred_datas, model=None, device=None, pred_dim=0):
+    """SLBP MPV = mean over the horizon of the sample variance of ONE feature, no inverse scaling;
+    prediction error = |sample mean - scaled truth| (reference :529-550)."""
+    items = []
+    for pred_future in pred_future_list:
+        pred_future = torch.as_tensor(pred_future).detach()
+        if pred_future.ndim != 3:
+            raise ValueError("SLBP sensitivity cache elements must have shape [pred_len, F, n_z_samples].")
+        if pred_dim >= pred_future.shape[1]:
+            raise IndexError("pred_dim {} out of bounds for F={}.".format(pred_dim, pred_future.shape[1]))
+        items.append(pred_future.unsqueeze(0))
+    mpv_list = []
+    if items:
+        _, _, feat = _reduce_on_device(items, model, per_feature=True, inverse=False)
+        mpv_list = [np.asarray(v) for v in feat[:, pred_dim]]
+    err_list = []
+    for pred_future, truth in zip(pred_future_list, pred_datas):
+        pred_future = torch.as_tensor(pred_future).detach().cpu()
+        truth = torch.as_tensor(truth).detach().cpu()
+        if getattr(model, "scaler", None) is not None and hasattr(model, "scaler_transform"):
+            truth = (truth - model.scaler_mean.cpu()) / model.scaler_std.cpu()
+        err = torch.abs(pred_future.mean(dim=-1) - truth).mean(dim=0)
+        err_list.append(err[pred_dim].numpy())
+    return mpv_list, err_list
+
+
+def _slbp_intrinsic_dimension(trajectories):
+    """Number of principal components holding 80% of the sample-trajectory variance (reference :686-698)."""
+    traj = torch.as_tensor(trajectories, dtype=torch.float32)
+    if traj.ndim != 2 or traj.shape[0] < 2:
+        return np.nan
+    centered = traj - traj.mean(dim=0, keepdim=True)
+    cov = centered.T.mm(centered) / max(traj.shape[0] - 1, 1)
+    eig = torch.sort(torch.linalg.eigvalsh(cov), descending=True).values.clamp_min(0)
+    total = eig.sum()
+    if float(total) <= 0:
+        return np.nan
+    return int(torch.where(torch.cumsum(eig / total, dim=0) >= 0.8)[0][0].item() + 1)
+
+
+def summarize_slbp_sampling_for_fig6(pred_future_list, pred_dim=0):
+    mpv_list, _ = summarize_slbp_sensitivity(pred_future_list, (), pred_dim=pred_dim)
+    dims = []
+    for pred_future in pred_future_list:
+        pred_future = torch.as_tensor(pred_future).detach().cpu()
+        dims.append(_slbp_intrinsic_dimension(pred_future.permute(2, 0, 1).reshape(pred_future.shape[-1], -1)))
+    return [float(v) for v in mpv_list], dims
+
+
+# ----------------------------------------------------------------------------------------
+# public entry points
+# ----------------------------------------------------------------------------------------
+def slbp_sensitivity_ews(model_root, model_name, torch_time_series, time_data, data_trend="increase", pred_dim=0,
+                         sample_window_step=10, infer_params=None, force_recompute=False, max_windows=None, device=None):
+    """SLBP single-series MPV curve for one model of a sensitivity sweep (reference :553-621)."""
+    model_root = _resolve_project_path(model_root)
+    device = _default_device(device)
+    model, method_config, net_param = load_sensitivity_model(model_root, model_name, device=device, infer_params=infer_params)
+    dataset_config = method_config.get("dataset", {})
+    windows, pred_len, sampling_t = dataset_config["windows"], dataset_config["pred_len"], dataset_config["sampling_t"]
+    input_datas, pred_datas, time_points = build_slbp_sensitivity_windows(
+        torch_time_series, time_data, windows, pred_len, sampling_t, sample_window_step)
+    cache_path = slbp_sensitivity_cache_path(model_root, model_name, data_trend, sample_window_step)
+    preds = run_slbp_sensitivity_cache(model, input_datas, cache_path, device, force_recompute=force_recompute,
+                                       max_windows=max_windows)
+    mpv_list, err_list = summarize_slbp_sensitivity(preds, pred_datas, model=model, device=device, pred_dim=pred_dim)
+    return {
+        "time_points": time_points, "mpv": mpv_list, "prediction_error": err_list, "pred_future_list": preds,
+        "cache_path": str(cache_path), "windows": windows, "pred_len": pred_len, "sampling_t": sampling_t,
+        "sample_window_step": sample_window_step, "model_root": str(model_root), "model_name": model_name,
+        "loaded_net_param": net_param,
+    }
+
+
+_METHOD_ALIASES = {"variance": "sampling", "sampling_variance": "sampling", "pred_future": "sampling", "pred": "sampling",
+                   "g": "gx", "preg": "gx", "nsdiff_g": "gx"}
+
+
+def uncertainty_ews(model_save_file=None, data_file=None, torch_time_series=None, time_data=None, dynamic_type=None,
+                    task_model=None, graph_file=None, cache_path=None, sample_window_step=None, sampling_t=None,
+                    infer_params=None, pred_dim=0, force_recompute=False, save_nsdiff_g=True, nsdiff_g_path=None,
+                    uncertainty_method="sampling", max_windows=None, device=None, load_model_when_cached=False):
+    """Trajectory + trained model -> MPV early-warning curve (reference :1253-1541).
+
+    Same arguments and result keys as the reference.  `uncertainty_method`: "sampling" (variance
+    of N sampled futures), "gx" (sigma head only) or "both".
+    """
+    dynamic_type = _dynamic_name(dynamic_type)
+    method = _METHOD_ALIASES.get(str(uncertainty_method).lower(), str(uncertainty_method).lower())
+    if method not in {"sampling", "gx", "both"}:
+        raise ValueError("uncertainty_method must be one of: sampling, gx, both.")
+
+    if data_file is not None:
+        data_file = _resolve_project_path(data_file)
+        loaded = load_dynamic_data(data_file, dynamic_type=dynamic_type)
+        torch_time_series, time_data = loaded["torch_time_series"], loaded["time_data"]
+        dynamic_type = dynamic_type or loaded["dynamic_type"]
+    elif torch_time_series is not None:
+        torch_time_series = normalize_time_series(torch_time_series, dynamic_type=dynamic_type)
+    else:
+        raise ValueError("Provide data_file or torch_time_series.")
+    if time_data is None:
+        raise ValueError("time_data is required when data_file is not provided.")
+
+    method_config = None
+    if model_save_file is not None:
+        model_save_file = _resolve_project_path(model_save_file)
+        method_config = read_model_config(model_save_file)
+    if task_model is None and method_config is not None:
+        task_model = method_config.get("net", {}).get("task_model")
+    dataset_config = method_config.get("dataset", {}) if method_config else {}
+    windows, pred_len = dataset_config.get("windows"), dataset_config.get("pred_len")
+    if windows is None or pred_len is None:
+        raise ValueError("model_trained.yaml must provide dataset.windows and dataset.pred_len.")
+    if task_model == "DiffSTG":
+        raise NotImplementedError("DiffSTG has no HIP path yet (SURVEY.md section 8, later row)")
+
+    cache_path = resolve_cache_path(cache_path, model_save_file, data_file, dynamic_type)
+    want_sampling = method in {"sampling", "both"}
+    want_gx = method in {"gx", "both"} or (save_nsdiff_g and method == "sampling")
+    gx_path = None
+    if want_gx:
+        gx_path = resolve_cache_path(nsdiff_g_path if nsdiff_g_path is not None else cache_path.parent, model_save_file,
+                                     data_file, dynamic_type, suffix="_gx")
+    cached_preds = _load_tensor_list(cache_path) if want_sampling and cache_path.exists() and not force_recompute else None
+    cached_gx = _load_tensor_list(gx_path) if want_gx and gx_path is not None and gx_path.exists() and not force_recompute else None
+
+    if sampling_t is None:
+        sampling_t = dataset_config.get("sampling_t", DEFAULT_SAMPLING_T.get(dynamic_type, 0.1))
+    sampled_series, sampled_time = sample_time_series(torch_time_series, time_data, sampling_t=sampling_t)
+    if sample_window_step is None:
+        fallback = default_sample_window_step(dynamic_type, task_model=task_model, dataset_config=dataset_config)
+        known = len(cached_preds) if cached_preds is not None else (len(cached_gx) if cached_gx is not None else None)
+        sample_window_step = fallback if known is None else infer_sample_window_step_from_cache(
+            sampled_series.shape[1], windows, known, fallback)
+    window_views, time_points = build_sliding_windows(sampled_series, sampled_time, windows, sample_window_step)
+
+    model, net_param = None, None
+
+    def need_model():
+        nonlocal model, net_param, device
+        if model is None:
+            if model_save_file is None:
+                raise ValueError("model_save_file is required when cache_path does not exist or force_recompute=True.")
+            device = _default_device(device)
+            model, net_param = load_model_from_dir(model_save_file, device=device, infer_params=infer_params,
+                                                   method_config=method_config)
+        return model
+
+    preds, pred_mean_list, ews_list = None, [], []
+    if want_sampling:
+        if cached_preds is not None:
+            preds = cached_preds
+            if model_save_file is not None and load_model_when_cached:
+                need_model()
+        else:
+            preds = run_evaluation_cache(need_model(), window_views, pred_len, cache_path, device,
+                                         force_recompute=force_recompute, max_windows=max_windows)
+        pred_mean_list, ews_list = summarize_pred_future_list(preds, model=model)
+
+    result = {
+        "pred_future_list": list(preds) if preds is not None else None,
+        "pred_mean": pred_mean_list, "ews": ews_list, "time_points": time_points[: len(ews_list)],
+        "cache_path": str(cache_path), "figure_path": str(resolve_figure_path(cache_path)),
+        "torch_time_series": torch_time_series, "time_data": torch.as_tensor(time_data).cpu().detach().numpy(),
+        "dynamic_type": dynamic_type, "sampling_t": sampling_t, "sample_window_step": sample_window_step,
+        "windows": windows, "pred_len": pred_len, "task_model": task_model, "uncertainty_method": method,
+        "uncertainty_source": "sampling" if want_sampling else None,
+        "graph_file": str(_resolve_project_path(graph_file)) if graph_file is not None else None,
+        "model_save_file": str(model_save_file) if model_save_file is not None else None,
+        "loaded_net_param": net_param,
+    }
+
+    has_g_model = model is not None and getattr(model, "cond_pred_model_g", None) is not None
+    g_list = None
+    if want_gx and ("NsDiff" in str(task_model) or has_g_model):
+        if cached_gx is not None:
+            g_list = cached_gx
+        else:
+            if model is None and model_save_file is not None:
+                need_model()
+                result["loaded_net_param"] = net_param
+            if model is not None and getattr(model, "cond_pred_model_g", None) is not None:
+                g_list = run_nsdiff_g_cache(model, window_views, gx_path, device, pred_dim=pred_dim,
+                                            force_recompute=force_recompute, max_windows=max_windows)
+        if g_list is not None:
+            g_mean, g_ews = summarize_nsdiff_g_list(g_list, pred_dim=pred_dim)
+            result["nsdiff_g"] = {"pred_future_list": g_list, "pred_mean": g_mean, "ews": g_ews,
+                                  "time_points": time_points[: len(g_ews)], "cache_path": str(gx_path)}
+            if method == "gx":
+                result.update({"pred_future_list": None, "pred_mean": g_mean, "ews": g_ews,
+                               "time_points": time_points[: len(g_ews)], "cache_path": str(gx_path),
+                               "figure_path": str(resolve_figure_path(gx_path)), "uncertainty_source": "gx"})
+    if method == "gx" and g_list is None:
+        raise ValueError("uncertainty_method='gx' requires a task_model containing 'NsDiff' "
+                         "and a loaded model with cond_pred_model_g, or an existing _gx cache.")
+    return result

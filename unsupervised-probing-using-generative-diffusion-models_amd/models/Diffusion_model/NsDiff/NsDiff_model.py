@@ -110,8 +110,15 @@ class _NsDiffBase(nn.Module):
         """All normals of `n_windows` evaluation_step calls, drawn with torch.randn on the CPU in
         the reference's order: window, chunk, draw k=0..T-1, tensor [nodes*P, O, F]."""
         P, S = int(self.configs.parallel_sample), int(self.configs.n_z_samples)
-        shape = (n_windows, S // P, self.diffusion_steps, nodes * P, self.pred_len, self.dataset_nf)
-        return torch.randn(shape)
+        draw = (nodes * P, self.pred_len, self.dataset_nf)
+        # one torch.randn call per reference draw: a single big call is NOT the same stream when a
+        # draw's element count is not a multiple of 16 (torch's vectorised normal fill)
+        out = torch.empty((n_windows, S // P, self.diffusion_steps) + draw)
+        for w in range(n_windows):
+            for c in range(S // P):
+                for k in range(self.diffusion_steps):
+                    out[w, c, k] = torch.randn(draw)
+        return out
 
     def _prior_variance(self, ctx, series, n_windows, first, step, scaled_input: bool):
         raise NotImplementedError

@@ -1,0 +1,90 @@
+"""Seeded synthetic inputs of the reference's shapes (no datasets travel).
+
+* `ba_graph`            : Barabasi-Albert preferential attachment (the reference draws its test
+                          topologies with igraph/networkx; dataset/graph_generate.py:61-84)
+* `biomass_trajectory`  : Euler-Maruyama restatement of the harvested-biomass network SDE
+                          dx_i = [r x_i (1 - x_i/k) - eps(t) x_i^2/(x_i^2+1) + d sum_j A_ij (x_j - x_i)] dt + eta dW_i
+                          (dataset/spdata_sde_biomass_dynamic_gene.py:53-68; r=0.7, k=10, d=0.5,
+                          eta=0.005 as in paper_figures/common.py:41), dt = 0.1, burn-in, then a
+                          linear ramp of the harvesting pressure eps(t) through the fold.
+* `slbp_like_series`    : a seeded two-feature single series for the SLBP plumbing shape.
+
+Record format matches the harness input: {'ys_dynamic': [ticks, V], 'ts_dynamic': [ticks]}.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def ba_graph(n: int, m: int = 3, seed: int = 0) -> np.ndarray:
+    """Dense symmetric 0/1 adjacency of a BA graph (n nodes, m edges per new node)."""
+    rng = np.random.default_rng(seed)
+    adj = np.zeros((n, n), dtype=np.float64)
+    targets = list(range(m))
+    repeated = []
+    for src in range(m, n):
+        for t in set(targets):
+            adj[src, t] = adj[t, src] = 1.0
+        repeated.extend(set(targets))
+        repeated.extend([src] * m)
+        targets = []
+        while len(set(targets)) < m:
+            targets.append(repeated[rng.integers(len(repeated))])
+    return adj
+
+
+def biomass_trajectory(nodes: int = 100, ticks: int = 100_000, seed: int = 0, r: float = 0.7, k: float = 10.0,
+                       d: float = 0.5, eta: float = 0.005, dt: float = 0.1, burn_ticks: int = 1000,
+                       eps_start: float = 0.0, eps_end: float = 2.7, m: int = 3):
+    """-> record dict with ys_dynamic [ticks, nodes] float32 and ts_dynamic [ticks]."""
+    rng = np.random.default_rng(seed)
+    A = ba_graph(nodes, m=m, seed=seed)
+    deg = A.sum(axis=1)
+    x = rng.uniform(0.0, 1.0, nodes)
+    sq = np.sqrt(dt)
+
+    def drift(x, eps):
+        x = np.maximum(x, 0.0)
+        return r * x * (1 - x / k) - eps * x * x / (x * x + 1) + d * (A @ x - deg * x)
+
+    for _ in range(burn_ticks):
+        x = x + drift(x, eps_start) * dt + eta * sq * rng.standard_normal(nodes)
+    ys = np.empty((ticks, nodes), dtype=np.float32)
+    ramp = np.linspace(eps_start, eps_end, ticks)
+    noise = rng.standard_normal((ticks, nodes)) * (eta * sq)
+    for i in range(ticks):
+        x = x + drift(x, ramp[i]) * dt + noise[i]
+        ys[i] = x
+    return {"ys_dynamic": torch.from_numpy(ys), "ts_dynamic": torch.arange(ticks, dtype=torch.float32) * dt,
+            "tp_values": torch.from_numpy(ramp.astype(np.float32))}
+
+
+def slbp_like_series(ticks: int = 50_000, seed: int = 0, dt: float = 0.1):
+    rng = np.random.default_rng(seed)
+    t = np.arange(ticks) * dt
+    a = 2.0 + 0.4 * np.sin(t / 40.0) + np.cumsum(rng.normal(0, 0.01, ticks))
+    b = 1.0 + 0.2 * np.cos(t / 25.0) + np.cumsum(rng.normal(0, 0.015, ticks)) + 0.0004 * t
+    return {"ys_dynamic": torch.tensor(np.stack([a, b], axis=1), dtype=torch.float32),
+            "ts_dynamic": torch.tensor(t, dtype=torch.float32), "N_values": torch.zeros(ticks)}
+
+
+def seeded_nsdiff_state(model, series: torch.Tensor, seed: int = 123):
+    """Re-initialise `model` in place with torch.manual_seed(seed) default inits (nn.Linear
+    kaiming-uniform, embed ~ U(0,1), LayerNorm 1/0) and fit its scaler on `series` [V, L, F]:
+    the shipped checkpoints pin T=20, so other step counts need random weights."""
+    gen_state = torch.get_rng_state()
+    torch.manual_seed(seed)
+    for mod in model.modules():
+        if isinstance(mod, (torch.nn.Linear, torch.nn.LayerNorm)):
+            mod.reset_parameters()
+        elif isinstance(mod, torch.nn.Embedding):
+            mod.weight.data.uniform_()
+    torch.set_rng_state(gen_state)
+    flat = series.reshape(-1, series.shape[-1]).float()
+    std = flat.std(dim=0)
+    std[std == 0] = 1
+    model.scaler_mean = flat.mean(dim=0).to(model.scaler_mean.device)
+    model.scaler_std = std.to(model.scaler_std.device)
+    model.refresh_native()
+    return model
