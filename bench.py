@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=1, help="windows of the workload timed on the CPU oracle")
+    ap.add_argument("--max-windows", type=int, default=None, help="profiling aid: cut the trajectory to this many windows "
+                    "(the reported metric is then NOT the BASELINE workload and says so)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,6 +101,8 @@ def main():
     sampled, _ = H.sample_time_series(full, record["ts_dynamic"], CFG["sampling_t"])        # [V, 1000, 1]
     sampled = sampled.contiguous()
     n_windows = H.sliding_window_count(sampled.shape[1], CFG["windows"], CFG["window_step"])
+    if args.max_windows is not None:
+        n_windows = min(n_windows, args.max_windows)
     model = build_model(device, sampled)
     ctx = model.native_context()
     series_dev = sampled.to(device)
@@ -155,7 +159,7 @@ def main():
         "config": {"workload": "NsDiff cond_var on 100-node BA-graph biomass trajectory (BASELINE configs[1]): "
                                "windows=100, pred_len=100, rolling=50, N=32 samples, T=50 steps, {} windows per "
                                "trajectory, one trajectory per GPU per step".format(n_windows),
-                   "windows_per_step_per_gpu": n_windows, "noise": "on-device Philox4x32-10",
+                   "windows_per_step_per_gpu": n_windows, "truncated_for_profiling": args.max_windows is not None, "noise": "on-device Philox4x32-10",
                    "weights": "seeded default init (shipped checkpoints pin T=20)"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,

@@ -43,6 +43,14 @@ extern "C" {
 #define MPV_MAX_NF 4       /* features per series the kernels are built for  */
 #define MPV_COEF_COLS 20   /* per-step posterior coefficient row, see below  */
 
+/* Evaluation of the two 128x128 layers of the epsilon network (everything else is fp32 VALU):
+ *   MPV_GEMM_F16X3  exact two-term fp16 split of weights and activations, three f16 MFMAs with fp32
+ *                   accumulation per product (W_hi h_hi + W_hi h_lo + W_lo h_hi; ~2^-21 relative per
+ *                   product, i.e. ~1e-6 on the samples).  Default: ~3x faster, inside the 1e-4 parity budget.
+ *   MPV_GEMM_F32    v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 FMA chain.                              */
+#define MPV_GEMM_F16X3 0
+#define MPV_GEMM_F32 1
+
 typedef struct mpv_ctx mpv_ctx;
 
 int mpv_abi_version(void);
@@ -112,7 +120,7 @@ typedef struct {
     int32_t pred_len;     /* O                                                                     */
     int32_t n_samples;    /* S = n_z_samples                                                       */
     int32_t chunk;        /* P = parallel_sample; S % P == 0.  Only fixes the noise draw order.   */
-    int32_t reserved;
+    int32_t gemm;         /* MPV_GEMM_F16X3 (0, default) or MPV_GEMM_F32: how the two 128x128 layers are evaluated */
     uint64_t seed;        /* Philox key when noise == NULL                                         */
     uint64_t offset;      /* Philox stream offset (counter word 3) when noise == NULL              */
 } mpv_sample_shape;

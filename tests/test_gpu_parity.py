@@ -59,21 +59,23 @@ def test_library_loads_and_reports_device():
         ctx.sample(torch.ones(1, 1, 4, 1, device=dev()), None, 4, 4)          # nothing loaded yet
 
 
+@pytest.mark.parametrize("gemm", ["f16x3", "f32"])
 @pytest.mark.parametrize("tag", ["seed50", "wofx20", "seed10"])
-def test_chain_matches_reference_loop(golden_cases, ckpt_wofx, tag):
+def test_chain_matches_reference_loop(golden_cases, ckpt_wofx, tag, gemm):
     """p_sample_loop golden (reference run, recorded noise) through mpv_nsdiff_sample."""
     sd, nf, steps = model_sd(tag, ckpt_wofx)
     ctx = make_ctx(sd, nf, steps)
     y0 = T(golden_cases["step_%s_y0" % tag]).to(dev())[None].contiguous()      # [1, 6, 5, F]
     gx = T(golden_cases["step_%s_gx" % tag]).to(dev())[None].contiguous()
     noise = T(golden_cases["loop_%s_noise" % tag]).to(dev()).contiguous()       # [T, 6, 5, F]
-    out = ctx.sample(gx, y0, 1, 1, noise=noise)[0, :, :, :, 0]
+    out = ctx.sample(gx, y0, 1, 1, noise=noise, gemm=gemm)[0, :, :, :, 0]
     err = rel_err(out, golden_cases["loop_%s_out" % tag])
-    print("chain %s rel err %.3e" % (tag, err))
+    print("chain %s [%s] rel err %.3e" % (tag, gemm, err))
     assert err < RTOL
 
 
-def test_chain_nan_on_negative_discriminant_like_reference(ckpt_wofx):
+@pytest.mark.parametrize("gemm", ["f16x3", "f32"])
+def test_chain_nan_on_negative_discriminant_like_reference(ckpt_wofx, gemm):
     """gx = 0 makes lambda_0 > 0, lambda_2 = 0 and -lambda_1 +- |lambda_1| -> the reference's own
     arithmetic (sqrt(noise) of a tiny negative, 0/0 ...) must be reproduced, not 'fixed': compare with
     the oracle elementwise including where it is NaN."""
@@ -84,7 +86,7 @@ def test_chain_nan_on_negative_discriminant_like_reference(ckpt_wofx):
     g = torch.Generator().manual_seed(3)
     noise = torch.randn(steps, 4, 1, 1, generator=g)
     want = O.sample_loop(sd, tb, torch.zeros(4, 1, 1), gx[0], torch.zeros(4, 1, 1), steps, O.replay_noise(list(noise)))
-    got = ctx.sample(gx.to(dev()), None, 1, 1, noise=noise.to(dev()))[0, :, :, :, 0].cpu()
+    got = ctx.sample(gx.to(dev()), None, 1, 1, noise=noise.to(dev()), gemm=gemm)[0, :, :, :, 0].cpu()
     assert torch.equal(torch.isnan(got), torch.isnan(want))
     ok = ~torch.isnan(want)
     assert rel_err(got[ok], want[ok]) < RTOL
@@ -138,36 +140,38 @@ def test_mpv_reduce_matches_torch(S):
     assert rel_err(feat2, want) < 2e-6
 
 
-def _variant_model(sd, select, nf, steps, windows, pred_len, rolling, n_z, par, noise_source="philox"):
+def _variant_model(sd, select, nf, steps, windows, pred_len, rolling, n_z, par, noise_source="philox", gemm="f16x3"):
     from mpv_amd.models.models import diffusion_models
     net_param = dict(device=dev(), scaler_type="StandardScaler", task_model="NsDiff_model_variants",
                      rolling_length=rolling, diffusion_schedule="linear", diffusion_steps=steps, beta_start=1e-4,
                      beta_end=0.02, n_z_samples=n_z, parallel_sample=par, windows=windows, pred_len=pred_len,
-                     dataset_nf=nf, noise_source=noise_source)
+                     dataset_nf=nf, noise_source=noise_source, gemm_mode=gemm)
     model = diffusion_models("NsDiff_model_variants", net_param, train_model_select=select).to(dev())
     own = model.state_dict()
     model.load_state_dict({k: sd[k] for k in own}, strict=True)
     return model.eval()
 
 
-def test_evaluation_step_real_checkpoint(golden_cases, ckpt_wofx):
+@pytest.mark.parametrize("gemm", ["f16x3", "f32"])
+def test_evaluation_step_real_checkpoint(golden_cases, ckpt_wofx, gemm):
     """C1 shape, real wo_fx checkpoint, two chunks: the reference's recorded noise injected."""
-    model = _variant_model(ckpt_wofx, "cond_var", 2, 20, 200, 200, 100, 4, 2)
+    model = _variant_model(ckpt_wofx, "cond_var", 2, 20, 200, 200, 100, 4, 2, gemm=gemm)
     outs, by = model.evaluation_step(T(golden_cases["eval_wofx_batch"]), noise=T(golden_cases["eval_wofx_noise"]))
     assert by is None and outs.device.type == "cpu" and tuple(outs.shape) == (1, 200, 2, 4)
     err = rel_err(outs, golden_cases["eval_wofx_out"])
-    print("evaluation_step wo_fx rel err %.3e" % err)
+    print("evaluation_step wo_fx [%s] rel err %.3e" % (gemm, err))
     assert err < RTOL
 
 
-def test_evaluation_step_seeded_and_torch_cpu_noise_stream(golden_cases):
+@pytest.mark.parametrize("gemm", ["f16x3", "f32"])
+def test_evaluation_step_seeded_and_torch_cpu_noise_stream(golden_cases, gemm):
     """Reduced C2 shape; noise_source='torch_cpu' + the reference's seed == the reference run."""
     sd = O.random_state_dict(1, 50, 100, 100, 50, seed=123)
-    model = _variant_model(sd, "cond_var", 1, 50, 100, 100, 50, 8, 4, noise_source="torch_cpu")
+    model = _variant_model(sd, "cond_var", 1, 50, 100, 100, 50, 8, 4, noise_source="torch_cpu", gemm=gemm)
     torch.manual_seed(12)
     outs, _ = model.evaluation_step(T(golden_cases["eval_seed_batch"]))
     err = rel_err(outs, golden_cases["eval_seed_out"])
-    print("evaluation_step seeded rel err %.3e" % err)
+    print("evaluation_step seeded [%s] rel err %.3e" % (gemm, err))
     assert err < RTOL
     m, v = O.mpv_network(outs)
     mw, vw = O.mpv_network(T(golden_cases["eval_seed_out"]))

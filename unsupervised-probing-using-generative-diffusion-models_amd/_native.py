@@ -13,11 +13,13 @@ from typing import Optional, Sequence
 import torch
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libmpv_hip.so"
+import os
+LIB_PATH = Path(os.environ.get("MPV_LIB", PKG / "libmpv_hip.so"))   # MPV_LIB: kernel-variant experiments only
 ABI_VERSION = 1
 HIDDEN = 128
 MAX_NF = 4
 COEF_COLS = 20
+GEMM_MODES = {"f16x3": 0, "f32": 1}
 
 EXPORTS = (
     "mpv_abi_version", "mpv_ctx_create", "mpv_ctx_destroy", "mpv_ctx_set_stream", "mpv_last_error",
@@ -44,7 +46,7 @@ class NsdiffWeights(C.Structure):
 
 class SampleShape(C.Structure):
     _fields_ = [("n_windows", C.c_int32), ("nodes", C.c_int32), ("pred_len", C.c_int32), ("n_samples", C.c_int32),
-                ("chunk", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64)]
+                ("chunk", C.c_int32), ("gemm", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64)]
 
 
 class SigmaDesc(C.Structure):
@@ -204,7 +206,7 @@ class Context:
         return gx
 
     def sample(self, gx: torch.Tensor, y0hat: Optional[torch.Tensor], n_samples: int, chunk: int,
-               noise: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0) -> torch.Tensor:
+               noise: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0, gemm: str = "f16x3") -> torch.Tensor:
         """gx / y0hat [W, B, O, F] on device -> samples [W, B, O, F, S]."""
         if self.nsdiff is None:
             raise MpvError("NsDiff weights not loaded")
@@ -218,7 +220,9 @@ class Context:
             if noise.numel() != need:
                 raise MpvError("noise has {} elements, the draw order needs {}".format(noise.numel(), need))
         out = torch.empty((W, B, O, F, n_samples), device=self.device, dtype=torch.float32)
-        shape = SampleShape(W, B, O, n_samples, chunk, 0, seed & (2 ** 64 - 1), offset & (2 ** 64 - 1))
+        if gemm not in GEMM_MODES:
+            raise MpvError("gemm must be one of {}".format(sorted(GEMM_MODES)))
+        shape = SampleShape(W, B, O, n_samples, chunk, GEMM_MODES[gemm], seed & (2 ** 64 - 1), offset & (2 ** 64 - 1))
         self._bind_stream()
         self._check(self.lib.mpv_nsdiff_sample(self._h, C.byref(shape), _dev_ptr(y0hat, self.device, "y0hat"),
                                                _dev_ptr(gx, self.device, "gx"), _dev_ptr(noise, self.device, "noise"),

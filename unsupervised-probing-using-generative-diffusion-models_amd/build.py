@@ -13,7 +13,7 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
-SOURCES = ["mpv_api.hip", "nsdiff_chain.hip", "sigma_head.hip", "mpv_reduce.hip"]
+SOURCES = ["mpv_api.hip", "nsdiff_chain.hip", "nsdiff_chain_f16.hip", "sigma_head.hip", "mpv_reduce.hip"]
 LIB = PKG / "libmpv_hip.so"
 
 
@@ -27,7 +27,7 @@ def hipcc_path() -> str:
 def stale() -> bool:
     if not LIB.exists():
         return True
-    deps = [PKG / "csrc" / s for s in SOURCES] + [PKG / "csrc" / "mpv_common.h", ROOT / "include" / "mpv_hip.h"]
+    deps = [PKG / "csrc" / s for s in SOURCES] + [PKG / "csrc" / "mpv_common.h", PKG / "csrc" / "chain_common.h", ROOT / "include" / "mpv_hip.h"]
     return any(d.stat().st_mtime > LIB.stat().st_mtime for d in deps)
 
 

@@ -1,0 +1,124 @@
+// Shared device helpers of the NsDiff chain kernels (fp32-MFMA and f16x3-MFMA variants).
+#pragma once
+#include "mpv_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace chain {
+
+constexpr int HID = MPV_HIDDEN;
+constexpr int WROW = 132;  // padded LDS row stride in floats: (33*i) mod 16 distinct over 16 lanes
+#ifndef MPV_WAVES
+#define MPV_WAVES 8
+#endif
+#ifndef MPV_PRIO_MFMA      // experiment: s_setprio value held during the MFMA layers (-1 = leave alone)
+#define MPV_PRIO_MFMA -1
+#endif
+#ifndef MPV_STAGGER        // experiment: delay the second half of the workgroup's waves once, in s_sleep(127) units
+#define MPV_STAGGER 0
+#endif
+constexpr int WAVES = MPV_WAVES;
+constexpr int THREADS = WAVES * 64;
+constexpr int TILE = 32;   // chains per wave
+
+// LDS carve (floats); every offset is a multiple of 4 floats (16 B)
+constexpr int L_W2 = 0;
+constexpr int L_W3 = L_W2 + HID * WROW;
+constexpr int L_W1T = L_W3 + HID * WROW;              // [3F][128]
+constexpr int L_B1 = L_W1T + 3 * MPV_MAX_NF * HID;
+constexpr int L_B2 = L_B1 + HID;
+constexpr int L_B3 = L_B2 + HID;
+constexpr int L_W4 = L_B3 + HID;                      // [F][128]
+constexpr int L_WS = L_W4 + MPV_MAX_NF * HID;         // [F][128]
+constexpr int L_HB = L_WS + MPV_MAX_NF * HID;         // b4[4], bs[4]
+constexpr int L_FLOATS = L_HB + 8;
+
+struct ChainArgs {
+    const float *w1t, *w2, *w3, *b1, *b2, *b3, *e1, *e2, *e3, *w4, *ws, *b4, *bs, *coef;
+    // f16x3 variant: split weights [128][128] f16 (columns permuted for the A fragment), scaled biases,
+    // folded per-step scale tables, sigma head pre-multiplied by ln 2
+    const unsigned short *w2h, *w2l, *w3h, *w3l;
+    const float *b2s, *b3s, *g1, *g2, *g3, *wsl;
+    const float* y0hat;
+    const float* gx;
+    const float* noise;
+    float* samples;
+    long long n_chains;
+    long long n_tiles;
+    long long noise_kstride;   // B*P*O*F
+    int T, B, O, S, P, C;
+    unsigned seed_lo, seed_hi, off_lo;
+};
+
+// ---- softplus(x) = x > 20 ? x : log1p(exp(x))  (torch.nn.functional.softplus defaults) ----
+// Raw v_exp_f32 / v_log_f32 (no denormal pre-scaling): exp2 underflowing to 0 gives softplus 0
+// where the true value is < 2^-126, and 1+e is always a normal number.  For e < 2^-12 the
+// series e - e^2/2 replaces log(1+e), whose argument would have lost e's low bits.
+__device__ __forceinline__ float softplus_dev(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+    float l = __builtin_amdgcn_logf(1.0f + e) * 0.693147180559945309f;
+    const float small = __builtin_fmaf(-0.5f * e, e, e);
+    l = (e < 2.44140625e-4f) ? small : l;
+    return (x > 20.0f) ? x : l;
+}
+
+// ---- Philox4x32-10 + Box-Muller -------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void philox_normals(unsigned long long chain, unsigned k, unsigned seed_lo, unsigned seed_hi,
+                                               unsigned off_lo, float (&z)[4]) {
+    unsigned x[4];
+    philox4x32_10((unsigned)chain, (unsigned)(chain >> 32), k, off_lo, seed_lo, seed_hi, x);
+    const float inv24 = 5.9604644775390625e-8f;  // 2^-24
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float u1 = ((float)(x[2 * i] >> 8) + 0.5f) * inv24;      // (0,1)
+        const float u2 = (float)(x[2 * i + 1] >> 8) * inv24;            // [0,1) revolutions
+        const float rad = sqrtf(-2.0f * logf(u1));
+        z[2 * i] = rad * __builtin_amdgcn_cosf(u2);
+        z[2 * i + 1] = rad * __builtin_amdgcn_sinf(u2);
+    }
+}
+
+
+// hidden-unit index of register (4q+e) of out-tile j in half-wave h is 32j + 8q + 4h + e
+__device__ __forceinline__ int hbase(int j, int q, int h) { return 32 * j + 8 * q + 4 * h; }
+
+struct StepCoef {
+    float c1, c2, q1, q2, c4, l4, l2, n1, bt, invr, omr, aoma, bt1, a, sp, sa, k1, k2;
+};
+
+// One element of p_sample / p_sample_t_1to0 (nsdiff_utils.py:131-157, 209-239).  Contraction is
+// off so each product and sum rounds once, as the reference's eager fp32 tensor ops do.
+__device__ __forceinline__ float posterior(const StepCoef& c, float y, float mu, float g, float eps, float sig, float z,
+                                           bool last) {
+#pragma clang fp contract(off)
+    const float lam1 = c.c1 * g - sig * c.c2;
+    const float lam2 = g * g * c.q1 * c.q2 - sig * g * c.c4;
+    const float sy0 = (-lam1 + sqrtf(lam1 * lam1 - c.l4 * lam2)) / c.l2;   // NaN if disc < 0, as reference
+    const float nz = c.n1 * g + c.bt * sy0;
+    const float y0r = c.invr * (y - c.omr * mu - eps * sqrtf(nz));
+    if (last) return y0r;
+    const float s1 = c.q1 * g + c.aoma * sy0;
+    const float s2 = c.q2 * g + c.bt1 * sy0;
+    const float den = c.a * s2 + s1;
+    const float g0 = c.sp * s1 / den;
+    const float g1 = c.sa * s2 / den;
+    const float g2 = (c.k1 * s2 + c.k2 * s1) / den;
+    return g0 * y0r + g1 * y + g2 * mu + sqrtf(sig) * z;
+}
+
+
+}  // namespace chain

@@ -1,4 +1,5 @@
 // C ABI of libmpv_hip (include/mpv_hip.h): context, weight upload, argument checks, dispatch.
+#include <cmath>
 #include <cstring>
 #include <mutex>
 
@@ -42,6 +43,35 @@ int upload_blob(mpv_ctx* ctx, const std::vector<std::pair<const float*, size_t>>
     dev->clear();
     for (size_t o : off) dev->push_back(*blob + o);
     return MPV_OK;
+}
+
+// power-of-two scale that puts max|w| in [2^12, 2^13): f16 hi parts stay far from overflow, lo parts normal
+int scale_log2(const float* w, size_t n) {
+    float m = 0.0f;
+    for (size_t i = 0; i < n; ++i) m = std::fmax(m, std::fabs(w[i]));
+    if (!(m > 0.0f) || !std::isfinite(m)) return 0;
+    int e = 0;
+    std::frexp(m, &e);                 // m = f * 2^e, f in [0.5, 1)
+    return 13 - e;
+}
+
+// [128][128] fp32 -> two f16 images (hi, lo) of w * 2^sl, columns permuted for the 32x32x16 A fragment:
+// LDS position p of a row holds column (p & ~15) | swap_bits_2_3(p & 15)
+void split_weights(const float* w, int sl, std::vector<unsigned short>* hi, std::vector<unsigned short>* lo) {
+    const int H = MPV_HIDDEN;
+    hi->assign((size_t)H * H, 0);
+    lo->assign((size_t)H * H, 0);
+    const float sc = std::ldexp(1.0f, sl);
+    for (int r = 0; r < H; ++r)
+        for (int p = 0; p < H; ++p) {
+            const int pl = p & 15;
+            const int c = (p & ~15) | (pl & 3) | (((pl >> 2) & 1) << 3) | (((pl >> 3) & 1) << 2);
+            const float x = w[(size_t)r * H + c] * sc;
+            const _Float16 h = (_Float16)x;
+            const _Float16 l = (_Float16)(x - (float)h);
+            std::memcpy(&(*hi)[(size_t)r * H + p], &h, 2);
+            std::memcpy(&(*lo)[(size_t)r * H + p], &l, 2);
+        }
 }
 
 std::vector<float> transposed(const float* w, int rows, int cols) {   // [rows][cols] -> [cols][rows]
@@ -98,6 +128,7 @@ void mpv_ctx_destroy(mpv_ctx* ctx) {
         (void)hipEventDestroy(e.second);
     }
     if (ctx->ns.blob) (void)hipFree(ctx->ns.blob);
+    if (ctx->ns.blob16) (void)hipFree(ctx->ns.blob16);
     if (ctx->sg.blob) (void)hipFree(ctx->sg.blob);
     if (ctx->reduce_ws) (void)hipFree(ctx->reduce_ws);
     delete ctx;
@@ -141,6 +172,36 @@ int mpv_nsdiff_load(mpv_ctx* ctx, const mpv_nsdiff_desc* d, const mpv_nsdiff_wei
     m.w1t = dev[0]; m.w2 = dev[1]; m.w3 = dev[2]; m.b1 = dev[3]; m.b2 = dev[4]; m.b3 = dev[5];
     m.e1 = dev[6]; m.e2 = dev[7]; m.e3 = dev[8]; m.w4 = dev[9]; m.ws = dev[10]; m.b4 = dev[11]; m.bs = dev[12];
     m.coef = dev[13];
+    // ---- split-f16 variant: scaled/split weights, scaled biases, folded per-step tables ---------------
+    const float LOG2E = 1.44269504088896341f, LN2 = 0.693147180559945309f;
+    const int s2 = scale_log2(w->lin_w[1], (size_t)H * H), s3 = scale_log2(w->lin_w[2], (size_t)H * H);
+    std::vector<unsigned short> w2h, w2l, w3h, w3l;
+    split_weights(w->lin_w[1], s2, &w2h, &w2l);
+    split_weights(w->lin_w[2], s3, &w3h, &w3l);
+    const int ACT = 12;                                   // activation scale 2^12 (nsdiff_chain_f16.hip)
+    std::vector<float> b2s(H), b3s(H), g1((size_t)T * H), g2((size_t)T * H), g3((size_t)T * H), wsl((size_t)F * H);
+    for (int i = 0; i < H; ++i) {
+        b2s[i] = std::ldexp(w->lin_b[1][i], s2 + ACT);
+        b3s[i] = std::ldexp(w->lin_b[2][i], s3 + ACT);
+    }
+    for (size_t i = 0; i < (size_t)T * H; ++i) {
+        g1[i] = w->embed[0][i] * LOG2E;
+        g2[i] = std::ldexp(w->embed[1][i] * LOG2E, -(s2 + ACT));
+        g3[i] = std::ldexp(w->embed[2][i] * LOG2E, -(s3 + ACT));
+    }
+    for (size_t i = 0; i < (size_t)F * H; ++i) wsl[i] = w->sig_w[i] * LN2;
+    auto as_f32 = [](const std::vector<unsigned short>& v) { return reinterpret_cast<const float*>(v.data()); };
+    std::vector<const float*> d16;
+    rc = upload_blob(ctx,
+                     {{as_f32(w2h), (size_t)H * H / 2}, {as_f32(w2l), (size_t)H * H / 2}, {as_f32(w3h), (size_t)H * H / 2},
+                      {as_f32(w3l), (size_t)H * H / 2}, {b2s.data(), (size_t)H}, {b3s.data(), (size_t)H},
+                      {g1.data(), (size_t)T * H}, {g2.data(), (size_t)T * H}, {g3.data(), (size_t)T * H},
+                      {wsl.data(), (size_t)F * H}},
+                     &ctx->ns.blob16, &d16);
+    if (rc != MPV_OK) return rc;
+    m.w2h = reinterpret_cast<const unsigned short*>(d16[0]); m.w2l = reinterpret_cast<const unsigned short*>(d16[1]);
+    m.w3h = reinterpret_cast<const unsigned short*>(d16[2]); m.w3l = reinterpret_cast<const unsigned short*>(d16[3]);
+    m.b2s = d16[4]; m.b3s = d16[5]; m.g1 = d16[6]; m.g2 = d16[7]; m.g3 = d16[8]; m.wsl = d16[9];
     m.steps = T; m.nf = F; m.loaded = true;
     return MPV_OK;
 }
@@ -154,6 +215,8 @@ int mpv_nsdiff_sample(mpv_ctx* ctx, const mpv_sample_shape* s, const float* y0ha
         return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: negative extent");
     const bool empty = s->n_windows == 0 || s->nodes == 0 || s->pred_len == 0 || s->n_samples == 0;
     if (!empty && (!gx || !samples)) return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: NULL argument");
+    if (s->gemm != MPV_GEMM_F16X3 && s->gemm != MPV_GEMM_F32)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: gemm must be MPV_GEMM_F16X3 or MPV_GEMM_F32");
     if (s->n_samples > 0 && (s->chunk < 1 || s->n_samples % s->chunk != 0))
         return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: n_samples must be a positive multiple of chunk");
     DeviceGuard g(ctx->device);

@@ -12,6 +12,10 @@ struct NsdiffModel {
     int steps = 0, nf = 0;
     float* blob = nullptr;        // one device allocation, sub-pointers below
     const float *w1t, *w2, *w3, *b1, *b2, *b3, *e1, *e2, *e3, *w4, *ws, *b4, *bs, *coef;
+    // split-f16 matrix-core variant (see nsdiff_chain_f16.hip)
+    float* blob16 = nullptr;
+    const unsigned short *w2h, *w2l, *w3h, *w3l;
+    const float *b2s, *b3s, *g1, *g2, *g3, *wsl;
 };
 
 struct SigmaModel {
@@ -49,6 +53,8 @@ int mpv_fail(mpv_ctx* ctx, int code, const std::string& msg);
 // launchers implemented next to their kernels
 int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* gx,
                         const float* noise, float* samples);
+namespace chain { struct ChainArgs; }
+int launch_chain_f16(mpv_ctx* ctx, const chain::ChainArgs& a, bool philox, int grid, int nf);
 int launch_philox_dump(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out);
 int launch_sigma_head(mpv_ctx* ctx, const float* series, int V, int64_t L, int n_windows, int64_t first, int64_t step,
                       const float* mean, const float* std, float add_eps, float* gx);

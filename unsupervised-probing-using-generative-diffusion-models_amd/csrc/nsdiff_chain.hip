@@ -24,87 +24,11 @@
 //
 // Algorithmic work per chain-step: 2*128*(128+128) + 2*128*3F + 2*2*128*F = 256*(256+5F) flop
 // (SURVEY.md section 8d), ~98% of it in the two MFMA layers -> roofline: fp32 MFMA peak.
-#include "mpv_common.h"
+#include "chain_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using namespace chain;
 
 namespace {
-
-constexpr int HID = MPV_HIDDEN;
-constexpr int WROW = 132;  // padded LDS row stride in floats: (33*i) mod 16 distinct over 16 lanes
-constexpr int WAVES = 8;
-constexpr int THREADS = WAVES * 64;
-constexpr int TILE = 32;   // chains per wave
-
-// LDS carve (floats); every offset is a multiple of 4 floats (16 B)
-constexpr int L_W2 = 0;
-constexpr int L_W3 = L_W2 + HID * WROW;
-constexpr int L_W1T = L_W3 + HID * WROW;              // [3F][128]
-constexpr int L_B1 = L_W1T + 3 * MPV_MAX_NF * HID;
-constexpr int L_B2 = L_B1 + HID;
-constexpr int L_B3 = L_B2 + HID;
-constexpr int L_W4 = L_B3 + HID;                      // [F][128]
-constexpr int L_WS = L_W4 + MPV_MAX_NF * HID;         // [F][128]
-constexpr int L_HB = L_WS + MPV_MAX_NF * HID;         // b4[4], bs[4]
-constexpr int L_FLOATS = L_HB + 8;
-
-struct ChainArgs {
-    const float *w1t, *w2, *w3, *b1, *b2, *b3, *e1, *e2, *e3, *w4, *ws, *b4, *bs, *coef;
-    const float* y0hat;
-    const float* gx;
-    const float* noise;
-    float* samples;
-    long long n_chains;
-    long long n_tiles;
-    long long noise_kstride;   // B*P*O*F
-    int T, B, O, S, P, C;
-    unsigned seed_lo, seed_hi, off_lo;
-};
-
-// ---- softplus(x) = x > 20 ? x : log1p(exp(x))  (torch.nn.functional.softplus defaults) ----
-// Raw v_exp_f32 / v_log_f32 (no denormal pre-scaling): exp2 underflowing to 0 gives softplus 0
-// where the true value is < 2^-126, and 1+e is always a normal number.  For e < 2^-12 the
-// series e - e^2/2 replaces log(1+e), whose argument would have lost e's low bits.
-__device__ __forceinline__ float softplus_dev(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
-    float l = __builtin_amdgcn_logf(1.0f + e) * 0.693147180559945309f;
-    const float small = __builtin_fmaf(-0.5f * e, e, e);
-    l = (e < 2.44140625e-4f) ? small : l;
-    return (x > 20.0f) ? x : l;
-}
-
-// ---- Philox4x32-10 + Box-Muller -------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
-                                              unsigned k1, unsigned (&out)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-__device__ __forceinline__ void philox_normals(unsigned long long chain, unsigned k, unsigned seed_lo, unsigned seed_hi,
-                                               unsigned off_lo, float (&z)[4]) {
-    unsigned x[4];
-    philox4x32_10((unsigned)chain, (unsigned)(chain >> 32), k, off_lo, seed_lo, seed_hi, x);
-    const float inv24 = 5.9604644775390625e-8f;  // 2^-24
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float u1 = ((float)(x[2 * i] >> 8) + 0.5f) * inv24;      // (0,1)
-        const float u2 = (float)(x[2 * i + 1] >> 8) * inv24;            // [0,1) revolutions
-        const float rad = sqrtf(-2.0f * logf(u1));
-        z[2 * i] = rad * __builtin_amdgcn_cosf(u2);
-        z[2 * i + 1] = rad * __builtin_amdgcn_sinf(u2);
-    }
-}
-
-// hidden-unit index of register (4q+e) of out-tile j in half-wave h is 32j + 8q + 4h + e
-__device__ __forceinline__ int hbase(int j, int q, int h) { return 32 * j + 8 * q + 4 * h; }
 
 // v <- normalize(softplus(gamma * v)) over the 128 hidden units of each chain
 __device__ __forceinline__ void activate(float (&v)[64], const float* __restrict__ gamma_row, int h) {
@@ -161,32 +85,8 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ Ws, const f
         for (int i = 0; i < 16; ++i) hv[j * 16 + i] = acc[j][i];
 }
 
-struct StepCoef {
-    float c1, c2, q1, q2, c4, l4, l2, n1, bt, invr, omr, aoma, bt1, a, sp, sa, k1, k2;
-};
-
-// One element of p_sample / p_sample_t_1to0 (nsdiff_utils.py:131-157, 209-239).  Contraction is
-// off so each product and sum rounds once, as the reference's eager fp32 tensor ops do.
-__device__ __forceinline__ float posterior(const StepCoef& c, float y, float mu, float g, float eps, float sig, float z,
-                                           bool last) {
-#pragma clang fp contract(off)
-    const float lam1 = c.c1 * g - sig * c.c2;
-    const float lam2 = g * g * c.q1 * c.q2 - sig * g * c.c4;
-    const float sy0 = (-lam1 + sqrtf(lam1 * lam1 - c.l4 * lam2)) / c.l2;   // NaN if disc < 0, as reference
-    const float nz = c.n1 * g + c.bt * sy0;
-    const float y0r = c.invr * (y - c.omr * mu - eps * sqrtf(nz));
-    if (last) return y0r;
-    const float s1 = c.q1 * g + c.aoma * sy0;
-    const float s2 = c.q2 * g + c.bt1 * sy0;
-    const float den = c.a * s2 + s1;
-    const float g0 = c.sp * s1 / den;
-    const float g1 = c.sa * s2 / den;
-    const float g2 = (c.k1 * s2 + c.k2 * s1) / den;
-    return g0 * y0r + g1 * y + g2 * mu + sqrtf(sig) * z;
-}
-
 template <int F, bool PHILOX>
-__global__ __launch_bounds__(THREADS, 2) void nsdiff_chain_kernel(const ChainArgs p) {
+__global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_kernel(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     // ---- stage the weights once per workgroup -------------------------------------------
@@ -214,6 +114,9 @@ __global__ __launch_bounds__(THREADS, 2) void nsdiff_chain_kernel(const ChainArg
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r_lane = lane & 31, h_lane = lane >> 5;
+    if (MPV_STAGGER > 0 && __builtin_amdgcn_readfirstlane(wave) >= WAVES / 2) {
+        for (int i = 0; i < MPV_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < p.n_tiles; tile += (long long)gridDim.x * WAVES) {
         const long long n_raw = tile * TILE + r_lane;
@@ -287,9 +190,13 @@ __global__ __launch_bounds__(THREADS, 2) void nsdiff_chain_kernel(const ChainArg
             }
             activate(hv, p.e1 + (long long)t * HID, h);
             // ---- layers 2, 3 on the fp32 matrix pipe ---------------------------------------
+            if (MPV_PRIO_MFMA >= 0) __builtin_amdgcn_s_setprio(MPV_PRIO_MFMA);
             mfma_layer(lds + L_W2, lds + L_B2, hv, r, h);
+            if (MPV_PRIO_MFMA >= 0) __builtin_amdgcn_s_setprio(MPV_PRIO_MFMA ? 0 : 3);
             activate(hv, p.e2 + (long long)t * HID, h);
+            if (MPV_PRIO_MFMA >= 0) __builtin_amdgcn_s_setprio(MPV_PRIO_MFMA);
             mfma_layer(lds + L_W3, lds + L_B3, hv, r, h);
+            if (MPV_PRIO_MFMA >= 0) __builtin_amdgcn_s_setprio(MPV_PRIO_MFMA ? 0 : 3);
             activate(hv, p.e3 + (long long)t * HID, h);
             // ---- heads: eps = W4 h + b4 ; sigma = softplus(Ws softplus(h) + bs) --------------
             float ea[F], sa[F];
@@ -367,6 +274,8 @@ int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0
     ChainArgs a{};
     a.w1t = m.w1t; a.w2 = m.w2; a.w3 = m.w3; a.b1 = m.b1; a.b2 = m.b2; a.b3 = m.b3;
     a.e1 = m.e1; a.e2 = m.e2; a.e3 = m.e3; a.w4 = m.w4; a.ws = m.ws; a.b4 = m.b4; a.bs = m.bs; a.coef = m.coef;
+    a.w2h = m.w2h; a.w2l = m.w2l; a.w3h = m.w3h; a.w3l = m.w3l;
+    a.b2s = m.b2s; a.b3s = m.b3s; a.g1 = m.g1; a.g2 = m.g2; a.g3 = m.g3; a.wsl = m.wsl;
     a.y0hat = y0hat; a.gx = gx; a.noise = noise; a.samples = samples;
     a.T = m.steps; a.B = s.nodes; a.O = s.pred_len; a.S = s.n_samples; a.P = s.chunk; a.C = s.n_samples / s.chunk;
     a.n_chains = (long long)s.n_windows * s.nodes * s.pred_len * s.n_samples;
@@ -389,6 +298,9 @@ int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0
     }
     int rc;
     const bool philox = (noise == nullptr);
+    if (s.gemm == MPV_GEMM_F16X3) {
+        rc = launch_chain_f16(ctx, a, philox, grid, m.nf);
+    } else
     switch (m.nf) {
         case 1: rc = launch_f<1>(ctx, a, philox, grid); break;
         case 2: rc = launch_f<2>(ctx, a, philox, grid); break;

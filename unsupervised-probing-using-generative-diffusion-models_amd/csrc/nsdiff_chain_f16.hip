@@ -1,0 +1,313 @@
+// NsDiff chain, split-f16 matrix-core variant for gfx950 (the default sampler).
+//
+// Why: on gfx950 v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate and excludes the VALU while it
+// executes (measured, tools/ubench/pipe_overlap4.hip: an fp32 MFMA + N v_fma gap costs 64 + N*issue
+// cycles, no overlap in-wave or across the two waves of a SIMD), so the exact-fp32 kernel of
+// nsdiff_chain.hip is bound by MFMA + VALU in series (62 % of the fp32 matrix peak).  The f16 matrix
+// pipe is 16x faster and does run beside the VALU, so the two 128x128 layers are evaluated as
+//      W h  =  W_hi h_hi + W_hi h_lo + W_lo h_hi            (three v_mfma_f32_32x32x16_f16, fp32 accumulate)
+// with x = x_hi + x_lo an exact two-term fp16 split of the power-of-two-scaled fp32 value (hi = RN_f16(x),
+// lo = RN_f16(x - hi): 22 significand bits kept; the dropped lo*lo term is 2^-22 relative).  The result
+// differs from an fp32 FMA chain by ~1e-6 relative, two orders inside the 1e-4 parity budget, while the
+// matrix work shrinks from 32.8k to 6.1k cycles per wave-step and hides under the elementwise work.
+// The kernel is then bound by VALU / transcendental issue (~3.6k VALU + 514 exp/log per 32 chain-steps).
+//
+// Data flow is the same as the fp32 kernel (see nsdiff_chain.hip): a wave owns 32 chains, activations
+// never change lanes.  For v_mfma_f32_32x32x16_f16 the B operand of k-step ks is eight f16 per lane; with
+// k-steps enumerated as (tile, 8 consecutive accumulator registers) those are exactly accumulator
+// registers 8ks..8ks+7 of the lane (hidden unit 32*(ks>>1) + 16*(ks&1) + 8*(jj>>2) + 4*h + (jj&3) for
+// element jj of half-wave h), and the A operand reads the weight row with the matching column
+// permutation (bits 2 and 3 of the column swapped inside each 16-block; done once on the host).
+//
+// Elementwise work is done in the log2 domain: with x' = x*log2(e) folded into the per-step scale table,
+//   softplus(x)/ln2 = max( clamp(log2(1 + 2^x'), (e - e^2/2)/ln2, e/ln2), x' ),   e = 2^min(x',126)
+// (the clamp replaces log1p's small-argument branch, the max replaces torch's threshold=20 branch: for
+// x > 20 log2(1+2^x') == x' in fp32).  F.normalize is scale invariant, so the ln2 never has to be applied.
+#include "chain_common.h"
+
+using namespace chain;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int HROW = 136;                       // LDS row stride of the f16 weight images, in halfs (272 B)
+constexpr int ACT_SCALE_LOG2 = 12;              // activations in [0,1] are scaled by 2^12 before the split
+// LDS carve in bytes
+constexpr int B_W2H = 0;
+constexpr int B_W2L = B_W2H + HID * HROW * 2;
+constexpr int B_W3H = B_W2L + HID * HROW * 2;
+constexpr int B_W3L = B_W3H + HID * HROW * 2;
+constexpr int B_F32 = B_W3L + HID * HROW * 2;   // float region starts here (16-B aligned)
+constexpr int F_W1T = 0;                         // [3F][128]
+constexpr int F_B1 = F_W1T + 3 * MPV_MAX_NF * HID;
+constexpr int F_B2S = F_B1 + HID;
+constexpr int F_B3S = F_B2S + HID;
+constexpr int F_W4 = F_B3S + HID;
+constexpr int F_WSL = F_W4 + MPV_MAX_NF * HID;
+constexpr int F_HB = F_WSL + MPV_MAX_NF * HID;
+constexpr int F_FLOATS = F_HB + 8;
+constexpr int LDS_BYTES = B_F32 + F_FLOATS * 4;
+
+constexpr float LOG2E = 1.44269504088896341f;
+constexpr float HALF_LOG2E = 0.72134752044448170f;
+constexpr float LN2 = 0.693147180559945309f;
+
+// softplus(x) / ln2 from x' = x * log2(e); plain VALU + one v_exp + one v_log, no compares
+__device__ __forceinline__ float softplus_log2(float xs) {
+    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(xs, -3.0e38f, 126.0f));
+    const float c = __builtin_amdgcn_logf(1.0f + e);
+    const float lo = e * __builtin_fmaf(e, -HALF_LOG2E, LOG2E);       // (e - e^2/2)/ln2  <= log2(1+e)
+    const float hi = e * LOG2E;                                        // e/ln2            >= log2(1+e)
+    return __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(c, lo, hi), xs, 3.0e38f);   // = max(clamped, xs)
+}
+
+// acc (pre-activations, any scale) -> l = softplus(gamma''*acc)/ln2 in place; returns 1/max(||l||, eps/ln2)
+__device__ __forceinline__ float activate_log2(f32x16 (&acc)[4], const float* __restrict__ grow, int h) {
+    float ss = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(grow + hbase(j, q, h));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float l = softplus_log2(gm[e] * acc[j][q * 4 + e]);
+                acc[j][q * 4 + e] = l;
+                ss = __builtin_fmaf(l, l, ss);
+            }
+        }
+    }
+    ss += __shfl_xor(ss, 32);
+    return 1.0f / fmaxf(sqrtf(ss), 1e-12f / LN2);
+}
+
+// normalised, 2^12-scaled activations -> exact two-term f16 split, laid out as the MFMA B fragments
+__device__ __forceinline__ void split_f16(const f32x16 (&acc)[4], float scale, f16x8 (&bh)[8], f16x8 (&bl)[8]) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int j = ks >> 1, r0 = (ks & 1) * 8 + 2 * p;
+            const f32x2 v = {acc[j][r0] * scale, acc[j][r0 + 1] * scale};
+            const f16x2 hi = __builtin_convertvector(v, f16x2);
+            const f32x2 rem = {v[0] - (float)hi[0], v[1] - (float)hi[1]};
+            const f16x2 lo = __builtin_convertvector(rem, f16x2);
+            bh[ks][2 * p] = hi[0]; bh[ks][2 * p + 1] = hi[1];
+            bl[ks][2 * p] = lo[0]; bl[ks][2 * p + 1] = lo[1];
+        }
+    }
+}
+
+// acc = bias_s + (W_hi + W_lo)(h_hi + h_lo) without the lo*lo term, on the f16 matrix pipe
+__device__ __forceinline__ void mfma_layer_f16(const unsigned char* __restrict__ whi, const unsigned char* __restrict__ wlo,
+                                               const float* __restrict__ bias_s, const f16x8 (&bh)[8], const f16x8 (&bl)[8],
+                                               f32x16 (&acc)[4], int r, int h) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + hbase(j, q, h));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j][q * 4 + e] = b[e];
+        }
+    }
+    const int lane_off = r * (HROW * 2) + h * 16;        // bytes: row r of the tile, k-group h
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int off = lane_off + j * 32 * (HROW * 2) + ks * 32;
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(whi + off);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(wlo + off);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc[j], 0, 0, 0);
+        }
+    }
+}
+
+template <int F, bool PHILOX>
+__global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(const ChainArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* ldsf = reinterpret_cast<float*>(smem + B_F32);
+
+    // ---- stage the weights once per workgroup (rows padded from 256 B to 272 B) ----------------
+    for (int i = threadIdx.x; i < HID * 16; i += THREADS) {          // 16-byte pieces: 16 per row
+        const int row = i >> 4, piece = i & 15;
+        const int dst = row * (HROW * 2) + piece * 16, src = row * HID + piece * 8;
+        *reinterpret_cast<uint4*>(smem + B_W2H + dst) = *reinterpret_cast<const uint4*>(p.w2h + src);
+        *reinterpret_cast<uint4*>(smem + B_W2L + dst) = *reinterpret_cast<const uint4*>(p.w2l + src);
+        *reinterpret_cast<uint4*>(smem + B_W3H + dst) = *reinterpret_cast<const uint4*>(p.w3h + src);
+        *reinterpret_cast<uint4*>(smem + B_W3L + dst) = *reinterpret_cast<const uint4*>(p.w3l + src);
+    }
+    for (int i = threadIdx.x; i < 3 * F * HID; i += THREADS) ldsf[F_W1T + i] = p.w1t[i];
+    for (int i = threadIdx.x; i < HID; i += THREADS) {
+        ldsf[F_B1 + i] = p.b1[i];
+        ldsf[F_B2S + i] = p.b2s[i];
+        ldsf[F_B3S + i] = p.b3s[i];
+    }
+    for (int i = threadIdx.x; i < F * HID; i += THREADS) {
+        ldsf[F_W4 + i] = p.w4[i];
+        ldsf[F_WSL + i] = p.wsl[i];
+    }
+    if (threadIdx.x < F) {
+        ldsf[F_HB + threadIdx.x] = p.b4[threadIdx.x];
+        ldsf[F_HB + 4 + threadIdx.x] = p.bs[threadIdx.x];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r_lane = lane & 31, h_lane = lane >> 5;
+    const float act_scale = (float)(1 << ACT_SCALE_LOG2);
+
+    for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < p.n_tiles; tile += (long long)gridDim.x * WAVES) {
+        const long long n_raw = tile * TILE + r_lane;
+        const bool valid = n_raw < p.n_chains;
+        const long long n = valid ? n_raw : p.n_chains - 1;
+        const int s = (int)(n % p.S);
+        const long long row = n / p.S;            // (w*B + b)*O + o
+        const int o = (int)(row % p.O);
+        const long long gi = row / p.O;           // w*B + b
+        const int b = (int)(gi % p.B);
+        const long long w = gi / p.B;
+
+        float g[F], mu[F], y[F], z[4];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            g[f] = p.gx[row * F + f];
+            mu[f] = p.y0hat ? p.y0hat[row * F + f] : 0.0f;
+        }
+        long long nbase = 0;
+        if (!PHILOX) {
+            const int c = s / p.P, pp = s - c * p.P;
+            nbase = (((w * p.C + c) * p.T) * ((long long)p.B * p.P) + (long long)b * p.P + pp) * ((long long)p.O * F) +
+                    (long long)o * F;
+        }
+        if (PHILOX) {
+            philox_normals((unsigned long long)n, 0u, p.seed_lo, p.seed_hi, p.off_lo, z);
+        } else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) z[f] = p.noise[nbase + f];
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+#pragma clang fp contract(off)
+            y[f] = sqrtf(g[f]) * z[f] + mu[f];
+        }
+
+#pragma nounroll
+        for (int t = p.T - 1; t >= 0; --t) {
+            // keep the (t-invariant) LDS operand loads inside the step loop: see nsdiff_chain.hip
+            int h = h_lane, r = r_lane;
+            asm volatile("" : "+v"(h), "+v"(r));
+            if (t > 0) {
+                if (PHILOX) {
+                    philox_normals((unsigned long long)n, (unsigned)(p.T - t), p.seed_lo, p.seed_hi, p.off_lo, z);
+                } else {
+#pragma unroll
+                    for (int f = 0; f < F; ++f) z[f] = p.noise[nbase + (long long)(p.T - t) * p.noise_kstride + f];
+                }
+            }
+            f32x16 acc[4];
+            f16x8 bh[8], bl[8];
+            // ---- layer 1 on the VALU (K = 3F) -----------------------------------------------------
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int base = hbase(j, q, h);
+                    f32x4 a = *reinterpret_cast<const f32x4*>(ldsf + F_B1 + base);
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        a += *reinterpret_cast<const f32x4*>(ldsf + F_W1T + f * HID + base) * y[f];
+                        a += *reinterpret_cast<const f32x4*>(ldsf + F_W1T + (F + f) * HID + base) * mu[f];
+                        a += *reinterpret_cast<const f32x4*>(ldsf + F_W1T + (2 * F + f) * HID + base) * g[f];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][q * 4 + e] = a[e];
+                }
+            }
+            float inv = activate_log2(acc, p.g1 + (long long)t * HID, h);
+            split_f16(acc, inv * act_scale, bh, bl);
+            // ---- layers 2 and 3 on the f16 matrix pipe ----------------------------------------------
+            mfma_layer_f16(smem + B_W2H, smem + B_W2L, ldsf + F_B2S, bh, bl, acc, r, h);
+            inv = activate_log2(acc, p.g2 + (long long)t * HID, h);
+            split_f16(acc, inv * act_scale, bh, bl);
+            mfma_layer_f16(smem + B_W3H, smem + B_W3L, ldsf + F_B3S, bh, bl, acc, r, h);
+            inv = activate_log2(acc, p.g3 + (long long)t * HID, h);
+            // ---- heads on h3 = acc * inv (in [0,1]):  eps = W4 h3 + b4 ; sigma = softplus((Ws ln2) softplus(h3)/ln2 + bs)
+            float ea[F], sa[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) ea[f] = sa[f] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int base = hbase(j, q, h);
+                    float hv[4], sp[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hv[e] = acc[j][q * 4 + e] * inv;
+                        // h3 in [0,1]: 1 + e^h in [2, 3.72], no small-argument or overflow cases
+                        sp[e] = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(hv[e] * LOG2E));
+                    }
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(ldsf + F_W4 + f * HID + base);
+                        const f32x4 wsg = *reinterpret_cast<const f32x4*>(ldsf + F_WSL + f * HID + base);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ea[f] = __builtin_fmaf(w4[e], hv[e], ea[f]);
+                            sa[f] = __builtin_fmaf(wsg[e], sp[e], sa[f]);
+                        }
+                    }
+                }
+            }
+            const float* cr = p.coef + t * MPV_COEF_COLS;
+            const StepCoef c = {cr[0], cr[1], cr[2],  cr[3],  cr[4],  cr[5],  cr[6],  cr[7],  cr[8],
+                                cr[9], cr[10], cr[11], cr[12], cr[13], cr[14], cr[15], cr[16], cr[17]};
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const float eps = ea[f] + __shfl_xor(ea[f], 32) + ldsf[F_HB + f];
+                const float sig = softplus_dev(sa[f] + __shfl_xor(sa[f], 32) + ldsf[F_HB + 4 + f]);
+                y[f] = posterior(c, y[f], mu[f], g[f], eps, sig, z[f], t == 0);
+            }
+        }
+        if (valid && h_lane == 0) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) p.samples[(row * F + f) * p.S + s] = y[f];
+        }
+    }
+}
+
+template <int F>
+int launch_f16_f(mpv_ctx* ctx, const ChainArgs& a, bool philox, int grid) {
+    auto kp = nsdiff_chain_f16_kernel<F, true>;
+    auto kn = nsdiff_chain_f16_kernel<F, false>;
+    MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(philox ? kp : kn),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    if (philox)
+        hipLaunchKernelGGL(kp, dim3(grid), dim3(THREADS), LDS_BYTES, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(kn, dim3(grid), dim3(THREADS), LDS_BYTES, ctx->stream, a);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+}  // namespace
+
+int launch_chain_f16(mpv_ctx* ctx, const chain::ChainArgs& a, bool philox, int grid, int nf) {
+    if ((size_t)LDS_BYTES > ctx->max_lds)
+        return mpv_fail(ctx, MPV_EINVAL, "device LDS too small for the resident-weight chain kernel");
+    switch (nf) {
+        case 1: return launch_f16_f<1>(ctx, a, philox, grid);
+        case 2: return launch_f16_f<2>(ctx, a, philox, grid);
+        case 3: return launch_f16_f<3>(ctx, a, philox, grid);
+        case 4: return launch_f16_f<4>(ctx, a, philox, grid);
+        default: return mpv_fail(ctx, MPV_EINVAL, "nf must be 1..4");
+    }
+}

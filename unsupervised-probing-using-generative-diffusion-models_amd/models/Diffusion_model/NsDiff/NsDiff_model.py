@@ -58,6 +58,7 @@ class _NsDiffBase(nn.Module):
         self.configs = SimpleNamespace(**net_param)
         self.scaler = net_param["scaler_type"]
         self.noise_source = net_param.get("noise_source", "philox")
+        self.gemm_mode = net_param.get("gemm_mode", "f16x3")     # "f16x3" (split-f16 matrix cores) | "f32" (exact)
         if self.noise_source not in ("philox", "torch_cpu"):
             raise ValueError("noise_source must be 'philox' or 'torch_cpu'")
         self.register_buffer("scaler_mean", torch.zeros(self.dataset_nf))
@@ -155,7 +156,7 @@ class _NsDiffBase(nn.Module):
             noise = noise.to(device=ctx.device, dtype=torch.float32).contiguous()
         elif seed is None:
             seed = _draw_seed()
-        samples = ctx.sample(gx, y0hat, S, P, noise=noise, seed=seed or 0, offset=offset)
+        samples = ctx.sample(gx, y0hat, S, P, noise=noise, seed=seed or 0, offset=offset, gemm=self.gemm_mode)
         return samples, gx
 
     def _evaluation_step(self, batch, y0hat, noise):
