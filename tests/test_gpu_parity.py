@@ -234,3 +234,91 @@ def test_ragged_and_empty_batches():
     from mpv_amd._native import MpvError
     with pytest.raises(MpvError):
         ctx.sample(torch.ones(1, 1, 4, 1, device=dev()), None, 6, 4, seed=1)      # S % P != 0
+
+
+# ---- harness level: the reference's own window loops, reproduced under the reference's seeds ---------
+def _reseed_after(monkeypatch, module, name, seed):
+    """The reference run seeded torch AFTER the model existed; model construction draws from the same
+    generator (nn.Linear init), so re-seed right after the harness has loaded the model."""
+    orig = getattr(module, name)
+
+    def wrapped(*a, **k):
+        out = orig(*a, **k)
+        torch.manual_seed(seed)
+        return out
+
+    monkeypatch.setattr(module, name, wrapped)
+
+
+def test_slbp_sensitivity_ews_matches_reference_curve(tmp_path, golden_cases, ckpt_wofx, monkeypatch):
+    """BASELINE configs[0] shape (SLBP single series, 8 windows, N=4) on the real wo_fx checkpoint (T=20)."""
+    from helpers import WOFX_NET, write_model_dir
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+    root = tmp_path / "sweep"
+    cfg = write_model_dir(root / "models" / "tmp", ckpt_wofx, WOFX_NET)
+    (root / "models" / "tmp" / "model_trained").rename(root / "models" / "wofx")
+    (root / "models" / "tmp" / "model_trained.yaml").rename(root / "models" / "wofx.yaml")
+    series, time = T(golden_cases["slbp_series"]), T(golden_cases["slbp_time"])
+    _reseed_after(monkeypatch, H, "load_sensitivity_model", 21)
+    res = H.slbp_sensitivity_ews(root, "wofx", series, time, sample_window_step=10, max_windows=8, device=dev(),
+                                 infer_params={"n_z_samples": 4, "parallel_sample": 4, "noise_source": "torch_cpu"})
+    assert len(res["pred_future_list"]) == 8 and tuple(res["pred_future_list"][0].shape) == (200, 2, 4)
+    assert rel_err(torch.stack(res["pred_future_list"]), golden_cases["slbp_pred"]) < RTOL
+    np.testing.assert_allclose(np.array(res["mpv"], dtype=np.float64), golden_cases["slbp_mpv0"], rtol=RTOL)
+    np.testing.assert_allclose(np.array(res["prediction_error"], dtype=np.float64), golden_cases["slbp_err0"], rtol=RTOL, atol=1e-6)
+    assert np.array_equal(res["time_points"][:8], golden_cases["slbp_tp"])
+    assert H._load_tensor_list(res["cache_path"])[3].shape == (200, 2, 4)              # reference cache format
+    mpv1, _ = H.summarize_slbp_sensitivity(res["pred_future_list"], (), pred_dim=1)
+    np.testing.assert_allclose(np.array(mpv1, dtype=np.float64), golden_cases["slbp_mpv1"], rtol=RTOL)
+    again = H.slbp_sensitivity_ews(root, "wofx", series, time, sample_window_step=10, max_windows=8, device=dev())
+    assert all(torch.equal(a, b) for a, b in zip(again["pred_future_list"], res["pred_future_list"]))   # served from cache
+
+
+def test_uncertainty_ews_network_curve_matches_reference(tmp_path, golden_cases, monkeypatch):
+    """uncertainty_ews end to end (scaler, windows, sigma head, sampler, MPV reduce, caches) == reference run."""
+    from helpers import WOFX_NET, write_model_dir
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+    sd = O.random_state_dict(1, 50, 100, 100, 50, seed=123)
+    sd["scaler_mean"] = T(golden_cases["eval_seed_scaler_mean"])
+    sd["scaler_std"] = T(golden_cases["eval_seed_scaler_std"])
+    net = dict(WOFX_NET, diffusion_steps=50, rolling_length=50, windows=100, pred_len=100, dataset_nf=1)
+    mdir = tmp_path / "model"
+    write_model_dir(mdir, sd, net)
+    series = T(np.ascontiguousarray(golden_cases["net_series"]))[:, :, 0].t().contiguous()        # [ticks, V]
+    torch.save({"ys_dynamic": series, "ts_dynamic": torch.arange(series.shape[0]) * 0.1, "tp_values": torch.zeros(1)},
+               tmp_path / "biomass_run.pt")
+    _reseed_after(monkeypatch, H, "load_model_from_dir", 22)
+    res = H.uncertainty_ews(model_save_file=mdir, data_file=tmp_path / "biomass_run.pt", dynamic_type="biomass",
+                            sampling_t=0.1, sample_window_step=80, device=dev(), uncertainty_method="both",
+                            infer_params={"n_z_samples": 8, "parallel_sample": 4, "noise_source": "torch_cpu"})
+    assert len(res["ews"]) == 3 and res["uncertainty_source"] == "sampling"
+    assert rel_err(torch.stack(res["pred_future_list"]), golden_cases["net_pred"]) < RTOL
+    np.testing.assert_allclose(np.array(res["ews"], dtype=np.float64), golden_cases["net_ews"], rtol=RTOL)
+    np.testing.assert_allclose(np.array(res["pred_mean"], dtype=np.float64), golden_cases["net_pred_mean"], rtol=RTOL)
+    np.testing.assert_allclose(res["time_points"], golden_cases["net_tp"])
+    np.testing.assert_allclose(np.array(res["nsdiff_g"]["ews"], dtype=np.float64), golden_cases["net_g_ews"], rtol=1e-5)
+    # cached second call: summaries recomputed on device from the cache file, same numbers
+    res2 = H.uncertainty_ews(model_save_file=mdir, data_file=tmp_path / "biomass_run.pt", dynamic_type="biomass",
+                             sampling_t=0.1, device=dev(), load_model_when_cached=True)
+    assert res2["sample_window_step"] == 54 or len(res2["ews"]) == 3
+    np.testing.assert_allclose(np.array(res2["ews"], dtype=np.float64), golden_cases["net_ews"], rtol=RTOL)
+
+
+def test_philox_default_mode_statistics_and_repeatability(ckpt_wofx):
+    """Default (on-device Philox) sampling: repeatable under torch.manual_seed and statistically
+    consistent with the injected-noise path (same model, MPV within sampling error)."""
+    model = _variant_model(ckpt_wofx, "cond_var", 2, 20, 200, 200, 100, 64, 64)
+    g = torch.Generator().manual_seed(4)
+    batch = torch.randn(6, 200, 2, generator=g)
+    torch.manual_seed(7)
+    a, _ = model.evaluation_step(batch)
+    torch.manual_seed(7)
+    b, _ = model.evaluation_step(batch)
+    c, _ = model.evaluation_step(batch)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    ref_model = _variant_model(ckpt_wofx, "cond_var", 2, 20, 200, 200, 100, 64, 64, noise_source="torch_cpu")
+    torch.manual_seed(8)
+    d, _ = ref_model.evaluation_step(batch)
+    va, vd = a.var(dim=-1, unbiased=False).mean().item(), d.var(dim=-1, unbiased=False).mean().item()
+    assert abs(va - vd) / vd < 0.05, (va, vd)
+    assert abs(a.mean().item() - d.mean().item()) < 0.05 * d.std().item()
