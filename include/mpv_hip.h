@@ -133,13 +133,20 @@ typedef struct {
  *         row b*P+p is sample s = c*P+p of node b:
  *             noise[((((w*(S/P) + c)*T + k)*(B*P) + b*P + p)*O + o)*F + f]
  *         When NULL, normals come from Philox4x32-10 keyed by `seed`, counter
- *         (chain_lo, chain_hi, k, offset) with chain = ((w*B+b)*O+o)*S+s, Box-Muller on
- *         the four output words (feature f uses normal f).
+ *         (chain_lo, chain_hi, block, offset) with chain = ((w*B+b)*O+o)*S+s, Box-Muller on
+ *         the four output words.  Draw k, feature f uses normal (k*F+f)&3 of block (k*F)>>2
+ *         when F is 1 or 2 (all four normals of a block are consumed), normal f of block k
+ *         when F is 3 or 4.
  * samples: dev [W][B][O][F][S] -- window w's slice is the reference's `outs`
  *         [B, pred_len, F, n_z_samples] (NsDiff_model.py:262-266).
  */
 int mpv_nsdiff_sample(mpv_ctx* ctx, const mpv_sample_shape* shape, const float* y0hat, const float* gx,
                       const float* noise, float* samples);
+
+/* Bound on |pre-activation| of layers 2 and 3 proved at load time from the weights
+ * (max |gamma| (||W_row||_2 + |b|); the layer input has unit 2-norm).  Below 4 the f16x3 kernel
+ * drops the exp-overflow / log1p small-argument guards of those layers (validation aid). */
+int mpv_nsdiff_preact_bound(mpv_ctx* ctx, float* bound);
 
 /* Debug/validation helper: write the Philox normals mpv_nsdiff_sample would consume, in the
  * dense layout [n_chains][T][F] (chain-major), so a CPU checker can replay them. */

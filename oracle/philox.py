@@ -27,13 +27,18 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def normals(seed: int, offset: int, n_chains: int, steps: int, nf: int) -> np.ndarray:
-    """[n_chains, steps, nf] float32 normals = what mpv_nsdiff_philox_normals writes."""
-    chain = np.repeat(np.arange(n_chains, dtype=np.uint64), steps)
-    k = np.tile(np.arange(steps, dtype=np.uint64), n_chains)
+    """[n_chains, steps, nf] float32 normals = what mpv_nsdiff_philox_normals writes.
+
+    Draw k, feature f takes normal (k*nf+f)&3 of Philox block (k*nf)>>2 when nf is 1 or 2 (all four
+    normals of a block are used), normal f of block k otherwise (csrc/chain_common.h::step_normals)."""
+    packed = nf in (1, 2)
+    n_blocks = (steps * nf + 3) // 4 if packed else steps
+    chain = np.repeat(np.arange(n_chains, dtype=np.uint64), n_blocks)
+    blk = np.tile(np.arange(n_blocks, dtype=np.uint64), n_chains)
     seed_lo, seed_hi = seed & 0xFFFFFFFF, ((seed >> 32) + (offset >> 32)) & 0xFFFFFFFF
-    x = philox4x32_10(chain & MASK, chain >> np.uint64(32), k, np.full_like(k, offset & 0xFFFFFFFF), seed_lo, seed_hi)
+    x = philox4x32_10(chain & MASK, chain >> np.uint64(32), blk, np.full_like(blk, offset & 0xFFFFFFFF), seed_lo, seed_hi)
     inv24 = np.float32(2.0 ** -24)
-    z = np.empty((n_chains * steps, 4), dtype=np.float32)
+    z = np.empty((n_chains * n_blocks, 4), dtype=np.float32)
     for i in range(2):
         u1 = ((x[2 * i] >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * inv24
         u2 = (x[2 * i + 1] >> np.uint32(8)).astype(np.float32) * inv24
@@ -41,4 +46,6 @@ def normals(seed: int, offset: int, n_chains: int, steps: int, nf: int) -> np.nd
         ang = 2.0 * np.pi * u2.astype(np.float64)
         z[:, 2 * i] = rad * np.cos(ang).astype(np.float32)
         z[:, 2 * i + 1] = rad * np.sin(ang).astype(np.float32)
+    if packed:
+        return z.reshape(n_chains, n_blocks * 4)[:, : steps * nf].reshape(n_chains, steps, nf)
     return z[:, :nf].reshape(n_chains, steps, nf)

@@ -185,10 +185,11 @@ def test_evaluation_step_gaussian_variant(golden_cases):
     assert rel_err(outs, golden_cases["eval_gauss_out"]) < RTOL
 
 
-def test_philox_mode_replays_through_oracle():
+@pytest.mark.parametrize("nf,steps", [(2, 10), (1, 50), (1, 7)])
+def test_philox_mode_replays_through_oracle(nf, steps):
     """Device Philox normals == numpy restatement, and a Philox-mode launch == the oracle fed
     the normals the device dumped."""
-    sd, nf, steps = O.random_state_dict(2, 10, 200, 200, 100, seed=321), 2, 10
+    sd = O.random_state_dict(nf, steps, 200, 200, 100, seed=321)
     ctx = make_ctx(sd, nf, steps)
     W, B, Ol, S = 2, 3, 7, 5
     n_chains = W * B * Ol * S
@@ -211,6 +212,28 @@ def test_philox_mode_replays_through_oracle():
     assert torch.equal(got, again)                                            # counter-based: bitwise repeatable
     other = ctx.sample(gx.to(dev()), y0.to(dev()), S, S, seed=100, offset=5).cpu()
     assert not torch.equal(got, other)
+
+
+def test_fast_and_guarded_activation_paths_are_both_exercised(ckpt_wofx):
+    """Seeded-init weights prove |pre-activation| < 4 (fast epilogue); scaled-up weights force the guarded one,
+    including pre-activations beyond torch's softplus threshold (x > 20)."""
+    sd = O.random_state_dict(1, 10, 100, 100, 50, seed=5)
+    ctx = make_ctx(sd, 1, 10)
+    assert ctx.preact_bound() < 4.0
+    big = dict(sd)
+    for i in (2, 3):
+        big[O.EPS_NET + "lin%d.lin.weight" % i] = sd[O.EPS_NET + "lin%d.lin.weight" % i] * 60.0
+    ctx_big = make_ctx(big, 1, 10)
+    assert ctx_big.preact_bound() > 20.0
+    g = torch.Generator().manual_seed(9)
+    gx = (torch.rand(1, 4, 6, 1, generator=g) + 0.1)
+    noise = torch.randn(10, 4, 6, 1, generator=g)
+    tb = O.schedule_tables(10)
+    for c, w in ((ctx, sd), (ctx_big, big)):
+        want = O.sample_loop(w, tb, torch.zeros(4, 6, 1), gx[0], torch.zeros(4, 6, 1), 10, O.replay_noise(list(noise)))
+        for gemm in ("f16x3", "f32"):
+            got = c.sample(gx.to(dev()), None, 1, 1, noise=noise.to(dev()), gemm=gemm)[0, :, :, :, 0].cpu()
+            assert rel_err(got, want) < RTOL, gemm
 
 
 def test_ragged_and_empty_batches():

@@ -23,7 +23,7 @@ GEMM_MODES = {"f16x3": 0, "f32": 1}
 
 EXPORTS = (
     "mpv_abi_version", "mpv_ctx_create", "mpv_ctx_destroy", "mpv_ctx_set_stream", "mpv_last_error",
-    "mpv_nsdiff_load", "mpv_nsdiff_sample", "mpv_nsdiff_philox_normals", "mpv_sigma_load", "mpv_sigma_head",
+    "mpv_nsdiff_load", "mpv_nsdiff_sample", "mpv_nsdiff_preact_bound", "mpv_nsdiff_philox_normals", "mpv_sigma_load", "mpv_sigma_head",
     "mpv_reduce", "mpv_chain_timing", "mpv_chain_timing_enable",
 )
 
@@ -83,6 +83,7 @@ def load_library():
         "mpv_nsdiff_load": (C.c_int, [vp, C.POINTER(NsdiffDesc), C.POINTER(NsdiffWeights), _F]),
         "mpv_nsdiff_sample": (C.c_int, [vp, C.POINTER(SampleShape), vp, vp, vp, vp]),
         "mpv_nsdiff_philox_normals": (C.c_int, [vp, u64, u64, i64, vp]),
+        "mpv_nsdiff_preact_bound": (C.c_int, [vp, C.POINTER(C.c_float)]),
         "mpv_sigma_load": (C.c_int, [vp, C.POINTER(SigmaDesc), C.POINTER(SigmaWeights)]),
         "mpv_sigma_head": (C.c_int, [vp, vp, i32, i64, i32, i64, i64, vp, vp, f32, vp]),
         "mpv_reduce": (C.c_int, [vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
@@ -228,6 +229,11 @@ class Context:
                                                _dev_ptr(gx, self.device, "gx"), _dev_ptr(noise, self.device, "noise"),
                                                _dev_ptr(out, self.device, "samples")), "mpv_nsdiff_sample")
         return out
+
+    def preact_bound(self) -> float:
+        b = C.c_float()
+        self._check(self.lib.mpv_nsdiff_preact_bound(self._h, C.byref(b)), "mpv_nsdiff_preact_bound")
+        return b.value
 
     def philox_normals(self, seed: int, offset: int, n_chains: int) -> torch.Tensor:
         if self.nsdiff is None:

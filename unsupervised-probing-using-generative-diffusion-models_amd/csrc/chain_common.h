@@ -93,6 +93,27 @@ __device__ __forceinline__ void philox_normals(unsigned long long chain, unsigne
 }
 
 
+// Normal draw k (0 = z_T, k = T - t for step t) of one chain, feature f = z[f].  One Philox block gives four
+// normals; when F divides 4 they are used up over 4/F consecutive draws (element (k*F + f) & 3 of block
+// (k*F) >> 2, kept in `cache` between steps), otherwise block k serves draw k.
+template <int F>
+__device__ __forceinline__ void step_normals(unsigned long long chain, unsigned k, unsigned seed_lo, unsigned seed_hi,
+                                             unsigned off_lo, float (&cache)[4], float (&z)[4]) {
+    if (F == 1 || F == 2) {
+        const unsigned idx = k * F;
+        if ((idx & 3u) == 0u) philox_normals(chain, idx >> 2, seed_lo, seed_hi, off_lo, cache);
+        const unsigned e = idx & 3u;
+        if (F == 1) {
+            z[0] = e == 0u ? cache[0] : (e == 1u ? cache[1] : (e == 2u ? cache[2] : cache[3]));
+        } else {
+            z[0] = e ? cache[2] : cache[0];
+            z[1] = e ? cache[3] : cache[1];
+        }
+    } else {
+        philox_normals(chain, k, seed_lo, seed_hi, off_lo, z);
+    }
+}
+
 // hidden-unit index of register (4q+e) of out-tile j in half-wave h is 32j + 8q + 4h + e
 __device__ __forceinline__ int hbase(int j, int q, int h) { return 32 * j + 8 * q + 4 * h; }
 

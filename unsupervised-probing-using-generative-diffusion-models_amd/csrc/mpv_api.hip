@@ -190,6 +190,16 @@ int mpv_nsdiff_load(mpv_ctx* ctx, const mpv_nsdiff_desc* d, const mpv_nsdiff_wei
         g3[i] = std::ldexp(w->embed[2][i] * LOG2E, -(s3 + ACT));
     }
     for (size_t i = 0; i < (size_t)F * H; ++i) wsl[i] = w->sig_w[i] * LN2;
+    // |x_j| = |gamma_tj (W_j . h + b_j)| <= |gamma_tj| (||W_j||_2 + |b_j|) because the layer input has unit 2-norm
+    float bound = 0.0f;
+    for (int L = 1; L <= 2; ++L)
+        for (int j = 0; j < H; ++j) {
+            double n2 = 0.0;
+            for (int k = 0; k < H; ++k) n2 += (double)w->lin_w[L][(size_t)j * H + k] * w->lin_w[L][(size_t)j * H + k];
+            const float reach = (float)std::sqrt(n2) + std::fabs(w->lin_b[L][j]);
+            for (int t = 0; t < T; ++t) bound = std::fmax(bound, std::fabs(w->embed[L][(size_t)t * H + j]) * reach);
+        }
+    m.preact_bound23 = std::isfinite(bound) ? bound : 1e30f;
     auto as_f32 = [](const std::vector<unsigned short>& v) { return reinterpret_cast<const float*>(v.data()); };
     std::vector<const float*> d16;
     rc = upload_blob(ctx,
@@ -221,6 +231,14 @@ int mpv_nsdiff_sample(mpv_ctx* ctx, const mpv_sample_shape* s, const float* y0ha
         return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: n_samples must be a positive multiple of chunk");
     DeviceGuard g(ctx->device);
     return launch_nsdiff_chain(ctx, *s, y0hat, gx, noise, samples);
+}
+
+int mpv_nsdiff_preact_bound(mpv_ctx* ctx, float* bound) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nsdiff_preact_bound: ctx is NULL");
+    if (!ctx->ns.loaded) return mpv_fail(ctx, MPV_ESTATE, "mpv_nsdiff_preact_bound: call mpv_nsdiff_load first");
+    if (!bound) return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_preact_bound: NULL argument");
+    *bound = ctx->ns.preact_bound23;
+    return MPV_OK;
 }
 
 int mpv_nsdiff_philox_normals(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out) {

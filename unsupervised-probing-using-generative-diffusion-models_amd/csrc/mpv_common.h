@@ -16,6 +16,7 @@ struct NsdiffModel {
     float* blob16 = nullptr;
     const unsigned short *w2h, *w2l, *w3h, *w3l;
     const float *b2s, *b3s, *g1, *g2, *g3, *wsl;
+    float preact_bound23 = 1e30f;   // max over t, unit of |gamma| (||W_row||_2 + |b|) for layers 2 and 3
 };
 
 struct SigmaModel {

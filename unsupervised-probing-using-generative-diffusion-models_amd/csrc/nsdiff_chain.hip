@@ -129,7 +129,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_kernel(const 
         const int b = (int)(gi % p.B);
         const long long w = gi / p.B;
 
-        float g[F], mu[F], y[F], z[4];
+        float g[F], mu[F], y[F], z[4], zc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             g[f] = p.gx[row * F + f];
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_kernel(const 
         }
         // y_T = sqrt(g) * z_T + mu       (nsdiff_utils.py:273-274)
         if (PHILOX) {
-            philox_normals((unsigned long long)n, 0u, p.seed_lo, p.seed_hi, p.off_lo, z);
+            step_normals<F>((unsigned long long)n, 0u, p.seed_lo, p.seed_hi, p.off_lo, zc, z);
         } else {
 #pragma unroll
             for (int f = 0; f < F; ++f) z[f] = p.noise[nbase + f];
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_kernel(const 
             // the step's normal draw (k = T - t); unused at t == 0
             if (t > 0) {
                 if (PHILOX) {
-                    philox_normals((unsigned long long)n, (unsigned)(p.T - t), p.seed_lo, p.seed_hi, p.off_lo, z);
+                    step_normals<F>((unsigned long long)n, (unsigned)(p.T - t), p.seed_lo, p.seed_hi, p.off_lo, zc, z);
                 } else {
 #pragma unroll
                     for (int f = 0; f < F; ++f) z[f] = p.noise[nbase + (long long)(p.T - t) * p.noise_kstride + f];
@@ -240,15 +240,16 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_kernel(const 
     }
 }
 
-__global__ void philox_dump_kernel(float* out, long long n_chains, int T, int F, unsigned seed_lo, unsigned seed_hi,
+template <int F>
+__global__ void philox_dump_kernel(float* out, long long n_chains, int T, unsigned seed_lo, unsigned seed_hi,
                                    unsigned off_lo) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_chains * T) return;
-    const long long n = i / T;
-    const int k = (int)(i % T);
-    float z[4];
-    philox_normals((unsigned long long)n, (unsigned)k, seed_lo, seed_hi, off_lo, z);
-    for (int f = 0; f < F; ++f) out[i * F + f] = z[f];
+    const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_chains) return;
+    float z[4], zc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < T; ++k) {                       // same sequential consumption as the sampler
+        step_normals<F>((unsigned long long)n, (unsigned)k, seed_lo, seed_hi, off_lo, zc, z);
+        for (int f = 0; f < F; ++f) out[(n * T + k) * F + f] = z[f];
+    }
 }
 
 template <int F>
@@ -318,12 +319,16 @@ int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0
 
 int launch_philox_dump(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out) {
     const NsdiffModel& m = ctx->ns;
-    const long long total = (long long)n_chains * m.steps;
-    if (total == 0) return MPV_OK;
+    if (n_chains == 0) return MPV_OK;
     const int threads = 256;
-    const long long blocks = (total + threads - 1) / threads;
-    hipLaunchKernelGGL(philox_dump_kernel, dim3((unsigned)blocks), dim3(threads), 0, ctx->stream, out, (long long)n_chains,
-                       m.steps, m.nf, (unsigned)seed, (unsigned)(seed >> 32) + (unsigned)(offset >> 32), (unsigned)offset);
+    const dim3 grid((unsigned)((n_chains + threads - 1) / threads)), block(threads);
+    const unsigned lo = (unsigned)seed, hi = (unsigned)(seed >> 32) + (unsigned)(offset >> 32), off = (unsigned)offset;
+    switch (m.nf) {
+        case 1: hipLaunchKernelGGL(philox_dump_kernel<1>, grid, block, 0, ctx->stream, out, (long long)n_chains, m.steps, lo, hi, off); break;
+        case 2: hipLaunchKernelGGL(philox_dump_kernel<2>, grid, block, 0, ctx->stream, out, (long long)n_chains, m.steps, lo, hi, off); break;
+        case 3: hipLaunchKernelGGL(philox_dump_kernel<3>, grid, block, 0, ctx->stream, out, (long long)n_chains, m.steps, lo, hi, off); break;
+        default: hipLaunchKernelGGL(philox_dump_kernel<4>, grid, block, 0, ctx->stream, out, (long long)n_chains, m.steps, lo, hi, off); break;
+    }
     MPV_HIP_TRY(ctx, hipGetLastError());
     return MPV_OK;
 }

@@ -48,15 +48,22 @@ constexpr int F_B3S = F_B2S + HID;
 constexpr int F_W4 = F_B3S + HID;
 constexpr int F_WSL = F_W4 + MPV_MAX_NF * HID;
 constexpr int F_HB = F_WSL + MPV_MAX_NF * HID;
-constexpr int F_FLOATS = F_HB + 8;
+constexpr int F_GAM = F_HB + 8;                  // per wave: the three folded scale rows of its current step [3][128]
+constexpr int F_FLOATS = F_GAM + WAVES * 3 * HID;
 constexpr int LDS_BYTES = B_F32 + F_FLOATS * 4;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 constexpr float LOG2E = 1.44269504088896341f;
 constexpr float HALF_LOG2E = 0.72134752044448170f;
 constexpr float LN2 = 0.693147180559945309f;
 
-// softplus(x) / ln2 from x' = x * log2(e); plain VALU + one v_exp + one v_log, no compares
+// softplus(x) / ln2 from x' = x * log2(e); plain VALU + one v_exp + one v_log, no compares.
+// SAFE: any x' (clamp against exp2 overflow, small-e clamp for log1p accuracy, max with x' = torch's
+// threshold branch).  !SAFE: the host has proved |x| < 4 for this layer (||h|| = 1, so |x| <=
+// gamma (||W_row|| + |b|)), where 2^-6 < e < 2^6 and log2(1+e) needs none of that.
+template <bool SAFE>
 __device__ __forceinline__ float softplus_log2(float xs) {
+    if (!SAFE) return __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(xs));
     const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(xs, -3.0e38f, 126.0f));
     const float c = __builtin_amdgcn_logf(1.0f + e);
     const float lo = e * __builtin_fmaf(e, -HALF_LOG2E, LOG2E);       // (e - e^2/2)/ln2  <= log2(1+e)
@@ -65,6 +72,7 @@ __device__ __forceinline__ float softplus_log2(float xs) {
 }
 
 // acc (pre-activations, any scale) -> l = softplus(gamma''*acc)/ln2 in place; returns 1/max(||l||, eps/ln2)
+template <bool SAFE>
 __device__ __forceinline__ float activate_log2(f32x16 (&acc)[4], const float* __restrict__ grow, int h) {
     float ss = 0.0f;
 #pragma unroll
@@ -74,7 +82,7 @@ __device__ __forceinline__ float activate_log2(f32x16 (&acc)[4], const float* __
             const f32x4 gm = *reinterpret_cast<const f32x4*>(grow + hbase(j, q, h));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float l = softplus_log2(gm[e] * acc[j][q * 4 + e]);
+                const float l = softplus_log2<SAFE>(gm[e] * acc[j][q * 4 + e]);
                 acc[j][q * 4 + e] = l;
                 ss = __builtin_fmaf(l, l, ss);
             }
@@ -129,7 +137,7 @@ __device__ __forceinline__ void mfma_layer_f16(const unsigned char* __restrict__
     }
 }
 
-template <int F, bool PHILOX>
+template <int F, bool PHILOX, bool SAFE23>
 __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* ldsf = reinterpret_cast<float*>(smem + B_F32);
@@ -163,6 +171,9 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
     const int wave = threadIdx.x >> 6;
     const int r_lane = lane & 31, h_lane = lane >> 5;
     const float act_scale = (float)(1 << ACT_SCALE_LOG2);
+    float* gam = ldsf + F_GAM + wave * (3 * HID);        // this wave's [3][128] scale rows (wave-private: no barrier)
+    // lanes 0..31 fetch 4 consecutive floats of each of the 3 rows; coalesced, once per step
+    const int gl = (lane & 31) * 4;
 
     for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < p.n_tiles; tile += (long long)gridDim.x * WAVES) {
         const long long n_raw = tile * TILE + r_lane;
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
         const int b = (int)(gi % p.B);
         const long long w = gi / p.B;
 
-        float g[F], mu[F], y[F], z[4];
+        float g[F], mu[F], y[F], z[4], zc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             g[f] = p.gx[row * F + f];
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
                     (long long)o * F;
         }
         if (PHILOX) {
-            philox_normals((unsigned long long)n, 0u, p.seed_lo, p.seed_hi, p.off_lo, z);
+            step_normals<F>((unsigned long long)n, 0u, p.seed_lo, p.seed_hi, p.off_lo, zc, z);
         } else {
 #pragma unroll
             for (int f = 0; f < F; ++f) z[f] = p.noise[nbase + f];
@@ -199,14 +210,28 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
             y[f] = sqrtf(g[f]) * z[f] + mu[f];
         }
 
+        if (lane < 32) {                                   // rows of the first step t = T-1
+            const long long g0 = (long long)(p.T - 1) * HID + gl;
+            *reinterpret_cast<f32x4*>(gam + gl) = *reinterpret_cast<const f32x4*>(p.g1 + g0);
+            *reinterpret_cast<f32x4*>(gam + HID + gl) = *reinterpret_cast<const f32x4*>(p.g2 + g0);
+            *reinterpret_cast<f32x4*>(gam + 2 * HID + gl) = *reinterpret_cast<const f32x4*>(p.g3 + g0);
+        }
 #pragma nounroll
         for (int t = p.T - 1; t >= 0; --t) {
             // keep the (t-invariant) LDS operand loads inside the step loop: see nsdiff_chain.hip
             int h = h_lane, r = r_lane;
             asm volatile("" : "+v"(h), "+v"(r));
+            // prefetch the next step's scale rows into registers now, park them in LDS at the end of the step
+            f32x4 nx1 = {0, 0, 0, 0}, nx2 = nx1, nx3 = nx1;
+            if (t > 0 && lane < 32) {
+                const long long g0 = (long long)(t - 1) * HID + gl;
+                nx1 = *reinterpret_cast<const f32x4*>(p.g1 + g0);
+                nx2 = *reinterpret_cast<const f32x4*>(p.g2 + g0);
+                nx3 = *reinterpret_cast<const f32x4*>(p.g3 + g0);
+            }
             if (t > 0) {
                 if (PHILOX) {
-                    philox_normals((unsigned long long)n, (unsigned)(p.T - t), p.seed_lo, p.seed_hi, p.off_lo, z);
+                    step_normals<F>((unsigned long long)n, (unsigned)(p.T - t), p.seed_lo, p.seed_hi, p.off_lo, zc, z);
                 } else {
 #pragma unroll
                     for (int f = 0; f < F; ++f) z[f] = p.noise[nbase + (long long)(p.T - t) * p.noise_kstride + f];
@@ -231,14 +256,14 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
                     for (int e = 0; e < 4; ++e) acc[j][q * 4 + e] = a[e];
                 }
             }
-            float inv = activate_log2(acc, p.g1 + (long long)t * HID, h);
+            float inv = activate_log2<true>(acc, gam, h);
             split_f16(acc, inv * act_scale, bh, bl);
             // ---- layers 2 and 3 on the f16 matrix pipe ----------------------------------------------
             mfma_layer_f16(smem + B_W2H, smem + B_W2L, ldsf + F_B2S, bh, bl, acc, r, h);
-            inv = activate_log2(acc, p.g2 + (long long)t * HID, h);
+            inv = activate_log2<SAFE23>(acc, gam + HID, h);
             split_f16(acc, inv * act_scale, bh, bl);
             mfma_layer_f16(smem + B_W3H, smem + B_W3L, ldsf + F_B3S, bh, bl, acc, r, h);
-            inv = activate_log2(acc, p.g3 + (long long)t * HID, h);
+            inv = activate_log2<SAFE23>(acc, gam + 2 * HID, h);
             // ---- heads on h3 = acc * inv (in [0,1]):  eps = W4 h3 + b4 ; sigma = softplus((Ws ln2) softplus(h3)/ln2 + bs)
             float ea[F], sa[F];
 #pragma unroll
@@ -276,6 +301,11 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
                 const float sig = softplus_dev(sa[f] + __shfl_xor(sa[f], 32) + ldsf[F_HB + 4 + f]);
                 y[f] = posterior(c, y[f], mu[f], g[f], eps, sig, z[f], t == 0);
             }
+            if (t > 0 && lane < 32) {                       // all reads of this step's rows are done (same wave, in order)
+                *reinterpret_cast<f32x4*>(gam + gl) = nx1;
+                *reinterpret_cast<f32x4*>(gam + HID + gl) = nx2;
+                *reinterpret_cast<f32x4*>(gam + 2 * HID + gl) = nx3;
+            }
         }
         if (valid && h_lane == 0) {
 #pragma unroll
@@ -284,10 +314,10 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
     }
 }
 
-template <int F>
-int launch_f16_f(mpv_ctx* ctx, const ChainArgs& a, bool philox, int grid) {
-    auto kp = nsdiff_chain_f16_kernel<F, true>;
-    auto kn = nsdiff_chain_f16_kernel<F, false>;
+template <int F, bool SAFE23>
+int launch_f16_fs(mpv_ctx* ctx, const ChainArgs& a, bool philox, int grid) {
+    auto kp = nsdiff_chain_f16_kernel<F, true, SAFE23>;
+    auto kn = nsdiff_chain_f16_kernel<F, false, SAFE23>;
     MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(philox ? kp : kn),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     if (philox)
@@ -298,16 +328,23 @@ int launch_f16_f(mpv_ctx* ctx, const ChainArgs& a, bool philox, int grid) {
     return MPV_OK;
 }
 
+template <int F>
+int launch_f16_f(mpv_ctx* ctx, const ChainArgs& a, bool philox, int grid, bool safe23) {
+    return safe23 ? launch_f16_fs<F, true>(ctx, a, philox, grid) : launch_f16_fs<F, false>(ctx, a, philox, grid);
+}
+
 }  // namespace
 
 int launch_chain_f16(mpv_ctx* ctx, const chain::ChainArgs& a, bool philox, int grid, int nf) {
+    // layers 2/3 may drop the overflow / small-argument guards when |pre-activation| < 4 is proven (mpv_nsdiff_load)
+    const bool safe23 = !(ctx->ns.preact_bound23 < 4.0f);
     if ((size_t)LDS_BYTES > ctx->max_lds)
         return mpv_fail(ctx, MPV_EINVAL, "device LDS too small for the resident-weight chain kernel");
     switch (nf) {
-        case 1: return launch_f16_f<1>(ctx, a, philox, grid);
-        case 2: return launch_f16_f<2>(ctx, a, philox, grid);
-        case 3: return launch_f16_f<3>(ctx, a, philox, grid);
-        case 4: return launch_f16_f<4>(ctx, a, philox, grid);
+        case 1: return launch_f16_f<1>(ctx, a, philox, grid, safe23);
+        case 2: return launch_f16_f<2>(ctx, a, philox, grid, safe23);
+        case 3: return launch_f16_f<3>(ctx, a, philox, grid, safe23);
+        case 4: return launch_f16_f<4>(ctx, a, philox, grid, safe23);
         default: return mpv_fail(ctx, MPV_EINVAL, "nf must be 1..4");
     }
 }
