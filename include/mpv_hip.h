@@ -109,7 +109,7 @@ typedef struct {
  *  15 sa   = sqrt(a)                                gamma_1 = sa*Sigma_2/D
  *  16 k1   = sa*(a-1)                               gamma_2 = (k1*Sigma_2 + k2*Sigma_1)/D
  *  17 k2   = 1-sp
- *  18,19 reserved (0)
+ *  18,19 reserved: filled by mpv_nsdiff_load (bound coefficients of the layer-1 pre-activation)
  */
 int mpv_nsdiff_load(mpv_ctx* ctx, const mpv_nsdiff_desc* desc, const mpv_nsdiff_weights* host_weights,
                     const float* host_coef);

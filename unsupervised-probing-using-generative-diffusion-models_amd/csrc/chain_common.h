@@ -39,7 +39,12 @@ struct ChainArgs {
     // f16x3 variant: split weights [128][128] f16 (columns permuted for the A fragment), scaled biases,
     // folded per-step scale tables, sigma head pre-multiplied by ln 2
     const unsigned short *w2h, *w2l, *w3h, *w3l;
-    const float *b2s, *b3s, *g1, *g2, *g3, *wsl;
+    const unsigned short* w1img;   // layer 1 as MFMA k-slots: [128][16*NK] f16 (nsdiff_chain_f16.hip::L1)
+    const unsigned *b2p, *b3p;     // layer 2/3 biases, (hi | lo << 16) f16 pairs of b * 2^sB
+    const float *g1, *g2, *g3, *wsl;
+    float bone2, bone3;            // B-operand value of the bias MFMA: 2^(s_layer + 12 - sB)
+    float l1_scale;                // 2^(s1 + 4): scale of the layer-1 accumulators
+    unsigned hi_mask;              // 0xFFFFE000: keeps the 11 leading significand bits of an fp32
     const float* y0hat;
     const float* gx;
     const float* noise;

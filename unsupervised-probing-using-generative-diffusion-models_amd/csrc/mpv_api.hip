@@ -1,4 +1,5 @@
 // C ABI of libmpv_hip (include/mpv_hip.h): context, weight upload, argument checks, dispatch.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -172,22 +173,60 @@ int mpv_nsdiff_load(mpv_ctx* ctx, const mpv_nsdiff_desc* d, const mpv_nsdiff_wei
     m.w1t = dev[0]; m.w2 = dev[1]; m.w3 = dev[2]; m.b1 = dev[3]; m.b2 = dev[4]; m.b3 = dev[5];
     m.e1 = dev[6]; m.e2 = dev[7]; m.e3 = dev[8]; m.w4 = dev[9]; m.ws = dev[10]; m.b4 = dev[11]; m.bs = dev[12];
     m.coef = dev[13];
-    // ---- split-f16 variant: scaled/split weights, scaled biases, folded per-step tables ---------------
+    // ---- split-f16 variant (nsdiff_chain_f16.hip): scaled/split weights, biases as MFMA k-slots, folded
+    // per-step scale rows, layer-1 pre-activation bound coefficients
     const float LOG2E = 1.44269504088896341f, LN2 = 0.693147180559945309f;
-    const int s2 = scale_log2(w->lin_w[1], (size_t)H * H), s3 = scale_log2(w->lin_w[2], (size_t)H * H);
-    std::vector<unsigned short> w2h, w2l, w3h, w3l;
-    split_weights(w->lin_w[1], s2, &w2h, &w2l);
-    split_weights(w->lin_w[2], s3, &w3h, &w3l);
-    const int ACT = 12;                                   // activation scale 2^12 (nsdiff_chain_f16.hip)
-    std::vector<float> b2s(H), b3s(H), g1((size_t)T * H), g2((size_t)T * H), g3((size_t)T * H), wsl((size_t)F * H);
-    for (int i = 0; i < H; ++i) {
-        b2s[i] = std::ldexp(w->lin_b[1][i], s2 + ACT);
-        b3s[i] = std::ldexp(w->lin_b[2][i], s3 + ACT);
+    const int ACT = 12, INS = 4;                          // activations scaled 2^12, layer-1 inputs 2^4
+    auto f16bits = [](float x) { const _Float16 h = (_Float16)x; unsigned short u; std::memcpy(&u, &h, 2); return u; };
+    auto f16val = [](float x) { return (float)(_Float16)x; };
+    // layers 2/3: one power-of-two scale per matrix, chosen over {W, b/8} so the bias fits beside it
+    int sW[3] = {0, 0, 0}, sB[3] = {0, 0, 0};
+    for (int L = 1; L <= 2; ++L) {
+        std::vector<float> joint(w->lin_w[L], w->lin_w[L] + (size_t)H * H);
+        for (int i = 0; i < H; ++i) joint.push_back(w->lin_b[L][i] * 0.125f);
+        sW[L] = scale_log2(joint.data(), joint.size());
+        int s = scale_log2(w->lin_b[L], (size_t)H);
+        sB[L] = std::max(sW[L] - 3, std::min(s, sW[L] + ACT + 14));
     }
+    std::vector<unsigned short> w2h, w2l, w3h, w3l;
+    split_weights(w->lin_w[1], sW[1], &w2h, &w2l);
+    split_weights(w->lin_w[2], sW[2], &w3h, &w3l);
+    std::vector<unsigned> bp[3];
+    for (int L = 1; L <= 2; ++L) {
+        bp[L].resize(H);
+        for (int i = 0; i < H; ++i) {
+            const float x = std::ldexp(w->lin_b[L][i], sB[L]);
+            const float hi = f16val(x);
+            bp[L][i] = (unsigned)f16bits(hi) | ((unsigned)f16bits(x - hi) << 16);
+        }
+    }
+    m.bone2 = std::ldexp(1.0f, sW[1] + ACT - sB[1]);
+    m.bone3 = std::ldexp(1.0f, sW[2] + ACT - sB[2]);
+    // layer 1: one scale over {W1, b1}; k-slots: 3F x W_hi (x_hi), 3F x W_hi (x_lo), 3F x W_lo (x_hi), b_hi, b_lo
+    std::vector<float> joint1(w->lin_w[0], w->lin_w[0] + (size_t)H * 3 * F);
+    joint1.insert(joint1.end(), w->lin_b[0], w->lin_b[0] + H);
+    const int s1 = scale_log2(joint1.data(), joint1.size());
+    const int nk1 = (9 * F + 2 + 15) / 16;
+    std::vector<unsigned short> w1img((size_t)H * 16 * nk1, 0);
+    for (int j = 0; j < H; ++j) {
+        for (int c = 0; c < 3 * F; ++c) {
+            const float x = std::ldexp(w->lin_w[0][(size_t)j * 3 * F + c], s1);
+            const float hi = f16val(x);
+            w1img[(size_t)j * 16 * nk1 + c] = f16bits(hi);
+            w1img[(size_t)j * 16 * nk1 + 3 * F + c] = f16bits(hi);
+            w1img[(size_t)j * 16 * nk1 + 6 * F + c] = f16bits(x - hi);
+        }
+        const float b = std::ldexp(w->lin_b[0][j], s1);
+        const float bhi = f16val(b);
+        w1img[(size_t)j * 16 * nk1 + 9 * F] = f16bits(bhi);
+        w1img[(size_t)j * 16 * nk1 + 9 * F + 1] = f16bits(b - bhi);
+    }
+    m.l1_scale = std::ldexp(1.0f, s1 + INS);
+    std::vector<float> g1((size_t)T * H), g2((size_t)T * H), g3((size_t)T * H), wsl((size_t)F * H);
     for (size_t i = 0; i < (size_t)T * H; ++i) {
-        g1[i] = w->embed[0][i] * LOG2E;
-        g2[i] = std::ldexp(w->embed[1][i] * LOG2E, -(s2 + ACT));
-        g3[i] = std::ldexp(w->embed[2][i] * LOG2E, -(s3 + ACT));
+        g1[i] = std::ldexp(w->embed[0][i] * LOG2E, -(s1 + INS));
+        g2[i] = std::ldexp(w->embed[1][i] * LOG2E, -(sW[1] + ACT));
+        g3[i] = std::ldexp(w->embed[2][i] * LOG2E, -(sW[2] + ACT));
     }
     for (size_t i = 0; i < (size_t)F * H; ++i) wsl[i] = w->sig_w[i] * LN2;
     // |x_j| = |gamma_tj (W_j . h + b_j)| <= |gamma_tj| (||W_j||_2 + |b_j|) because the layer input has unit 2-norm
@@ -200,18 +239,36 @@ int mpv_nsdiff_load(mpv_ctx* ctx, const mpv_nsdiff_desc* d, const mpv_nsdiff_wei
             for (int t = 0; t < T; ++t) bound = std::fmax(bound, std::fabs(w->embed[L][(size_t)t * H + j]) * reach);
         }
     m.preact_bound23 = std::isfinite(bound) ? bound : 1e30f;
-    auto as_f32 = [](const std::vector<unsigned short>& v) { return reinterpret_cast<const float*>(v.data()); };
+    // layer 1 (inputs unbounded): |x'_j| <= K1_t + K2_t * sum_c |in_c| in log2 units -> coefficient columns 18, 19
+    std::vector<float> coef2(coef, coef + (size_t)T * MPV_COEF_COLS);
+    for (int t = 0; t < T; ++t) {
+        float k1 = 0.0f, k2 = 0.0f;
+        for (int j = 0; j < H; ++j) {
+            const float gl = std::fabs(w->embed[0][(size_t)t * H + j]) * LOG2E;
+            float wm = 0.0f;
+            for (int c = 0; c < 3 * F; ++c) wm = std::fmax(wm, std::fabs(w->lin_w[0][(size_t)j * 3 * F + c]));
+            k1 = std::fmax(k1, gl * std::fabs(w->lin_b[0][j]));
+            k2 = std::fmax(k2, gl * wm);
+        }
+        coef2[(size_t)t * MPV_COEF_COLS + 18] = std::isfinite(k1) ? k1 * 1.0001f : 1e30f;
+        coef2[(size_t)t * MPV_COEF_COLS + 19] = std::isfinite(k2) ? k2 * 1.0001f : 1e30f;
+    }
+    auto as_f32 = [](const void* v) { return reinterpret_cast<const float*>(v); };
     std::vector<const float*> d16;
     rc = upload_blob(ctx,
-                     {{as_f32(w2h), (size_t)H * H / 2}, {as_f32(w2l), (size_t)H * H / 2}, {as_f32(w3h), (size_t)H * H / 2},
-                      {as_f32(w3l), (size_t)H * H / 2}, {b2s.data(), (size_t)H}, {b3s.data(), (size_t)H},
+                     {{as_f32(w2h.data()), (size_t)H * H / 2}, {as_f32(w2l.data()), (size_t)H * H / 2},
+                      {as_f32(w3h.data()), (size_t)H * H / 2}, {as_f32(w3l.data()), (size_t)H * H / 2},
+                      {as_f32(w1img.data()), w1img.size() / 2}, {as_f32(bp[1].data()), (size_t)H}, {as_f32(bp[2].data()), (size_t)H},
                       {g1.data(), (size_t)T * H}, {g2.data(), (size_t)T * H}, {g3.data(), (size_t)T * H},
-                      {wsl.data(), (size_t)F * H}},
+                      {wsl.data(), (size_t)F * H}, {coef2.data(), coef2.size()}},
                      &ctx->ns.blob16, &d16);
     if (rc != MPV_OK) return rc;
     m.w2h = reinterpret_cast<const unsigned short*>(d16[0]); m.w2l = reinterpret_cast<const unsigned short*>(d16[1]);
     m.w3h = reinterpret_cast<const unsigned short*>(d16[2]); m.w3l = reinterpret_cast<const unsigned short*>(d16[3]);
-    m.b2s = d16[4]; m.b3s = d16[5]; m.g1 = d16[6]; m.g2 = d16[7]; m.g3 = d16[8]; m.wsl = d16[9];
+    m.w1img = reinterpret_cast<const unsigned short*>(d16[4]);
+    m.b2p = reinterpret_cast<const unsigned*>(d16[5]); m.b3p = reinterpret_cast<const unsigned*>(d16[6]);
+    m.g1 = d16[7]; m.g2 = d16[8]; m.g3 = d16[9]; m.wsl = d16[10];
+    m.coef = d16[11];                                     // same rows as given + columns 18, 19
     m.steps = T; m.nf = F; m.loaded = true;
     return MPV_OK;
 }

@@ -14,8 +14,10 @@ struct NsdiffModel {
     const float *w1t, *w2, *w3, *b1, *b2, *b3, *e1, *e2, *e3, *w4, *ws, *b4, *bs, *coef;
     // split-f16 matrix-core variant (see nsdiff_chain_f16.hip)
     float* blob16 = nullptr;
-    const unsigned short *w2h, *w2l, *w3h, *w3l;
-    const float *b2s, *b3s, *g1, *g2, *g3, *wsl;
+    const unsigned short *w2h, *w2l, *w3h, *w3l, *w1img;
+    const unsigned *b2p, *b3p;
+    const float *g1, *g2, *g3, *wsl;
+    float bone2 = 1.0f, bone3 = 1.0f, l1_scale = 1.0f;
     float preact_bound23 = 1e30f;   // max over t, unit of |gamma| (||W_row||_2 + |b|) for layers 2 and 3
 };
 

@@ -276,7 +276,8 @@ int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0
     a.w1t = m.w1t; a.w2 = m.w2; a.w3 = m.w3; a.b1 = m.b1; a.b2 = m.b2; a.b3 = m.b3;
     a.e1 = m.e1; a.e2 = m.e2; a.e3 = m.e3; a.w4 = m.w4; a.ws = m.ws; a.b4 = m.b4; a.bs = m.bs; a.coef = m.coef;
     a.w2h = m.w2h; a.w2l = m.w2l; a.w3h = m.w3h; a.w3l = m.w3l;
-    a.b2s = m.b2s; a.b3s = m.b3s; a.g1 = m.g1; a.g2 = m.g2; a.g3 = m.g3; a.wsl = m.wsl;
+    a.w1img = m.w1img; a.b2p = m.b2p; a.b3p = m.b3p; a.g1 = m.g1; a.g2 = m.g2; a.g3 = m.g3; a.wsl = m.wsl;
+    a.bone2 = m.bone2; a.bone3 = m.bone3; a.l1_scale = m.l1_scale; a.hi_mask = 0xFFFFE000u;
     a.y0hat = y0hat; a.gx = gx; a.noise = noise; a.samples = samples;
     a.T = m.steps; a.B = s.nodes; a.O = s.pred_len; a.S = s.n_samples; a.P = s.chunk; a.C = s.n_samples / s.chunk;
     a.n_chains = (long long)s.n_windows * s.nodes * s.pred_len * s.n_samples;
