@@ -91,8 +91,11 @@ def main():
         raise SystemExit("bench.py needs a ROCm device: the path has no CPU implementation")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    use_dist = world > 1 or os.environ.get("MPV_BENCH_FORCE_DIST") == "1"     # force: smoke the RCCL path on one GPU
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from mpv_amd import synthetic
     from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
@@ -118,14 +121,14 @@ def main():
         samples = ctx.sample(gx, None, S, P, seed=seed, gemm=args.gemm)
         mpv, pm, _ = ctx.reduce(samples, std_dev, mean_dev)
         curve = torch.stack([mpv, pm])                                                      # [2, W]
-        if world > 1:
+        if use_dist:
             out = torch.empty(world, 2, n_windows, device=device)
             dist.all_gather_into_tensor(out, curve)
             curve = out
         return curve.cpu()                                                                   # host copy = sync
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -144,7 +147,7 @@ def main():
     kernel_ms, launches = ctx.timing()
     ctx.timing_enable(False)
     log("timed %d steps in %.3f s; chain kernel avg %.2f ms" % (args.steps, elapsed, kernel_ms))
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -173,7 +176,7 @@ def main():
         out.update(cpu_baseline_and_parity(model, sampled, args.cpu_windows))
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
