@@ -148,6 +148,24 @@ int mpv_nsdiff_sample(mpv_ctx* ctx, const mpv_sample_shape* shape, const float* 
  * drops the exp-overflow / log1p small-argument guards of those layers (validation aid). */
 int mpv_nsdiff_preact_bound(mpv_ctx* ctx, float* bound);
 
+/* ------------------------------------------------------------------------------------
+ * TMDM sampler (CARD-style reverse process around a supplied prior mean)
+ * replaces: ConditionalGuidedModel.forward with cat_x & cat_y_pred (TMDM/tmdm_model.py:38-64),
+ *           p_sample / p_sample_t_1to0 / p_sample_loop (TMDM/tmdm_diffusion_utils.py:57-119) and the
+ *           tile/un-tile of TMDM_model.evaluation_step (TMDM/tmdm_adapter.py:131-155).
+ * The prior y_0_hat = ns-Transformer VAE mean (third-party torch_timeseries arithmetic) is an INPUT.
+ * Weights as mpv_nsdiff_weights with lin_w[0] = [128][2F], embed tables [T+1][128] (rows 0..T-1 used),
+ * sig_w / sig_b ignored (may be NULL).
+ * coef: host [T][MPV_COEF_COLS]: 0 invr = 1/sqrt(abar_t), 1 omr = 1-sqrt(abar_t), 2 s = sqrt(1-abar_t),
+ *       3..5 gamma_0..2, 6 sqrt(beta_hat_t)  (tmdm_diffusion_utils.py:69-88), rest 0.
+ * mpv_tmdm_sample: shape->pred_len is the SEQUENCE length the sampler runs on (label_len + pred_len);
+ * y0hat dev [W][B][L][F]; noise as in mpv_nsdiff_sample (draw 0 = z_T, then one per step t = T-1..1);
+ * samples dev [W][B][L][F][S]; shape->gemm must be MPV_GEMM_F32 (activations are not normalised, so the
+ * split-f16 path does not apply).
+ * ---------------------------------------------------------------------------------- */
+int mpv_tmdm_load(mpv_ctx* ctx, const mpv_nsdiff_desc* desc, const mpv_nsdiff_weights* host_weights, const float* host_coef);
+int mpv_tmdm_sample(mpv_ctx* ctx, const mpv_sample_shape* shape, const float* y0hat, const float* noise, float* samples);
+
 /* Debug/validation helper: write the Philox normals mpv_nsdiff_sample would consume, in the
  * dense layout [n_chains][T][F] (chain-major), so a CPU checker can replay them. */
 int mpv_nsdiff_philox_normals(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out_dev);

@@ -28,6 +28,12 @@ def golden_schedule():
     return np.load(GOLDEN / "nsdiff_schedule.npz")
 
 
+@pytest.fixture(scope="session")
+def golden_tmdm():
+    import numpy as np
+    return np.load(GOLDEN / "tmdm_cases.npz")
+
+
 def load_ckpt(tag):
     import numpy as np
     import torch

@@ -24,7 +24,7 @@ GEMM_MODES = {"f16x3": 0, "f32": 1}
 EXPORTS = (
     "mpv_abi_version", "mpv_ctx_create", "mpv_ctx_destroy", "mpv_ctx_set_stream", "mpv_last_error",
     "mpv_nsdiff_load", "mpv_nsdiff_sample", "mpv_nsdiff_preact_bound", "mpv_nsdiff_philox_normals", "mpv_sigma_load", "mpv_sigma_head",
-    "mpv_reduce", "mpv_chain_timing", "mpv_chain_timing_enable",
+    "mpv_reduce", "mpv_chain_timing", "mpv_chain_timing_enable", "mpv_tmdm_load", "mpv_tmdm_sample",
 )
 
 
@@ -82,6 +82,8 @@ def load_library():
         "mpv_last_error": (C.c_char_p, [vp]),
         "mpv_nsdiff_load": (C.c_int, [vp, C.POINTER(NsdiffDesc), C.POINTER(NsdiffWeights), _F]),
         "mpv_nsdiff_sample": (C.c_int, [vp, C.POINTER(SampleShape), vp, vp, vp, vp]),
+        "mpv_tmdm_load": (C.c_int, [vp, C.POINTER(NsdiffDesc), C.POINTER(NsdiffWeights), _F]),
+        "mpv_tmdm_sample": (C.c_int, [vp, C.POINTER(SampleShape), vp, vp, vp]),
         "mpv_nsdiff_philox_normals": (C.c_int, [vp, u64, u64, i64, vp]),
         "mpv_nsdiff_preact_bound": (C.c_int, [vp, C.POINTER(C.c_float)]),
         "mpv_sigma_load": (C.c_int, [vp, C.POINTER(SigmaDesc), C.POINTER(SigmaWeights)]),
@@ -136,6 +138,7 @@ class Context:
         if rc != 0:
             raise MpvError("mpv_ctx_create: {} ({})".format(rc, (self.lib.mpv_last_error(None) or b"").decode()))
         self.nsdiff = None     # (steps, nf)
+        self.tmdm = None       # (steps, nf)
         self.sigma = None      # SigmaDesc fields
 
     def close(self):
@@ -228,6 +231,46 @@ class Context:
         self._check(self.lib.mpv_nsdiff_sample(self._h, C.byref(shape), _dev_ptr(y0hat, self.device, "y0hat"),
                                                _dev_ptr(gx, self.device, "gx"), _dev_ptr(noise, self.device, "noise"),
                                                _dev_ptr(out, self.device, "samples")), "mpv_nsdiff_sample")
+        return out
+
+    # ---- TMDM sampler ----------------------------------------------------------------
+    def load_tmdm(self, steps: int, nf: int, lin_w: Sequence[torch.Tensor], lin_b: Sequence[torch.Tensor],
+                  embed: Sequence[torch.Tensor], eps_w, eps_b, coef: torch.Tensor):
+        """embed tables may carry the reference's T+1 rows (tmdm_model.py:25); rows 0..T-1 are uploaded."""
+        keep = [_host_f32(t) for t in (*lin_w, *lin_b)] + [_host_f32(t[:steps]) for t in embed] + \
+               [_host_f32(t) for t in (eps_w, eps_b, coef)]
+        want = [(HIDDEN, 2 * nf), (HIDDEN, HIDDEN), (HIDDEN, HIDDEN), (HIDDEN,), (HIDDEN,), (HIDDEN,),
+                (steps, HIDDEN), (steps, HIDDEN), (steps, HIDDEN), (nf, HIDDEN), (nf,), (steps, COEF_COLS)]
+        for t, shp in zip(keep, want):
+            if tuple(t.shape) != shp:
+                raise MpvError("TMDM weight has shape {}, expected {}".format(tuple(t.shape), shp))
+        w = NsdiffWeights()
+        for i in range(3):
+            w.lin_w[i], w.lin_b[i], w.embed[i] = _fptr(keep[i]), _fptr(keep[3 + i]), _fptr(keep[6 + i])
+        w.eps_w, w.eps_b = _fptr(keep[9]), _fptr(keep[10])
+        self._bind_stream()
+        self._check(self.lib.mpv_tmdm_load(self._h, C.byref(NsdiffDesc(steps, nf)), C.byref(w), _fptr(keep[11])),
+                    "mpv_tmdm_load")
+        self.tmdm = (steps, nf)
+
+    def sample_tmdm(self, y0hat: torch.Tensor, n_samples: int, chunk: int, noise: Optional[torch.Tensor] = None,
+                    seed: int = 0, offset: int = 0) -> torch.Tensor:
+        """y0hat [W, B, L, F] on device -> samples [W, B, L, F, S]."""
+        if self.tmdm is None:
+            raise MpvError("TMDM weights not loaded")
+        W, B, L, F = y0hat.shape
+        if F != self.tmdm[1]:
+            raise MpvError("y0hat has F={}, the model was loaded with F={}".format(F, self.tmdm[1]))
+        if noise is not None:
+            need = W * self.tmdm[0] * B * n_samples * L * F
+            if noise.numel() != need:
+                raise MpvError("noise has {} elements, the draw order needs {}".format(noise.numel(), need))
+        out = torch.empty((W, B, L, F, n_samples), device=self.device, dtype=torch.float32)
+        shape = SampleShape(W, B, L, n_samples, chunk, GEMM_MODES["f32"], seed & (2 ** 64 - 1), offset & (2 ** 64 - 1))
+        self._bind_stream()
+        self._check(self.lib.mpv_tmdm_sample(self._h, C.byref(shape), _dev_ptr(y0hat, self.device, "y0hat"),
+                                             _dev_ptr(noise, self.device, "noise"),
+                                             _dev_ptr(out, self.device, "samples")), "mpv_tmdm_sample")
         return out
 
     def preact_bound(self) -> float:

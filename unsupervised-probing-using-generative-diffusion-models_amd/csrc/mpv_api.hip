@@ -130,6 +130,7 @@ void mpv_ctx_destroy(mpv_ctx* ctx) {
     }
     if (ctx->ns.blob) (void)hipFree(ctx->ns.blob);
     if (ctx->ns.blob16) (void)hipFree(ctx->ns.blob16);
+    if (ctx->tm.blob) (void)hipFree(ctx->tm.blob);
     if (ctx->sg.blob) (void)hipFree(ctx->sg.blob);
     if (ctx->reduce_ws) (void)hipFree(ctx->reduce_ws);
     delete ctx;
@@ -288,6 +289,48 @@ int mpv_nsdiff_sample(mpv_ctx* ctx, const mpv_sample_shape* s, const float* y0ha
         return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: n_samples must be a positive multiple of chunk");
     DeviceGuard g(ctx->device);
     return launch_nsdiff_chain(ctx, *s, y0hat, gx, noise, samples);
+}
+
+int mpv_tmdm_load(mpv_ctx* ctx, const mpv_nsdiff_desc* d, const mpv_nsdiff_weights* w, const float* coef) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_tmdm_load: ctx is NULL");
+    if (!d || !w || !coef) return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_load: NULL argument");
+    if (d->steps < 1 || d->nf < 1 || d->nf > MPV_MAX_NF) return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_load: need steps >= 1 and 1 <= nf <= 4");
+    for (int i = 0; i < 3; ++i)
+        if (!w->lin_w[i] || !w->lin_b[i] || !w->embed[i]) return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_load: NULL weight");
+    if (!w->eps_w || !w->eps_b) return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_load: NULL head");
+    DeviceGuard g(ctx->device);
+    MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int T = d->steps, F = d->nf, H = MPV_HIDDEN;
+    const std::vector<float> w1t = transposed(w->lin_w[0], H, 2 * F);   // [2F][128]
+    std::vector<const float*> dev;
+    ctx->tm.loaded = false;
+    int rc = upload_blob(ctx,
+                         {{w1t.data(), (size_t)2 * F * H}, {w->lin_w[1], (size_t)H * H}, {w->lin_w[2], (size_t)H * H},
+                          {w->lin_b[0], H}, {w->lin_b[1], H}, {w->lin_b[2], H},
+                          {w->embed[0], (size_t)T * H}, {w->embed[1], (size_t)T * H}, {w->embed[2], (size_t)T * H},
+                          {w->eps_w, (size_t)F * H}, {w->eps_b, (size_t)F}, {coef, (size_t)T * MPV_COEF_COLS}},
+                         &ctx->tm.blob, &dev);
+    if (rc != MPV_OK) return rc;
+    NsdiffModel& m = ctx->tm;
+    m.w1t = dev[0]; m.w2 = dev[1]; m.w3 = dev[2]; m.b1 = dev[3]; m.b2 = dev[4]; m.b3 = dev[5];
+    m.e1 = dev[6]; m.e2 = dev[7]; m.e3 = dev[8]; m.w4 = dev[9]; m.b4 = dev[10]; m.coef = dev[11];
+    m.steps = T; m.nf = F; m.loaded = true;
+    return MPV_OK;
+}
+
+int mpv_tmdm_sample(mpv_ctx* ctx, const mpv_sample_shape* s, const float* y0hat, const float* noise, float* samples) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_tmdm_sample: ctx is NULL");
+    if (!ctx->tm.loaded) return mpv_fail(ctx, MPV_ESTATE, "mpv_tmdm_sample: call mpv_tmdm_load first");
+    if (!s) return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: NULL shape");
+    if (s->n_windows < 0 || s->nodes < 0 || s->pred_len < 0 || s->n_samples < 0)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: negative extent");
+    const bool empty = s->n_windows == 0 || s->nodes == 0 || s->pred_len == 0 || s->n_samples == 0;
+    if (!empty && (!y0hat || !samples)) return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: NULL argument");
+    if (s->gemm != MPV_GEMM_F32) return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: gemm must be MPV_GEMM_F32");
+    if (s->n_samples > 0 && (s->chunk < 1 || s->n_samples % s->chunk != 0))
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: n_samples must be a positive multiple of chunk");
+    DeviceGuard g(ctx->device);
+    return launch_tmdm_chain(ctx, *s, y0hat, noise, samples);
 }
 
 int mpv_nsdiff_preact_bound(mpv_ctx* ctx, float* bound) {

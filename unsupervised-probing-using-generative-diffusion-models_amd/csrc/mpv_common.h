@@ -34,6 +34,7 @@ struct mpv_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     NsdiffModel ns;
+    NsdiffModel tm;                // TMDM sampler weights (fp32 fields only)
     SigmaModel sg;
     double* reduce_ws = nullptr;   // partial sums of mpv_reduce
     size_t reduce_ws_bytes = 0;
@@ -58,6 +59,7 @@ int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0
                         const float* noise, float* samples);
 namespace chain { struct ChainArgs; }
 int launch_chain_f16(mpv_ctx* ctx, const chain::ChainArgs& a, bool philox, int grid, int nf);
+int launch_tmdm_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* noise, float* samples);
 int launch_philox_dump(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out);
 int launch_sigma_head(mpv_ctx* ctx, const float* series, int V, int64_t L, int n_windows, int64_t first, int64_t step,
                       const float* mean, const float* std, float add_eps, float* gx);

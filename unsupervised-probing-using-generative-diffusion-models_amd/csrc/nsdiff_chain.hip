@@ -30,7 +30,9 @@ using namespace chain;
 
 namespace {
 
-// v <- normalize(softplus(gamma * v)) over the 128 hidden units of each chain
+// v <- normalize(softplus(gamma * v)) over the 128 hidden units of each chain (TMDM: softplus only,
+// reference TMDM/tmdm_model.py:59-61)
+template <bool NORMALIZE>
 __device__ __forceinline__ void activate(float (&v)[64], const float* __restrict__ gamma_row, int h) {
     float ss = 0.0f;
 #pragma unroll
@@ -46,10 +48,21 @@ __device__ __forceinline__ void activate(float (&v)[64], const float* __restrict
             }
         }
     }
+    if (!NORMALIZE) return;
     ss += __shfl_xor(ss, 32);
     const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize eps
 #pragma unroll
     for (int i = 0; i < 64; ++i) v[i] *= inv;
+}
+
+// TMDM / CARD reverse step (reference TMDM/tmdm_diffusion_utils.py:57-90, 94-104): every coefficient is a
+// per-step scalar.  Columns: 0 invr = 1/sqrt(abar_t), 1 omr = 1 - sqrt(abar_t), 2 s = sqrt(1 - abar_t),
+// 3..5 gamma_0..2, 6 sqrt(beta_hat_t)
+__device__ __forceinline__ float posterior_tmdm(const float* cr, float y, float mu, float eps, float z, bool last) {
+#pragma clang fp contract(off)
+    const float y0r = cr[0] * (y - cr[1] * mu - eps * cr[2]);
+    if (last) return y0r;
+    return cr[3] * y0r + cr[4] * y + cr[5] * mu + cr[6] * z;
 }
 
 // acc = bias + W . hin on the fp32 matrix pipe; result copied back over hin
@@ -85,8 +98,11 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ Ws, const f
         for (int i = 0; i < 16; ++i) hv[j * 16 + i] = acc[j][i];
 }
 
-template <int F, bool PHILOX>
+// TMDM = false: NsDiff (inputs y, y0hat, g; normalised activations; eps and sigma heads; quadratic posterior).
+// TMDM = true : the CARD-style sampler of TMDM (inputs y, y0hat; plain softplus; eps head; scalar posterior).
+template <int F, bool PHILOX, bool TMDM>
 __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_kernel(const ChainArgs p) {
+    constexpr int NIN = TMDM ? 2 * F : 3 * F;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     // ---- stage the weights once per workgroup -------------------------------------------
@@ -95,7 +111,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_kernel(const 
         *reinterpret_cast<f32x4*>(lds + L_W2 + row * WROW + c4) = *reinterpret_cast<const f32x4*>(p.w2 + row * HID + c4);
         *reinterpret_cast<f32x4*>(lds + L_W3 + row * WROW + c4) = *reinterpret_cast<const f32x4*>(p.w3 + row * HID + c4);
     }
-    for (int i = threadIdx.x; i < 3 * F * HID; i += THREADS) lds[L_W1T + i] = p.w1t[i];
+    for (int i = threadIdx.x; i < NIN * HID; i += THREADS) lds[L_W1T + i] = p.w1t[i];
     for (int i = threadIdx.x; i < HID; i += THREADS) {
         lds[L_B1 + i] = p.b1[i];
         lds[L_B2 + i] = p.b2[i];
@@ -103,11 +119,11 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_kernel(const 
     }
     for (int i = threadIdx.x; i < F * HID; i += THREADS) {
         lds[L_W4 + i] = p.w4[i];
-        lds[L_WS + i] = p.ws[i];
+        if (!TMDM) lds[L_WS + i] = p.ws[i];
     }
     if (threadIdx.x < F) {
         lds[L_HB + threadIdx.x] = p.b4[threadIdx.x];
-        lds[L_HB + 4 + threadIdx.x] = p.bs[threadIdx.x];
+        if (!TMDM) lds[L_HB + 4 + threadIdx.x] = p.bs[threadIdx.x];
     }
     __syncthreads();
 
@@ -132,7 +148,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_kernel(const 
         float g[F], mu[F], y[F], z[4], zc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-            g[f] = p.gx[row * F + f];
+            g[f] = TMDM ? 1.0f : p.gx[row * F + f];          // TMDM: y_T = z + mean (tmdm_diffusion_utils.py:109-110)
             mu[f] = p.y0hat ? p.y0hat[row * F + f] : 0.0f;
         }
         long long nbase = 0;
@@ -182,22 +198,22 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_kernel(const 
                     for (int f = 0; f < F; ++f) {
                         a += *reinterpret_cast<const f32x4*>(lds + L_W1T + f * HID + base) * y[f];
                         a += *reinterpret_cast<const f32x4*>(lds + L_W1T + (F + f) * HID + base) * mu[f];
-                        a += *reinterpret_cast<const f32x4*>(lds + L_W1T + (2 * F + f) * HID + base) * g[f];
+                        if (!TMDM) a += *reinterpret_cast<const f32x4*>(lds + L_W1T + (2 * F + f) * HID + base) * g[f];
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) hv[j * 16 + q * 4 + e] = a[e];
                 }
             }
-            activate(hv, p.e1 + (long long)t * HID, h);
+            activate<!TMDM>(hv, p.e1 + (long long)t * HID, h);
             // ---- layers 2, 3 on the fp32 matrix pipe ---------------------------------------
             if (MPV_PRIO_MFMA >= 0) __builtin_amdgcn_s_setprio(MPV_PRIO_MFMA);
             mfma_layer(lds + L_W2, lds + L_B2, hv, r, h);
             if (MPV_PRIO_MFMA >= 0) __builtin_amdgcn_s_setprio(MPV_PRIO_MFMA ? 0 : 3);
-            activate(hv, p.e2 + (long long)t * HID, h);
+            activate<!TMDM>(hv, p.e2 + (long long)t * HID, h);
             if (MPV_PRIO_MFMA >= 0) __builtin_amdgcn_s_setprio(MPV_PRIO_MFMA);
             mfma_layer(lds + L_W3, lds + L_B3, hv, r, h);
             if (MPV_PRIO_MFMA >= 0) __builtin_amdgcn_s_setprio(MPV_PRIO_MFMA ? 0 : 3);
-            activate(hv, p.e3 + (long long)t * HID, h);
+            activate<!TMDM>(hv, p.e3 + (long long)t * HID, h);
             // ---- heads: eps = W4 h + b4 ; sigma = softplus(Ws softplus(h) + bs) --------------
             float ea[F], sa[F];
 #pragma unroll
@@ -207,17 +223,20 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_kernel(const 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int base = hbase(j, q, h);
-                    float sp[4];
+                    float sp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (!TMDM) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) sp[e] = softplus_dev(hv[j * 16 + q * 4 + e]);
+                        for (int e = 0; e < 4; ++e) sp[e] = softplus_dev(hv[j * 16 + q * 4 + e]);
+                    }
 #pragma unroll
                     for (int f = 0; f < F; ++f) {
                         const f32x4 w4 = *reinterpret_cast<const f32x4*>(lds + L_W4 + f * HID + base);
-                        const f32x4 wsg = *reinterpret_cast<const f32x4*>(lds + L_WS + f * HID + base);
+                        f32x4 wsg = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (!TMDM) wsg = *reinterpret_cast<const f32x4*>(lds + L_WS + f * HID + base);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             ea[f] = __builtin_fmaf(w4[e], hv[j * 16 + q * 4 + e], ea[f]);
-                            sa[f] = __builtin_fmaf(wsg[e], sp[e], sa[f]);
+                            if (!TMDM) sa[f] = __builtin_fmaf(wsg[e], sp[e], sa[f]);
                         }
                     }
                 }
@@ -229,8 +248,12 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_kernel(const 
 #pragma unroll
             for (int f = 0; f < F; ++f) {
                 const float eps = ea[f] + __shfl_xor(ea[f], 32) + lds[L_HB + f];
-                const float sig = softplus_dev(sa[f] + __shfl_xor(sa[f], 32) + lds[L_HB + 4 + f]);
-                y[f] = posterior(c, y[f], mu[f], g[f], eps, sig, z[f], t == 0);
+                if (TMDM) {
+                    y[f] = posterior_tmdm(cr, y[f], mu[f], eps, z[f], t == 0);
+                } else {
+                    const float sig = softplus_dev(sa[f] + __shfl_xor(sa[f], 32) + lds[L_HB + 4 + f]);
+                    y[f] = posterior(c, y[f], mu[f], g[f], eps, sig, z[f], t == 0);
+                }
             }
         }
         if (valid && h_lane == 0) {
@@ -252,11 +275,11 @@ __global__ void philox_dump_kernel(float* out, long long n_chains, int T, unsign
     }
 }
 
-template <int F>
+template <int F, bool TMDM = false>
 int launch_f(mpv_ctx* ctx, const ChainArgs& a, bool philox, int grid) {
     const size_t lds_bytes = L_FLOATS * sizeof(float);
-    auto kp = nsdiff_chain_kernel<F, true>;
-    auto kn = nsdiff_chain_kernel<F, false>;
+    auto kp = nsdiff_chain_kernel<F, true, TMDM>;
+    auto kn = nsdiff_chain_kernel<F, false, TMDM>;
     MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(philox ? kp : kn),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     if (philox)
@@ -316,6 +339,36 @@ int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0
         ctx->events.emplace_back(e0, e1);
     }
     return MPV_OK;
+}
+
+// TMDM sampler: same launch geometry, the exact-fp32 kernel with TMDM = true
+int launch_tmdm_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* noise, float* samples) {
+    const NsdiffModel& m = ctx->tm;
+    ChainArgs a{};
+    a.w1t = m.w1t; a.w2 = m.w2; a.w3 = m.w3; a.b1 = m.b1; a.b2 = m.b2; a.b3 = m.b3;
+    a.e1 = m.e1; a.e2 = m.e2; a.e3 = m.e3; a.w4 = m.w4; a.b4 = m.b4; a.coef = m.coef;
+    a.ws = m.w4; a.bs = m.b4;                               // unused by the TMDM instantiation
+    a.y0hat = y0hat; a.gx = nullptr; a.noise = noise; a.samples = samples;
+    a.T = m.steps; a.B = s.nodes; a.O = s.pred_len; a.S = s.n_samples; a.P = s.chunk; a.C = s.n_samples / s.chunk;
+    a.n_chains = (long long)s.n_windows * s.nodes * s.pred_len * s.n_samples;
+    a.n_tiles = (a.n_chains + TILE - 1) / TILE;
+    a.noise_kstride = (long long)s.nodes * s.chunk * s.pred_len * m.nf;
+    a.seed_lo = (unsigned)s.seed;
+    a.seed_hi = (unsigned)(s.seed >> 32) + (unsigned)(s.offset >> 32);
+    a.off_lo = (unsigned)s.offset;
+    if (a.n_chains == 0) return MPV_OK;
+    const long long wg_needed = (a.n_tiles + WAVES - 1) / WAVES;
+    const int grid = (int)(wg_needed < ctx->cu_count ? wg_needed : ctx->cu_count);
+    if ((size_t)L_FLOATS * sizeof(float) > ctx->max_lds)
+        return mpv_fail(ctx, MPV_EINVAL, "device LDS too small for the resident-weight chain kernel");
+    const bool philox = (noise == nullptr);
+    switch (m.nf) {
+        case 1: return launch_f<1, true>(ctx, a, philox, grid);
+        case 2: return launch_f<2, true>(ctx, a, philox, grid);
+        case 3: return launch_f<3, true>(ctx, a, philox, grid);
+        case 4: return launch_f<4, true>(ctx, a, philox, grid);
+        default: return mpv_fail(ctx, MPV_EINVAL, "nf must be 1..4");
+    }
 }
 
 int launch_philox_dump(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out) {

@@ -10,7 +10,10 @@ def diffusion_models(task_model, net_param, **kwargs):
     if task_model == "NsDiff_model_variants":
         from .Diffusion_model.NsDiff.NsDiff_model import NsDiff_model_variants
         return NsDiff_model_variants(net_param=net_param, train_model_select=kwargs["train_model_select"])
-    if task_model in ("DiffSTG", "DiffusionTS", "TMDM", "NsDiff_spatial"):
+    if task_model == "TMDM":
+        from .Diffusion_model.TMDM.tmdm_adapter import TMDM_model
+        return TMDM_model(net_param=net_param)
+    if task_model in ("DiffSTG", "DiffusionTS", "NsDiff_spatial"):
         raise NotImplementedError(
             "task_model {!r} is a later row of the hot-path scope table (SURVEY.md section 8): the NsDiff "
             "pointwise sampler is built first; this model family has no HIP path yet".format(task_model))
