@@ -34,7 +34,9 @@ def stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not stale():
         return LIB
-    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+    # -fno-slp-vectorize: packed-f32 VALU (v_pk_fma_f32 ...) issues at half rate beside MFMAs on gfx950
+    # (tools/ubench/pipe_overlap4: 4 v_pk_fma per MFMA gap = 68 cycles vs 8 v_fma = 48)
+    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared",
            "-I", str(ROOT / "include"), "-I", str(PKG / "csrc"), "-o", str(LIB)]
     cmd += [str(PKG / "csrc" / s) for s in SOURCES]
     if verbose:
