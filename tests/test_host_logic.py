@@ -167,7 +167,7 @@ def test_factory_and_config_errors(ckpt_wofx):
     from mpv_amd.models.models import diffusion_models
     with pytest.raises(ValueError, match="don't exit"):
         diffusion_models("nope", {})
-    for later in ("DiffSTG", "DiffusionTS", "TMDM", "NsDiff_spatial"):
+    for later in ("DiffSTG", "DiffusionTS", "NsDiff_spatial"):
         with pytest.raises(NotImplementedError):
             diffusion_models(later, {})
     base = dict(WOFX_NET, device="cpu")

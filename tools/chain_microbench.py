@@ -35,3 +35,19 @@ if os.environ.get("ACC"):
     print("   f16x3 vs f32 (same Philox noise): max|d|/max|ref| %.3e   mean|d|/mean|ref| %.3e   nan %d/%d" % (
         float(d[~d.isnan()].max() / b[~b.isnan()].abs().max()), float(d[~d.isnan()].mean() / b[~b.isnan()].abs().mean()),
         int(a.isnan().sum()), int(b.isnan().sum())))
+if os.environ.get("TRACE"):
+    import ctypes as C
+    lib = _native.load_library()
+    buf = (C.c_uint64 * 16)()
+    lib.mpv_debug_trace(buf, 1)
+    ctx.sample(gx, None, 32, 32, seed=11, gemm="f16x3"); torch.cuda.synchronize()
+    lib.mpv_debug_trace(buf, 0)
+    steps = buf[14]
+    names = ["act1 t0-2 (+L1 mfma)", "L2 t0 ks0-5 || act1 t3", "norm + L2 t0 ks6-7,b", "L2 t1-3 || act2 t0-2", "L3 t0 ks0-5 || act2 t3",
+             "norm + L3 t0 ks6-7,b", "L3 t1-3 || act3 t0-2", "act3 t3 + norm", "heads + posterior", "loop head (noise, rows)"]
+    tot = sum(buf[i] for i in range(10))
+    print("   trace of block 0 wave 0: %d steps, %.0f memtime ticks/step; s_memtime runs at %.3f GHz (vs 100 MHz s_memrealtime)" % (
+        steps, tot / steps, buf[12] / max(buf[13], 1) * 0.1))
+    print("   wave lifetimes (100 MHz ticks): min %d max %d; block0/wave0 tiles total %d realtime ticks, %d shader ticks" % (buf[10], buf[15], buf[13], buf[12]))
+    for i, nm in enumerate(names):
+        print("     %-28s %8.1f ticks/step  %5.1f %%" % (nm, buf[i] / steps, 100.0 * buf[i] / tot))

@@ -42,7 +42,7 @@ struct ChainArgs {
     const unsigned short* w1img;   // layer 1 as MFMA k-slots: [128][16*NK] f16 (nsdiff_chain_f16.hip::L1)
     const unsigned *b2p, *b3p;     // layer 2/3 biases, (hi | lo << 16) f16 pairs of b * 2^sB
     const float *g1, *g2, *g3, *wsl;
-    float bone2, bone3;            // B-operand value of the bias MFMA: 2^(s_layer + 12 - sB)
+    float bone2, bone3;            // bias k-slot constant of layers 2, 3: 2^(sW - sB)  (x the B-operand scale)
     float l1_scale;                // 2^(s1 + 4): scale of the layer-1 accumulators
     unsigned hi_mask;              // 0xFFFFE000: keeps the 11 leading significand bits of an fp32
     const float* y0hat;

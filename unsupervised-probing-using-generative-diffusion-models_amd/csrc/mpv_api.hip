@@ -177,17 +177,19 @@ int mpv_nsdiff_load(mpv_ctx* ctx, const mpv_nsdiff_desc* d, const mpv_nsdiff_wei
     // ---- split-f16 variant (nsdiff_chain_f16.hip): scaled/split weights, biases as MFMA k-slots, folded
     // per-step scale rows, layer-1 pre-activation bound coefficients
     const float LOG2E = 1.44269504088896341f, LN2 = 0.693147180559945309f;
-    const int ACT = 12, INS = 4;                          // activations scaled 2^12, layer-1 inputs 2^4
+    const int INS = 4;                                    // layer-1 inputs scaled 2^4
     auto f16bits = [](float x) { const _Float16 h = (_Float16)x; unsigned short u; std::memcpy(&u, &h, 2); return u; };
     auto f16val = [](float x) { return (float)(_Float16)x; };
-    // layers 2/3: one power-of-two scale per matrix, chosen over {W, b/8} so the bias fits beside it
+    // layers 2/3: one power-of-two scale per matrix, chosen over {W, b/4} so the bias fits beside it.  The kernel
+    // feeds B = c l with a per-chain scalar c (1 on the hot path, 2^12/||l|| on the exact path) and a bias k-slot
+    // worth c ||l|| 2^(sW-sB) b 2^sB, so acc = 2^sW c ||l|| (W h + b) and x' = (gamma log2e 2^-sW) acc / (c ||l||)
     int sW[3] = {0, 0, 0}, sB[3] = {0, 0, 0};
     for (int L = 1; L <= 2; ++L) {
         std::vector<float> joint(w->lin_w[L], w->lin_w[L] + (size_t)H * H);
-        for (int i = 0; i < H; ++i) joint.push_back(w->lin_b[L][i] * 0.125f);
+        for (int i = 0; i < H; ++i) joint.push_back(w->lin_b[L][i] * 0.25f);
         sW[L] = scale_log2(joint.data(), joint.size());
         int s = scale_log2(w->lin_b[L], (size_t)H);
-        sB[L] = std::max(sW[L] - 3, std::min(s, sW[L] + ACT + 14));
+        sB[L] = std::max(sW[L] - 2, std::min(s, sW[L] + 10));
     }
     std::vector<unsigned short> w2h, w2l, w3h, w3l;
     split_weights(w->lin_w[1], sW[1], &w2h, &w2l);
@@ -201,8 +203,8 @@ int mpv_nsdiff_load(mpv_ctx* ctx, const mpv_nsdiff_desc* d, const mpv_nsdiff_wei
             bp[L][i] = (unsigned)f16bits(hi) | ((unsigned)f16bits(x - hi) << 16);
         }
     }
-    m.bone2 = std::ldexp(1.0f, sW[1] + ACT - sB[1]);
-    m.bone3 = std::ldexp(1.0f, sW[2] + ACT - sB[2]);
+    m.bone2 = std::ldexp(1.0f, sW[1] - sB[1]);
+    m.bone3 = std::ldexp(1.0f, sW[2] - sB[2]);
     // layer 1: one scale over {W1, b1}; k-slots: 3F x W_hi (x_hi), 3F x W_hi (x_lo), 3F x W_lo (x_hi), b_hi, b_lo
     std::vector<float> joint1(w->lin_w[0], w->lin_w[0] + (size_t)H * 3 * F);
     joint1.insert(joint1.end(), w->lin_b[0], w->lin_b[0] + H);
@@ -226,8 +228,8 @@ int mpv_nsdiff_load(mpv_ctx* ctx, const mpv_nsdiff_desc* d, const mpv_nsdiff_wei
     std::vector<float> g1((size_t)T * H), g2((size_t)T * H), g3((size_t)T * H), wsl((size_t)F * H);
     for (size_t i = 0; i < (size_t)T * H; ++i) {
         g1[i] = std::ldexp(w->embed[0][i] * LOG2E, -(s1 + INS));
-        g2[i] = std::ldexp(w->embed[1][i] * LOG2E, -(sW[1] + ACT));
-        g3[i] = std::ldexp(w->embed[2][i] * LOG2E, -(sW[2] + ACT));
+        g2[i] = std::ldexp(w->embed[1][i] * LOG2E, -sW[1]);
+        g3[i] = std::ldexp(w->embed[2][i] * LOG2E, -sW[2]);
     }
     for (size_t i = 0; i < (size_t)F * H; ++i) wsl[i] = w->sig_w[i] * LN2;
     // |x_j| = |gamma_tj (W_j . h + b_j)| <= |gamma_tj| (||W_j||_2 + |b_j|) because the layer input has unit 2-norm

@@ -74,27 +74,99 @@ template <int F> struct Lds {                   // byte offsets
 #define LDS_F4(smem, off) (*reinterpret_cast<const f32x4*>((smem) + (off)))
 #define LDS_H8(smem, off) (*reinterpret_cast<const f16x8*>((smem) + (off)))
 
-// ---- softplus(x)/ln2 from x' = x*log2(e), in place on one accumulator tile (16 registers); sum(l^2) -> ss[0..3]
-// Each stage is a PASS over the 16 independent registers (the dependent chain mul -> exp -> add -> log -> fma of
-// one element is spread over five passes, so neighbouring instructions are independent).
-template <bool SAFE>
-__device__ __forceinline__ void softplus_tile(f32x16& a, const unsigned char* smem, unsigned grow, int j, float (&ss)[4]) {
+// ---- building blocks -----------------------------------------------------------------------------------
+// Scheduling: the f16 matrix pipe and the VALU of one SIMD run side by side only when the SAME wave issues them
+// interleaved (an MFMA holds the vector issue port for 8 of its 32 cycles; about 6 plain VALU instructions or 2
+// transcendentals fit in the rest; a second wave does not fill those slots: tools/ubench/pipe_overlap4).  A layer
+// is therefore software-pipelined by OUTPUT TILE: while the 25 MFMAs of tile j+1 run, the VALU activates tile j
+// (scale, softplus, sum of squares, f16 split).  That needs the activation of a tile to be independent of the
+// other tiles, so F.normalize is deferred: the next layer multiplies the UN-normalised l = softplus/ln2,
+//     acc' = 2^sW (W l + ||l|| b)   (the bias enters as an MFMA k-slot scaled by ||l||),   x' = g'' acc' / ||l||,
+// which is the same pre-activation W (l/||l||) + b.  MPV_SGB selects how the two streams are woven.
+#define SEG_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// -DMPV_TRACE: per-phase cycle totals of one wave (block 0, wave 0) in mpv_trace[], read back with mpv_debug_trace()
+#ifdef MPV_TRACE
+__device__ unsigned long long mpv_trace[16];
+#define TR_PARAMS , unsigned long long (&tr)[14], unsigned long long& tr_last
+#define TR_ARGS , tr, tr_last
+#define TR(i) do { SEG_FENCE(); const unsigned long long tr_now = __builtin_amdgcn_s_memtime(); tr[i] += tr_now - tr_last; tr_last = tr_now; SEG_FENCE(); } while (0)
+#else
+#define TR_PARAMS
+#define TR_ARGS
+#define TR(i)
+#endif
+
+template <int K> struct IC { static constexpr int value = K; };
+template <int K0, int K1, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+    if constexpr (K0 < K1) {
+        f(IC<K0>{});
+        static_for<K0 + 1, K1>(f);
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma16(const f16x8& a, const f16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// one k-step of output tile j: acc += W_lo h_hi + W_hi h_lo + W_hi h_hi   (FIRST: acc starts from zero)
+template <bool FIRST>
+__device__ __forceinline__ void mfma_ks(f32x16& acc, const unsigned char* smem, unsigned wbase, int img_hi, int img_lo, int j,
+                                        int ks, const f16x8& bh, const f16x8& bl) {
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int off = j * 32 * (HROW * 2) + ks * 32;
+    const f16x8 ah = LDS_H8(smem, wbase + img_hi + off);
+    const f16x8 al = LDS_H8(smem, wbase + img_lo + off);
+    acc = mfma16(al, bh, FIRST ? zero : acc);
+    acc = mfma16(ah, bl, acc);
+    acc = mfma16(ah, bh, acc);
+}
+
+// bias k-slots: A = (b_hi, b_lo, b_hi, 0...) of the lane's row (upper half-wave zero), B = (c_hi, c_hi, c_lo, 0...)
+__device__ __forceinline__ void mfma_bias(f32x16& acc, unsigned ab, const f16x8& bone) {
+    const u32x4 a = {ab, ab & 0xFFFFu, 0u, 0u};
+    acc = mfma16(__builtin_bit_cast(f16x8, a), bone, acc);
+}
+
+__device__ __forceinline__ f16x8 bias_operand(float c) {            // c = c_hi + c_lo in f16
+    const _Float16 h = (_Float16)c;
+    const _Float16 l = (_Float16)(c - (float)h);
+    const f16x8 b = {h, h, l, 0, 0, 0, 0, 0};
+    return b;
+}
+
+// all k-steps ks0..ks1-1 of tile j
+template <int KS0, int KS1>
+__device__ __forceinline__ void mfma_tile(f32x16& acc, const unsigned char* smem, unsigned wbase, int img_hi, int img_lo, int j,
+                                          const f16x8 (&bh)[8], const f16x8 (&bl)[8]) {
+#pragma unroll
+    for (int ks = KS0; ks < KS1; ++ks) {
+        if (ks == 0) mfma_ks<true>(acc, smem, wbase, img_hi, img_lo, j, ks, bh[ks], bl[ks]);
+        else mfma_ks<false>(acc, smem, wbase, img_hi, img_lo, j, ks, bh[ks], bl[ks]);
+    }
+}
+
+// ---- l = softplus(x)/ln2 from the accumulators of one output tile, in place; sum(l^2) -> ss[0..3] ------------
+// x' = acc * g''[row] (* m2 per chain when SCALE).  Each stage is a PASS over the 16 independent registers.
+template <bool SAFE, bool SCALE>
+__device__ __forceinline__ void softplus16(f32x16& a, const unsigned char* smem, unsigned grow, int j, float m2, float (&ss)[4]) {
     f32x4 gm[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) gm[q] = LDS_F4(smem, grow + (32 * j + 8 * q) * 4);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] *= gm[i >> 2][i & 3];                       // x'
-    MPV_FENCE();
+    for (int i = 0; i < 16; ++i) a[i] *= gm[i >> 2][i & 3];
+    if (SCALE) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] *= m2;
+    }
     if (!SAFE) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) a[i] = __builtin_amdgcn_exp2f(a[i]);
-        MPV_FENCE();
 #pragma unroll
         for (int i = 0; i < 16; ++i) a[i] += 1.0f;
-        MPV_FENCE();
 #pragma unroll
         for (int i = 0; i < 16; ++i) a[i] = __builtin_amdgcn_logf(a[i]);
-        MPV_FENCE();
     } else {
         f32x16 e, c, lo;
 #pragma unroll
@@ -107,101 +179,214 @@ __device__ __forceinline__ void softplus_tile(f32x16& a, const unsigned char* sm
         for (int i = 0; i < 16; ++i) c[i] = __builtin_amdgcn_fmed3f(c[i], lo[i], e[i] * LOG2E);  // <= e/ln2
 #pragma unroll
         for (int i = 0; i < 16; ++i) a[i] = __builtin_amdgcn_fmed3f(c[i], a[i], 3.0e38f);        // max(., x')
-        MPV_FENCE();
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) ss[i & 3] = __builtin_fmaf(a[i], a[i], ss[i & 3]);
-    MPV_FENCE();
 }
 
-template <bool SAFE>
-__device__ __forceinline__ float activate_log2(f32x16 (&acc)[4], const unsigned char* smem, unsigned grow) {
-    float ss[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+// t = a (* scale when SCALED) -> f16 pair: hi = t with the low 13 significand bits cleared (exact in f16),
+// lo = RTZ_f16(t - hi).  Registers 0..7 of the tile are the B operand of k-step 2j, 8..15 of k-step 2j+1.
+template <bool SCALED>
+__device__ __forceinline__ void split16(const f32x16& a, float scale, unsigned mask, f16x8& bh0, f16x8& bh1, f16x8& bl0, f16x8& bl1) {
+    f32x16 t, hi;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) softplus_tile<SAFE>(acc[j], smem, grow, j, ss);
-    float t = (ss[0] + ss[1]) + (ss[2] + ss[3]);
-    t += __shfl_xor(t, 32);
-    return 1.0f / fmaxf(sqrtf(t), 1e-12f / LN2);           // 1 / max(||l||, F.normalize eps / ln2)
+    for (int i = 0; i < 16; ++i) t[i] = SCALED ? a[i] * scale : a[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float v = t[i];                               // (a vector-element lvalue must not go through bit_cast)
+        hi[i] = __uint_as_float(__float_as_uint(v) & mask);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] -= hi[i];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const auto ph = __builtin_amdgcn_cvt_pkrtz(hi[2 * p], hi[2 * p + 1]);
+        const auto pl = __builtin_amdgcn_cvt_pkrtz(t[2 * p], t[2 * p + 1]);
+        f16x8& dh = (p < 4) ? bh0 : bh1;
+        f16x8& dl = (p < 4) ? bl0 : bl1;
+        const int q = p & 3;
+        dh[2 * q] = (_Float16)ph[0]; dh[2 * q + 1] = (_Float16)ph[1];
+        dl[2 * q] = (_Float16)pl[0]; dl[2 * q + 1] = (_Float16)pl[1];
+    }
 }
 
-// t = a*scale in [0, 2^12] -> f16 pair (hi, lo) with hi + lo = t to >= 22 significand bits.
-//  default      : hi = t with the low 13 significand bits cleared, lo = RTZ_f16(t - hi)
-//                 (v_mul, v_and with an SGPR mask, v_sub, v_cvt_pkrtz: 4-byte encodings)
-//  MPV_SPLIT_MIX: hi = RNE_f16(t), lo = RNE_f16(fma(a, scale, -hi)) -- two v_fma_mix{lo,hi}_f16 per element;
-//                 1.5 fewer instructions per element but measured 1 % slower (VOP3P issue cost)
-__device__ __forceinline__ void split_f16(f32x16 (&acc)[4], float scale, unsigned mask, f16x8 (&bh)[8], f16x8 (&bl)[8]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f32x16& a = acc[j];
-#ifndef MPV_SPLIT_MIX
-        f32x16 hi;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) a[i] *= scale;
-        MPV_FENCE();
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float v = a[i];                       // (a vector-element lvalue must not go through bit_cast)
-            hi[i] = __uint_as_float(__float_as_uint(v) & mask);
+// ---- one activation tile as a numbered list of single VALU instructions -------------------------------------------
+// Stages of element e (16 per tile): 0 a*=g''  1 a*=m2 (SCALE)  2 exp2  3 +1  4 log2  5 ss+=a^2
+//   SPLIT: 6 hi=a&mask  7 a-=hi  8 cvt(hi pair) (odd e)  9 cvt(lo pair) (odd e)      EPS: 6..6+F-1 ea[f]+=w4*a
+// The list is ordered by diagonals over (stage, quad of 4 elements), the cells of a diagonal interleaved element by
+// element: consecutive instructions are independent, one element's chain advances once per diagonal (>= 4
+// instructions apart), exps and logs are spread out.  It is cut into chunks of equal issue cost (plain 4 cycles,
+// transcendental 8); chunk g is issued right behind MFMA g of the tile being multiplied, starting at MFMA `SKIP`
+// (the first operands are the results of the MFMAs issued just before the segment, ~64 cycles away).
+template <bool SCALE, bool SPLIT, int NEPS, int NM>
+struct ActPlan {
+    static constexpr int NST = 6 + (SPLIT ? 4 : 0) + NEPS;
+    static constexpr int MAXOPS = 16 * NST;
+    static constexpr int SKIP = NM > 8 ? 2 : 0;
+    int n;
+    int st[MAXOPS], el[MAXOPS];
+    int start[NM + 1];
+    constexpr ActPlan() : n(0), st{}, el{}, start{} {
+        int cost[MAXOPS] = {};
+        int total = 0;
+        for (int d = 0; d < NST + 3; ++d)
+            for (int i = 0; i < 4; ++i)
+                for (int sg = 0; sg < NST; ++sg) {
+                    const int q = d - sg;
+                    if (q < 0 || q > 3) continue;
+                    const int e = 4 * q + i;
+                    if (sg == 1 && !SCALE) continue;
+                    if (SPLIT && (sg == 8 || sg == 9) && !(e & 1)) continue;
+                    st[n] = sg; el[n] = e;
+                    cost[n] = (sg == 2 || sg == 4) ? 8 : 4;
+                    total += cost[n];
+                    ++n;
+                }
+        int k = 0, acc = 0;
+        for (int g = 0; g < NM; ++g) {
+            start[g] = k;
+            if (g < SKIP) continue;
+            const int target = (total * (g + 1 - SKIP) + (NM - SKIP) - 1) / (NM - SKIP);
+            while (k < n && acc + cost[k] <= target) acc += cost[k++];
         }
-        MPV_FENCE();
-#pragma unroll
-        for (int i = 0; i < 16; ++i) a[i] -= hi[i];
-        MPV_FENCE();
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const auto ph = __builtin_amdgcn_cvt_pkrtz(hi[2 * p], hi[2 * p + 1]);
-            const auto pl = __builtin_amdgcn_cvt_pkrtz(a[2 * p], a[2 * p + 1]);
-            const int ks = 2 * j + (p >> 2), q = p & 3;
-            bh[ks][2 * q] = (_Float16)ph[0]; bh[ks][2 * q + 1] = (_Float16)ph[1];
-            bl[ks][2 * q] = (_Float16)pl[0]; bl[ks][2 * q + 1] = (_Float16)pl[1];
-        }
+        start[NM] = n;
+    }
+};
+
+template <bool SCALE, bool SPLIT, int NEPS, int NM>
+struct ActPlanOf {
+    static constexpr ActPlan<SCALE, SPLIT, NEPS, NM> P{};
+};
+
+template <int F>
+struct ActState {
+    f32x16& a;                // accumulators in, l (or l - hi when SPLIT) out
+    f32x16 hi;
+    f32x4 gm[4];
+    f32x4 w4[F > 0 ? F : 1][4];
+    float (&ss)[4];
+    float (*ea)[4];
+    float m2;
+    unsigned mask;
+    u32x4 ph[2], pl[2];
+};
+
+template <int ST, int E, int F>
+__device__ __forceinline__ void act_op(ActState<F>& s) {
+    if constexpr (ST == 0) s.a[E] *= s.gm[E >> 2][E & 3];
+    else if constexpr (ST == 1) s.a[E] *= s.m2;
+#ifdef MPV_ABL_NO_TRANS            // ablation: plain multiplies instead of exp2/log2 (results are wrong)
+    else if constexpr (ST == 2) s.a[E] *= 1.0001f;
+    else if constexpr (ST == 4) s.a[E] *= 0.9999f;
 #else
-        (void)mask;
-        u32x4 ph[2], pl[2];
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {                       // hi = RNE_f16(a * scale), packed (even, odd)
-            unsigned d;
-            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(d) : "v"(a[2 * p]), "v"(scale));
-            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(d) : "v"(a[2 * p + 1]), "v"(scale));
-            ph[p >> 2][p & 3] = d;
-        }
-        MPV_FENCE();
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {                       // lo = RNE_f16(fma(a, scale, -hi)), hi read as f16
-            unsigned d;
-            const unsigned h = ph[p >> 2][p & 3];
-            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a[2 * p]), "v"(scale), "v"(h));
-            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                : "+v"(d) : "v"(a[2 * p + 1]), "v"(scale), "v"(h));
-            pl[p >> 2][p & 3] = d;
-        }
-        bh[2 * j] = __builtin_bit_cast(f16x8, ph[0]); bh[2 * j + 1] = __builtin_bit_cast(f16x8, ph[1]);
-        bl[2 * j] = __builtin_bit_cast(f16x8, pl[0]); bl[2 * j + 1] = __builtin_bit_cast(f16x8, pl[1]);
+    else if constexpr (ST == 2) s.a[E] = __builtin_amdgcn_exp2f(s.a[E]);
+    else if constexpr (ST == 4) s.a[E] = __builtin_amdgcn_logf(s.a[E]);
 #endif
-        MPV_FENCE();
+    else if constexpr (ST == 3) s.a[E] += 1.0f;
+    else if constexpr (ST == 5) s.ss[E & 3] = __builtin_fmaf(s.a[E], s.a[E], s.ss[E & 3]);
+}
+template <int ST, int E, int F>
+__device__ __forceinline__ void split_op(ActState<F>& s) {
+    if constexpr (ST == 6) {
+        const float v = s.a[E];
+        s.hi[E] = __uint_as_float(__float_as_uint(v) & s.mask);
+    } else if constexpr (ST == 7) {
+        s.a[E] -= s.hi[E];
+    } else if constexpr (ST == 8) {
+        const auto c = __builtin_amdgcn_cvt_pkrtz(s.hi[E - 1], s.hi[E]);
+        s.ph[E >> 3][(E >> 1) & 3] = __builtin_bit_cast(unsigned, c);
+    } else if constexpr (ST == 9) {
+        const auto c = __builtin_amdgcn_cvt_pkrtz(s.a[E - 1], s.a[E]);
+        s.pl[E >> 3][(E >> 1) & 3] = __builtin_bit_cast(unsigned, c);
     }
 }
 
-// acc = bias + (W_hi + W_lo)(h_hi + h_lo) (without lo*lo) on the f16 matrix pipe.  The bias enters as one more
-// MFMA per tile: A = (b_hi, b_lo, 0...) of the lane's row (registers, zero in the upper half-wave), B = (c, c, 0...)
-__device__ __forceinline__ void mfma_layer_f16(const unsigned char* smem, unsigned wbase, int img_hi, int img_lo, const unsigned (&abias)[4],
-                                               const f16x8& bone, const f16x8 (&bh)[8], const f16x8 (&bl)[8],
-                                               f32x16 (&acc)[4]) {
+// One woven segment: MFMAs m = 0..NM-1 of output tile `jt` (k-steps KS0.., three per k-step, then the bias k-slots
+// when BIAS) with chunk m of the activation of another tile behind each.  A operands are read two k-steps ahead.
+template <int F, int KS0, int NKS, bool BIAS, bool SCALE, bool SPLIT, bool EPS>
+__device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, unsigned wbase, int img_hi, int img_lo, int jt,
+                                      const f16x8 (&bh)[8], const f16x8 (&bl)[8], unsigned ab, const f16x8& bone,
+                                      f32x16& a, unsigned grow, int ja, float m2, unsigned mask, float (&ss)[4],
+                                      unsigned f_base, float (*ea)[4],
+                                      f16x8* oh0, f16x8* oh1, f16x8* ol0, f16x8* ol1) {
+    using LD = Lds<F>;
+    constexpr int NM = 3 * NKS + (BIAS ? 1 : 0);
+    constexpr int NEPS = EPS ? F : 0;
+    using PL = ActPlanOf<SCALE, SPLIT, NEPS, NM>;
+    ActState<F> s{a, {}, {}, {}, ss, ea, m2, mask, {}, {}};
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f16x8 ah[3], al[3];                                       // ring: k-step ks lives in slot ks % 3
+    auto load_a = [&](auto ic) {
+        constexpr int ks = decltype(ic)::value;
+        const int off = jt * 32 * (HROW * 2) + ks * 32;
+        ah[ks % 3] = LDS_H8(smem, wbase + img_hi + off);
+        al[ks % 3] = LDS_H8(smem, wbase + img_lo + off);
+    };
+    // prologue: scale rows (and eps-head rows) of the activated tile, A operands of the first two k-steps
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const u32x4 ab = {abias[j], 0u, 0u, 0u};
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ab), bone, zero, 0, 0, 0);
+    for (int q = 0; q < 4; ++q) s.gm[q] = LDS_F4(smem, grow + (32 * ja + 8 * q) * 4);
+    if constexpr (EPS) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int off = j * 32 * (HROW * 2) + ks * 32;
-            const f16x8 ah = LDS_H8(smem, wbase + img_hi + off);
-            const f16x8 al = LDS_H8(smem, wbase + img_lo + off);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc[j], 0, 0, 0);
-        }
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s.w4[f][q] = LDS_F4(smem, f_base + (LD::W4 - LD::F32) + (f * HID + 32 * ja + 8 * q) * 4);
     }
+    load_a(IC<KS0>{});
+    if constexpr (NKS > 1) load_a(IC<KS0 + 1>{});
+    SEG_FENCE();
+    static_for<0, NM>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g < 3 * NKS) {
+            constexpr int ks = KS0 + g / 3, ty = g % 3;
+#ifndef MPV_ABL_NO_LDSA
+            if constexpr (ty == 0 && g / 3 + 2 < NKS) load_a(IC<ks + 2>{});
+#endif
+#if defined(MPV_ABL_NO_LDSA)      // ablation: every k-step multiplies the A operands of the first one (results are wrong)
+            if constexpr (ty == 0) acc = mfma16(al[KS0 % 3], bh[ks], (ks == 0) ? zero : acc);
+            else if constexpr (ty == 1) acc = mfma16(ah[KS0 % 3], bl[ks], acc);
+            else acc = mfma16(ah[KS0 % 3], bh[ks], acc);
+#elif defined(MPV_ABL_ONE_MFMA)     // ablation: one product per k-step (results are wrong)
+            if constexpr (ty == 2) acc = mfma16(ah[ks % 3], bh[ks], (ks == 0) ? zero : acc);
+#elif defined(MPV_ABL_NO_MFMA)
+            if constexpr (ty == 2 && ks == 0) acc = zero;
+#else
+            if constexpr (ty == 0) acc = mfma16(al[ks % 3], bh[ks], (ks == 0) ? zero : acc);
+            else if constexpr (ty == 1) acc = mfma16(ah[ks % 3], bl[ks], acc);
+            else acc = mfma16(ah[ks % 3], bh[ks], acc);
+#endif
+        } else {
+            mfma_bias(acc, ab, bone);
+        }
+        static_for<PL::P.start[g], PL::P.start[g + 1]>([&](auto kc) {
+            constexpr int kk = decltype(kc)::value;
+            constexpr int ST = PL::P.st[kk], E = PL::P.el[kk];
+            if constexpr (ST < 6) act_op<ST, E, F>(s);
+            else if constexpr (SPLIT) split_op<ST, E, F>(s);
+            else {
+                constexpr int f = ST - 6;
+                s.ea[f][E & 3] = __builtin_fmaf(s.w4[f][E >> 2][E & 3], s.a[E], s.ea[f][E & 3]);
+            }
+        });
+        SEG_FENCE();
+    });
+    if constexpr (SPLIT) {
+        *oh0 = __builtin_bit_cast(f16x8, s.ph[0]); *oh1 = __builtin_bit_cast(f16x8, s.ph[1]);
+        *ol0 = __builtin_bit_cast(f16x8, s.pl[0]); *ol1 = __builtin_bit_cast(f16x8, s.pl[1]);
+    }
+}
+
+// sum over the two half-waves of a chain (lanes n and n+32)
+__device__ __forceinline__ float chain_sum(const float (&ss)[4]) {
+    const float t = (ss[0] + ss[1]) + (ss[2] + ss[3]);
+    return t + __shfl_xor(t, 32);
+}
+
+// fast path: 1/sqrt(t) by v_rsq_f32 plus one Newton step (<= 1 ulp), ||l|| = t * that
+__device__ __forceinline__ void norm_fast(float t, float& nrm, float& inv) {
+    const float y0 = __builtin_amdgcn_rsqf(t);
+    const float y = y0 * __builtin_fmaf(-0.5f * t, y0 * y0, 1.5f);
+    inv = y;
+    nrm = t * y;
 }
 
 // ---- layer 1 ---------------------------------------------------------------------------------------------
@@ -298,92 +483,44 @@ struct StepCtx {                 // everything a step needs besides the chain st
     float l1_scale;
     unsigned a_base, a_base3, w1_base, f_base, g_base;   // a_base3 = a_base + W3H: keeps every immediate < 64 KB
     unsigned ab2[4], ab3[4];
-    float bone2, bone3;
+    float kb2, kb3;              // 2^(sW - sB) of layers 2, 3: bias B operand = (B-operand scale) * kb
     unsigned hi_mask;
     int h;
 };
 
-// One reverse step for 32 chains.  SAFE = false is the hot path: layer 1 on the matrix pipe and log2(1 + 2^x') for
-// every softplus; it also returns `ok` = every guard passed (inputs inside the f16 range of the layer-1 split, every
-// activation vector finite with norm > 1, i.e. no exp2 overflow and no all-tiny vector whose direction the plain
-// log2(1+e) would lose).  SAFE = true is the exact evaluation (fp32 VALU layer 1, guarded softplus); the kernel
-// re-runs a step through it (a cold, out-of-line call) in the rare case `ok` is false.
-template <int F, bool SAFE>
-__device__ __forceinline__ Vec<F> chain_step(const StepCtx& k, int t, const Vec<F>& y, const Vec<F>& mu,
-                                             const Vec<F>& g, const Vec<F>& z, bool& ok) {
+// ---- sigma / eps heads on h3 = l3 * inv3 in [0,1] and the posterior update (shared by both paths) ---------------
+// eps = W4 h3 + b4 (ea holds W4 l3, un-normalised); sigma = softplus((Ws ln2) softplus(h3)/ln2 + bs)
+template <int F>
+__device__ __forceinline__ Vec<F> heads_posterior(const StepCtx& k, int t, f32x16 (&l3)[4], float (&ea)[F][4], float inv,
+                                                  const Vec<F>& y, const Vec<F>& mu, const Vec<F>& g, const Vec<F>& z) {
     using LD = Lds<F>;
     const float* cr = k.coef + t * MPV_COEF_COLS;
-    f32x16 acc[4];
-    f16x8 bh[8], bl[8];
-    float in[3 * F], insum = 0.0f;
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-        in[f] = y.v[f]; in[F + f] = mu.v[f]; in[2 * F + f] = g.v[f];
-    }
-    float inv, nrm_lo, nrm_hi;
-    if (SAFE) {
-        layer1_valu<F>(k.w1t, k.b1, in, k.h, k.l1_scale, acc);
-    } else {
-#pragma unroll
-        for (int c = 0; c < 3 * F; ++c) insum += fabsf(in[c]);
-        ok = insum < IN_LIMIT;                               // false for NaN/inf as well
-        layer1_mfma<F>(k.smem, k.w1_base, in, k.h, acc);
-    }
-    inv = activate_log2<SAFE>(acc, k.smem, k.g_base);
-    nrm_lo = inv;
-    nrm_hi = inv;
-    split_f16(acc, inv * 4096.0f, k.hi_mask, bh, bl);          // activations in [0,1] scaled by 2^12
-    f16x8 bone = {0, 0, 0, 0, 0, 0, 0, 0};
-    bone[0] = bone[1] = (_Float16)k.bone2;
-    mfma_layer_f16(k.smem, k.a_base, LD::W2H, LD::W2L, k.ab2, bone, bh, bl, acc);
-    inv = activate_log2<SAFE>(acc, k.smem, k.g_base + HID * 4);
-    nrm_lo = fminf(nrm_lo, inv);
-    nrm_hi = fmaxf(nrm_hi, inv);
-    split_f16(acc, inv * 4096.0f, k.hi_mask, bh, bl);
-    bone[0] = bone[1] = (_Float16)k.bone3;
-    mfma_layer_f16(k.smem, k.a_base3, 0, LD::W3L - LD::W3H, k.ab3, bone, bh, bl, acc);
-    inv = activate_log2<SAFE>(acc, k.smem, k.g_base + 2 * HID * 4);
-    nrm_lo = fminf(nrm_lo, inv);
-    nrm_hi = fmaxf(nrm_hi, inv);
-    // inv = 1/||l||: guards  ||l|| > 1  and finite  <=>  0 < inv < 1   (NaN fails both)
-    if (!SAFE) ok = ok && (nrm_lo > 0.0f) && (nrm_hi < 1.0f);
-    // ---- heads on h3 = acc*inv in [0,1]: eps = W4 h3 + b4 ; sigma = softplus((Ws ln2) softplus(h3)/ln2 + bs)
-    float ea[F][4], sa[F][4];
+    float sa[F][4];
 #pragma unroll
     for (int f = 0; f < F; ++f)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ea[f][i] = sa[f][i] = 0.0f;
+        for (int i = 0; i < 4; ++i) sa[f][i] = 0.0f;
     const float inv_l2e = inv * LOG2E;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        f32x16& a = acc[j];
         f32x16 sp;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sp[i] = a[i] * inv_l2e;
-        MPV_FENCE();
+        for (int i = 0; i < 16; ++i) sp[i] = l3[j][i] * inv_l2e;
 #pragma unroll
         for (int i = 0; i < 16; ++i) sp[i] = __builtin_amdgcn_exp2f(sp[i]);       // 1 + e^h in [2, 3.72]: no
-        MPV_FENCE();                                                                //   small-argument or
-#pragma unroll                                                                      //   overflow cases
-        for (int i = 0; i < 16; ++i) sp[i] += 1.0f;
-        MPV_FENCE();
+#pragma unroll                                                                      //   small-argument or
+        for (int i = 0; i < 16; ++i) sp[i] += 1.0f;                                 //   overflow cases
 #pragma unroll
         for (int i = 0; i < 16; ++i) sp[i] = __builtin_amdgcn_logf(sp[i]);
-        MPV_FENCE();
 #pragma unroll
         for (int f = 0; f < F; ++f) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 w4 = LDS_F4(k.smem, k.f_base + (LD::W4 - LD::F32) + (f * HID + 32 * j + 8 * q) * 4);
                 const f32x4 wsg = LDS_F4(k.smem, k.f_base + (LD::WSL - LD::F32) + (f * HID + 32 * j + 8 * q) * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ea[f][e] = __builtin_fmaf(w4[e], a[q * 4 + e], ea[f][e]);       // un-normalised: * inv below
-                    sa[f][e] = __builtin_fmaf(wsg[e], sp[q * 4 + e], sa[f][e]);
-                }
+                for (int e = 0; e < 4; ++e) sa[f][e] = __builtin_fmaf(wsg[e], sp[q * 4 + e], sa[f][e]);
             }
         }
-        MPV_FENCE();
     }
     const StepCoef c = {cr[0], cr[1], cr[2],  cr[3],  cr[4],  cr[5],  cr[6],  cr[7],  cr[8],
                         cr[9], cr[10], cr[11], cr[12], cr[13], cr[14], cr[15], cr[16], cr[17]};
@@ -400,10 +537,157 @@ __device__ __forceinline__ Vec<F> chain_step(const StepCtx& k, int t, const Vec<
     return out;
 }
 
+// partial eps head of one l3 tile: ea[f][e] += W4[f][row] * l3[row]
+template <int F>
+__device__ __forceinline__ void eps_partial(const StepCtx& k, const f32x16& a, int j, float (&ea)[F][4]) {
+    using LD = Lds<F>;
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w4 = LDS_F4(k.smem, k.f_base + (LD::W4 - LD::F32) + (f * HID + 32 * j + 8 * q) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ea[f][e] = __builtin_fmaf(w4[e], a[q * 4 + e], ea[f][e]);
+        }
+}
+
+// ---- hot path: one reverse step for 32 chains, layers software-pipelined by output tile -------------------------
+// Returns `ok` = every guard passed: layer-1 inputs inside the f16 range of the input split, and for every layer
+// 1 < ||l|| < 2^13 (finite, no exp2 overflow, no all-tiny vector whose direction log2(1+e) would lose, every l and
+// the bias operand inside the f16 range).  Otherwise the kernel re-runs the step through chain_step_safe.
+template <int F>
+__device__ __forceinline__ Vec<F> chain_step_fast(const StepCtx& k, int t, const Vec<F>& y, const Vec<F>& mu,
+                                                  const Vec<F>& g, const Vec<F>& z, bool& ok TR_PARAMS) {
+    using LD = Lds<F>;
+    constexpr int W3REL = LD::W3L - LD::W3H;
+    float in[3 * F], insum = 0.0f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        in[f] = y.v[f]; in[F + f] = mu.v[f]; in[2 * F + f] = g.v[f];
+    }
+#pragma unroll
+    for (int c = 0; c < 3 * F; ++c) insum += fabsf(in[c]);
+    ok = insum < IN_LIMIT;                                   // false for NaN/inf as well
+    f32x16 a1[4];
+    layer1_mfma<F>(k.smem, k.w1_base, in, k.h, a1);
+    f16x8 Ah[8], Al[8], Bh[8], Bl[8];
+    float ss[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const unsigned g2 = k.g_base + HID * 4, g3 = k.g_base + 2 * HID * 4;
+    // ---- layer-1 activation, tiles 0..2 (nothing to run beside it)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        softplus16<false, false>(a1[j], k.smem, k.g_base, j, 1.0f, ss);
+        split16<false>(a1[j], 1.0f, k.hi_mask, Ah[2 * j], Ah[2 * j + 1], Al[2 * j], Al[2 * j + 1]);
+    }
+    SEG_FENCE();
+    TR(0);
+    f32x16 c2[2], l3[4];
+    f16x8 bone = {0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- layer 2 tile 0, k-steps 0..5  ||  layer-1 activation tile 3
+    woven<F, 0, 6, false, false, true, false>(c2[0], k.smem, k.a_base, LD::W2H, LD::W2L, 0, Ah, Al, 0u, bone, a1[3], k.g_base, 3,
+                                              1.0f, k.hi_mask, ss, k.f_base, nullptr, &Ah[6], &Ah[7], &Al[6], &Al[7]);
+    TR(1);
+    float nrm, inv, nlo, nhi;
+    norm_fast(chain_sum(ss), nrm, inv);
+    nlo = nhi = nrm;
+    bone = bias_operand(nrm * k.kb2);
+    mfma_tile<6, 8>(c2[0], k.smem, k.a_base, LD::W2H, LD::W2L, 0, Ah, Al);
+    mfma_bias(c2[0], k.ab2[0], bone);
+    TR(2);
+    ss[0] = ss[1] = ss[2] = ss[3] = 0.0f;
+    // ---- layer 2 tile j  ||  layer-2 activation of tile j-1
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        woven<F, 0, 8, true, true, true, false>(c2[j & 1], k.smem, k.a_base, LD::W2H, LD::W2L, j, Ah, Al, k.ab2[j], bone,
+                                                c2[(j - 1) & 1], g2, j - 1, inv, k.hi_mask, ss, k.f_base, nullptr,
+                                                &Bh[2 * j - 2], &Bh[2 * j - 1], &Bl[2 * j - 2], &Bl[2 * j - 1]);
+    TR(3);
+    // ---- layer 3 tile 0, k-steps 0..5  ||  layer-2 activation tile 3
+    woven<F, 0, 6, false, true, true, false>(l3[0], k.smem, k.a_base3, 0, W3REL, 0, Bh, Bl, 0u, bone, c2[1], g2, 3, inv,
+                                             k.hi_mask, ss, k.f_base, nullptr, &Bh[6], &Bh[7], &Bl[6], &Bl[7]);
+    TR(4);
+    norm_fast(chain_sum(ss), nrm, inv);
+    nlo = fminf(nlo, nrm);
+    nhi = fmaxf(nhi, nrm);
+    bone = bias_operand(nrm * k.kb3);
+    mfma_tile<6, 8>(l3[0], k.smem, k.a_base3, 0, W3REL, 0, Bh, Bl);
+    mfma_bias(l3[0], k.ab3[0], bone);
+    TR(5);
+    ss[0] = ss[1] = ss[2] = ss[3] = 0.0f;
+    float ea[F][4];
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ea[f][i] = 0.0f;
+    // ---- layer 3 tile j  ||  layer-3 activation (and eps-head partial sums) of tile j-1
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        woven<F, 0, 8, true, true, false, true>(l3[j], k.smem, k.a_base3, 0, W3REL, j, Bh, Bl, k.ab3[j], bone, l3[j - 1], g3,
+                                                j - 1, inv, k.hi_mask, ss, k.f_base, ea, nullptr, nullptr, nullptr, nullptr);
+    TR(6);
+    softplus16<false, true>(l3[3], k.smem, g3, 3, inv, ss);
+    eps_partial<F>(k, l3[3], 3, ea);
+    norm_fast(chain_sum(ss), nrm, inv);
+    nlo = fminf(nlo, nrm);
+    nhi = fmaxf(nhi, nrm);
+    ok = ok && (nlo > 1.0f) && (nhi < 8192.0f);              // NaN fails both
+    TR(7);
+    const Vec<F> out = heads_posterior<F>(k, t, l3, ea, inv, y, mu, g, z);
+    TR(8);
+    return out;
+}
+
+// ---- cold path: the exact evaluation (fp32 VALU layer 1, guarded softplus, normalised B operands) ---------------
+// Same weight images and scale rows: B = (l/||l||) 2^12, bias operand 2^12 kb, x' = g'' acc 2^-12.
 template <int F>
 __device__ __noinline__ Vec<F> chain_step_safe(StepCtx k, int t, Vec<F> y, Vec<F> mu, Vec<F> g, Vec<F> z) {
-    bool ok;
-    return chain_step<F, true>(k, t, y, mu, g, z, ok);
+    using LD = Lds<F>;
+    constexpr int W3REL = LD::W3L - LD::W3H;
+    float in[3 * F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        in[f] = y.v[f]; in[F + f] = mu.v[f]; in[2 * F + f] = g.v[f];
+    }
+    f32x16 a[4], c[4];
+    f16x8 bh[8], bl[8];
+    layer1_valu<F>(k.w1t, k.b1, in, k.h, k.l1_scale, a);
+    float ss[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) softplus16<true, false>(a[j], k.smem, k.g_base, j, 1.0f, ss);
+    float inv = 1.0f / fmaxf(sqrtf(chain_sum(ss)), 1e-12f / LN2);          // 1 / max(||l||, F.normalize eps / ln2)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split16<true>(a[j], inv * 4096.0f, k.hi_mask, bh[2 * j], bh[2 * j + 1], bl[2 * j], bl[2 * j + 1]);
+    f16x8 bone = bias_operand(4096.0f * k.kb2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mfma_tile<0, 8>(c[j], k.smem, k.a_base, LD::W2H, LD::W2L, j, bh, bl);
+        mfma_bias(c[j], k.ab2[j], bone);
+    }
+    ss[0] = ss[1] = ss[2] = ss[3] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) softplus16<true, true>(c[j], k.smem, k.g_base + HID * 4, j, 1.0f / 4096.0f, ss);
+    inv = 1.0f / fmaxf(sqrtf(chain_sum(ss)), 1e-12f / LN2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split16<true>(c[j], inv * 4096.0f, k.hi_mask, bh[2 * j], bh[2 * j + 1], bl[2 * j], bl[2 * j + 1]);
+    bone = bias_operand(4096.0f * k.kb3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mfma_tile<0, 8>(a[j], k.smem, k.a_base3, 0, W3REL, j, bh, bl);
+        mfma_bias(a[j], k.ab3[j], bone);
+    }
+    ss[0] = ss[1] = ss[2] = ss[3] = 0.0f;
+    float ea[F][4];
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ea[f][i] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        softplus16<true, true>(a[j], k.smem, k.g_base + 2 * HID * 4, j, 1.0f / 4096.0f, ss);
+        eps_partial<F>(k, a[j], j, ea);
+    }
+    inv = 1.0f / fmaxf(sqrtf(chain_sum(ss)), 1e-12f / LN2);
+    return heads_posterior<F>(k, t, a, ea, inv, y, mu, g, z);
 }
 
 template <int F, bool PHILOX>
@@ -438,6 +722,9 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r_lane = lane & 31, h_lane = lane >> 5;
+#ifdef MPV_TRACE
+    const unsigned long long tr_k0 = __builtin_amdgcn_s_memrealtime();
+#endif
     StepCtx k0;
     k0.smem = smem;
     k0.coef = p.coef; k0.w1t = p.w1t; k0.b1 = p.b1; k0.l1_scale = p.l1_scale;
@@ -453,8 +740,8 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
         k0.ab2[j] = h_lane ? 0u : p.b2p[32 * j + r_lane];
         k0.ab3[j] = h_lane ? 0u : p.b3p[32 * j + r_lane];
     }
-    k0.bone2 = p.bone2;
-    k0.bone3 = p.bone3;
+    k0.kb2 = p.bone2;
+    k0.kb3 = p.bone3;
     k0.hi_mask = p.hi_mask;                                                       // 0xFFFFE000, stays in an SGPR
     k0.h = h_lane;
     unsigned char* const gam_w = smem + LD::GAM + wave * (3 * HID * 4);
@@ -501,6 +788,11 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
             *reinterpret_cast<f32x4*>(gam_w + HID * 4 + gl) = *reinterpret_cast<const f32x4*>(p.g2 + g0);
             *reinterpret_cast<f32x4*>(gam_w + 2 * HID * 4 + gl) = *reinterpret_cast<const f32x4*>(p.g3 + g0);
         }
+#ifdef MPV_TRACE
+        unsigned long long tr[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long tr_last = __builtin_amdgcn_s_memtime();
+        const unsigned long long tr_t0 = tr_last, tr_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma nounroll
         for (int t = p.T - 1; t >= 0; --t) {
             // The LDS operands are loop invariant in t; left alone, LICM hoists hundreds of them out of the step
@@ -531,7 +823,8 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
             for (int i = 0; i < MPV_PAD_NOPS; ++i) asm volatile("s_nop 0");
 #endif
             bool ok = true;
-            Vec<F> yn = chain_step<F, false>(k, t, y, mu, g, zv, ok);
+            TR(9);
+            Vec<F> yn = chain_step_fast<F>(k, t, y, mu, g, zv, ok TR_ARGS);
             if (__builtin_expect(!__all(ok), 0)) yn = chain_step_safe<F>(k, t, y, mu, g, zv);
             y = yn;
             if (t > 0 && lane < 32) {                       // all reads of this step's rows are done (same wave, in order)
@@ -540,13 +833,29 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
                 *reinterpret_cast<f32x4*>(gam_w + 2 * HID * 4 + gl) = nx3;
             }
         }
+#ifdef MPV_TRACE
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            tr[12] = __builtin_amdgcn_s_memtime() - tr_t0;                 // shader-clock ticks of this tile
+            tr[13] = __builtin_amdgcn_s_memrealtime() - tr_r0;             // 100 MHz reference ticks of this tile
+            for (int i = 0; i < 14; ++i) atomicAdd(&mpv_trace[i], tr[i]);
+            atomicAdd(&mpv_trace[14], (unsigned long long)p.T);
+        }
+#endif
         if (valid && h_lane == 0) {
 #pragma unroll
             for (int f = 0; f < F; ++f) p.samples[(row * F + f) * p.S + s] = y.v[f];
         }
     }
+#ifdef MPV_TRACE
+    if (lane == 0) {
+        const unsigned long long life = __builtin_amdgcn_s_memrealtime() - tr_k0;
+        atomicMax(&mpv_trace[15], life);
+        atomicMin(&mpv_trace[10], life);
+    }
+#endif
 }
 
+// (trace) every wave: its lifetime in 100 MHz ticks -> min in [10], max in [15]
 template <int F>
 int launch_f16_f(mpv_ctx* ctx, const ChainArgs& a, bool philox, int grid) {
     auto kp = nsdiff_chain_f16_kernel<F, true>;
@@ -564,6 +873,18 @@ int launch_f16_f(mpv_ctx* ctx, const ChainArgs& a, bool philox, int grid) {
 }
 
 }  // namespace
+
+#ifdef MPV_TRACE
+extern "C" int mpv_debug_trace(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mpv_trace), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        z[10] = ~0ull;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mpv_trace), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 int launch_chain_f16(mpv_ctx* ctx, const chain::ChainArgs& a, bool philox, int grid, int nf) {
     switch (nf) {
