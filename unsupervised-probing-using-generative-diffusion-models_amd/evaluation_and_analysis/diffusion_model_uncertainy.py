@@ -553,6 +553,289 @@ def slbp_sensitivity_ews(model_root, model_name, torch_time_series, time_data, d
     }
 
 
+# ----------------------------------------------------------------------------------------
+# SLBP figure 5 / figure 6 analyses: which cache file holds what, and how it is summarised
+# (reference :624-1250).  All sampling goes through run_slbp_sensitivity_cache, all gx through the
+# native sigma head; the rest is cache bookkeeping that must stay file-compatible with the reference.
+# ----------------------------------------------------------------------------------------
+def _as_path(path):
+    return path if path is None or isinstance(path, Path) else Path(path)
+
+
+def _fig6_cache_dir(model_root, cache_subdir):
+    d = _resolve_project_path(model_root) / "datas"
+    return d / cache_subdir if cache_subdir else d
+
+
+def slbp_fig6_cache_path(model_root, model_name, data_trend, sample_window_step=10, cache_subdir=None, kind="pred_future"):
+    return _fig6_cache_dir(model_root, cache_subdir) / "{}_{}_{}_{}.pt".format(model_name, kind, data_trend, sample_window_step)
+
+
+def slbp_fig6_pred_future_gx_cache_path(model_root, model_name, data_trend, sample_window_step=10, cache_subdir=None):
+    return _fig6_cache_dir(model_root, cache_subdir) / "{}_pred_future_{}_{}_gx.pt".format(model_name, data_trend, sample_window_step)
+
+
+def _legacy_single_underscore_model_name(model_name):
+    return str(model_name).replace("dataset__", "dataset_", 1)
+
+
+def _read_slbp_fig6_model_config(model_root, model_name):
+    config_path = _resolve_project_path(model_root) / "models" / "{}.yaml".format(model_name)
+    if not config_path.exists():
+        return None
+    with open(config_path, "r", encoding="utf-8") as f:
+        return yaml.safe_load(f)
+
+
+def _slbp_fig6_dataset_config(model_root, model_name, windows=None, pred_len=None, sampling_t=None):
+    method_config = _read_slbp_fig6_model_config(model_root, model_name)
+    ds = method_config.get("dataset", {}) if method_config else {}
+    pick = lambda given, key, default: given if given is not None else ds.get(key, default)
+    return {"windows": pick(windows, "windows", 200), "pred_len": pick(pred_len, "pred_len", 200),
+            "sampling_t": pick(sampling_t, "sampling_t", 100), "method_config": method_config}
+
+
+def _slbp_cache_elements_have_ndim(data_list, ndim):
+    return bool(data_list) and all(torch.as_tensor(item).ndim == ndim for item in data_list)
+
+
+def _slbp_cache_elements_are_gx(data_list):
+    """[pred_len, F] (or [1, pred_len, F]) elements = a sigma-head cache; [pred_len, F, S] = a sampling cache."""
+    if _slbp_cache_elements_have_ndim(data_list, 2):
+        return True
+    return bool(data_list) and all(torch.as_tensor(i).ndim == 3 and torch.as_tensor(i).shape[0] == 1 for i in data_list)
+
+
+def summarize_slbp_gx_for_fig6(gx_list, pred_dim=0):
+    out = []
+    for gx in gx_list:
+        gx = torch.as_tensor(gx).detach().cpu()
+        if gx.ndim == 3 and gx.shape[0] == 1:
+            gx = gx.squeeze(0)
+        if gx.ndim != 2:
+            raise ValueError("SLBP gx cache elements must have shape [pred_len, F] or [1, pred_len, F].")
+        if pred_dim >= gx.shape[-1]:
+            raise IndexError("pred_dim {} out of bounds for F={}.".format(pred_dim, gx.shape[-1]))
+        out.append(float(gx[:, pred_dim].mean().numpy()))
+    return out
+
+
+def run_slbp_gx_cache_for_fig6(model, input_datas, cache_path, device, pred_dim=0, force_recompute=False, max_windows=None):
+    """sigma head over single-series windows -> list of [pred_len, F] (reference :731-765), one launch."""
+    cache_path = Path(cache_path)
+    if cache_path.exists() and not force_recompute:
+        cached = _load_tensor_list(cache_path)
+        if _slbp_cache_elements_are_gx(cached):
+            return cached
+    if getattr(model, "cond_pred_model_g", None) is None:
+        raise ValueError("model does not provide cond_pred_model_g for gx generation.")
+    windows = [torch.as_tensor(w).float().unsqueeze(0) for w in
+               (input_datas[:max_windows] if max_windows is not None else input_datas)]
+    gx_list = []
+    if windows:
+        ctx = model.native_context()
+        scale = _uses_scaler(model)
+        with torch.no_grad():
+            gx = ctx.sigma_head(_stack_windows(windows).to(ctx.device), 1, 0, 1, model.scaler_mean if scale else None,
+                                model.scaler_std if scale else None)
+        gx = gx.reshape(len(windows), model.pred_len, model.dataset_nf).cpu()
+        if pred_dim >= gx.shape[-1]:
+            raise IndexError("pred_dim {} out of bounds for F={}.".format(pred_dim, gx.shape[-1]))
+        gx_list = list(gx.unbind(0))
+    _save_tensor_list(gx_list, cache_path)
+    return gx_list
+
+
+def _fig6_windows(cfg, torch_time_series, time_data, sample_window_step):
+    return build_slbp_sensitivity_windows(torch_time_series, time_data, cfg["windows"], cfg["pred_len"], cfg["sampling_t"],
+                                          sample_window_step)
+
+
+def _cfg_fields(cfg, sample_window_step):
+    return {"windows": cfg["windows"], "pred_len": cfg["pred_len"], "sampling_t": cfg["sampling_t"],
+            "sample_window_step": sample_window_step}
+
+
+def slbp_sampling_analysis(model_root, model_name, torch_time_series, time_data, data_trend="increase", pred_dim=0,
+                           sample_window_step=10, cache_subdir=None, windows=None, pred_len=None, sampling_t=None,
+                           infer_params=None, force_recompute=False, max_windows=None, device=None, allow_unavailable=True):
+    """Figure-6 sampling curve: MPV and PCA dimension per window (reference :768-885).  The shared
+    `pred_future` cache name may hold a gx cache from older runs; sampling then lives in `sampling_pred_future`."""
+    cfg = _slbp_fig6_dataset_config(model_root, model_name, windows, pred_len, sampling_t)
+    input_datas, _targets, time_points = _fig6_windows(cfg, torch_time_series, time_data, sample_window_step)
+    shared = slbp_fig6_cache_path(model_root, model_name, data_trend, sample_window_step, cache_subdir, "pred_future")
+    own = slbp_fig6_cache_path(model_root, model_name, data_trend, sample_window_step, cache_subdir, "sampling_pred_future")
+    try:
+        active, preds = shared, None
+        if not force_recompute:
+            if shared.exists():
+                cand = _load_tensor_list(shared)
+                if _slbp_cache_elements_have_ndim(cand, 3):
+                    preds = cand
+                else:
+                    active = own
+            if preds is None and own.exists():
+                cand = _load_tensor_list(own)
+                if not _slbp_cache_elements_have_ndim(cand, 3):
+                    raise ValueError("sampling cache exists but is not [pred_len, F, n_z_samples]: {}".format(own))
+                preds, active = cand, own
+        if preds is None:
+            if shared.exists() and active == shared:
+                active = own
+            device = _default_device(device)
+            model, _cfg, _np = load_sensitivity_model(model_root, model_name, device=device, infer_params=infer_params)
+            preds = run_slbp_sensitivity_cache(model, input_datas, active, device, force_recompute=force_recompute,
+                                               max_windows=max_windows)
+            if not _slbp_cache_elements_have_ndim(preds, 3):
+                raise ValueError("generated sampling cache is not [pred_len, F, n_z_samples]: {}".format(active))
+        mpv, dims = summarize_slbp_sampling_for_fig6(preds, pred_dim=pred_dim)
+        return dict(available=True, time_points=time_points[: len(mpv)], mpv=mpv, intrinsic_dimension=dims,
+                    pred_future_list=preds, cache_path=str(active), reason="", **_cfg_fields(cfg, sample_window_step))
+    except Exception as exc:
+        if not allow_unavailable:
+            raise
+        return dict(available=False, time_points=time_points, mpv=[], intrinsic_dimension=[], pred_future_list=None,
+                    cache_path=str(own if shared.exists() else shared), reason=str(exc),
+                    **_cfg_fields(cfg, sample_window_step))
+
+
+def slbp_gx_analysis(model_root, model_name, torch_time_series, time_data, data_trend="increase", pred_dim=0,
+                     sample_window_step=10, cache_subdir=None, windows=None, pred_len=None, sampling_t=None,
+                     infer_params=None, force_recompute=False, max_windows=None, device=None):
+    """Figure-6 sigma-head curve (reference :888-1023).  Cache lookup order: `<name>_pred_future_*_gx.pt`, the
+    old `gx` kind, then the shared `pred_future` name (current and legacy single-underscore model name) if
+    it happens to hold a gx cache; otherwise compute into the first."""
+    cfg = _slbp_fig6_dataset_config(model_root, model_name, windows, pred_len, sampling_t)
+    input_datas, _targets, time_points = _fig6_windows(cfg, torch_time_series, time_data, sample_window_step)
+    target = slbp_fig6_pred_future_gx_cache_path(model_root, model_name, data_trend, sample_window_step, cache_subdir)
+    old_kind = slbp_fig6_cache_path(model_root, model_name, data_trend, sample_window_step, cache_subdir, "gx")
+    shared = [slbp_fig6_cache_path(model_root, n, data_trend, sample_window_step, cache_subdir, "pred_future")
+              for n in (model_name, _legacy_single_underscore_model_name(model_name))]
+
+    def compute():
+        dev = _default_device(device)
+        model, _cfg, _np = load_sensitivity_model(model_root, model_name, device=dev, infer_params=infer_params)
+        return run_slbp_gx_cache_for_fig6(model, input_datas, target, dev, pred_dim=pred_dim, force_recompute=force_recompute,
+                                          max_windows=max_windows)
+
+    used = target
+    if force_recompute:
+        gx_list = compute()
+    elif target.exists():
+        gx_list = _load_tensor_list(target)
+    elif old_kind.exists():
+        gx_list = _load_tensor_list(old_kind)
+        if not _slbp_cache_elements_are_gx(gx_list):
+            raise ValueError("gx cache exists but is not a gx cache: {}".format(old_kind))
+        used = old_kind
+    else:
+        first = next((c for c in shared if c.exists()), None)    # only the first existing candidate is examined
+        cand = _load_tensor_list(first) if first is not None else None
+        if cand is not None and _slbp_cache_elements_are_gx(cand):
+            gx_list, used = cand, first
+        else:
+            gx_list = compute()
+    return dict(time_points=time_points[: len(gx_list)], gx_mpv=summarize_slbp_gx_for_fig6(gx_list, pred_dim=pred_dim),
+                gx_list=gx_list, cache_path=str(used), **_cfg_fields(cfg, sample_window_step))
+
+
+def summarize_slbp_mpv_cache_for_fig5(data_list, pred_dim=0):
+    """-> (curve, "sampling" | "gx") according to what the cache elements look like (reference :1026-1036)."""
+    if _slbp_cache_elements_have_ndim(data_list, 3):
+        return summarize_slbp_sampling_for_fig6(data_list, pred_dim=pred_dim)[0], "sampling"
+    if _slbp_cache_elements_are_gx(data_list):
+        return summarize_slbp_gx_for_fig6(data_list, pred_dim=pred_dim), "gx"
+    shape = tuple(torch.as_tensor(data_list[0]).shape) if data_list else None
+    raise ValueError("Unsupported SLBP MPV cache element shape: {}".format(shape))
+
+
+def _cache_time_points(time_data, sampling_t, windows, cache_len, fallback_step, n):
+    sampled_time = torch_data_preprocessing_like_slbp(time_data, sampling_t=sampling_t, return_numpy=True)
+    step = infer_sample_window_step_from_cache(sampled_length=len(sampled_time), windows=windows, cache_len=cache_len,
+                                               fallback_step=fallback_step)
+    return sampled_time[windows - 1:: step][:n], step
+
+
+def slbp_mpv_analysis(model_root, model_name, torch_time_series, time_data, cache_path, pred_dim=0, sample_window_step=10,
+                      windows=None, pred_len=None, sampling_t=None, infer_params=None, force_recompute=False,
+                      max_windows=None, device=None):
+    """Figure-5 curve from an explicit cache file of either kind; the window step of an existing cache is
+    inferred from its length (reference :1039-1114)."""
+    cfg = _slbp_fig6_dataset_config(model_root, model_name, windows, pred_len, sampling_t)
+    cache_path = _resolve_project_path(cache_path)
+    if cache_path.exists() and not force_recompute:
+        data_list = _load_tensor_list(cache_path)
+        mpv, source = summarize_slbp_mpv_cache_for_fig5(data_list, pred_dim=pred_dim)
+        tp, step = _cache_time_points(time_data, cfg["sampling_t"], cfg["windows"], len(data_list), sample_window_step, len(mpv))
+    else:
+        dev = _default_device(device)
+        model, _cfg, _np = load_sensitivity_model(model_root, model_name, device=dev, infer_params=infer_params)
+        input_datas, _targets, time_points = _fig6_windows(cfg, torch_time_series, time_data, sample_window_step)
+        data_list = run_slbp_sensitivity_cache(model, input_datas, cache_path, dev, force_recompute=force_recompute,
+                                               max_windows=max_windows)
+        mpv, source = summarize_slbp_mpv_cache_for_fig5(data_list, pred_dim=pred_dim)
+        tp, step = time_points[: len(mpv)], sample_window_step
+    return dict(time_points=tp, mpv=mpv, pred_future_list=data_list, cache_path=str(cache_path), uncertainty_source=source,
+                **_cfg_fields(cfg, step))
+
+
+def slbp_direct_model_cache_analysis(model_save_file, torch_time_series, time_data, cache_path, pred_dim=0,
+                                     sample_window_step=10, cache_kind="auto", infer_params=None, force_recompute=False,
+                                     max_windows=None, device=None, compute_prediction_error=False):
+    """Same as slbp_mpv_analysis for a model directory (model_trained + .yaml) instead of a sweep root
+    (reference :1117-1230); optionally adds the prediction error of a sampling cache."""
+    method_config = read_model_config(model_save_file)
+    ds, net = method_config.get("dataset", {}), method_config.get("net", {})
+    windows = int(ds.get("windows", net.get("windows", 200)))
+    pred_len = int(ds.get("pred_len", net.get("pred_len", 200)))
+    sampling_t = int(ds.get("sampling_t", 100))
+    cache_path = _resolve_project_path(cache_path)
+    model = None
+
+    def need_model():
+        nonlocal model, device
+        if model is None:
+            device = _default_device(device)
+            model, _np = load_model_from_dir(model_save_file, device=device, infer_params=infer_params, method_config=method_config)
+        return model
+
+    if cache_path.exists() and not force_recompute:
+        data_list = _load_tensor_list(cache_path)
+    else:
+        if cache_kind not in {"gx", "sampling"}:
+            raise ValueError("cache_kind must be 'gx' or 'sampling' when cache is missing.")
+        input_datas, _targets, _tp = build_slbp_sensitivity_windows(torch_time_series, time_data, windows, pred_len, sampling_t,
+                                                                   sample_window_step)
+        runner = run_slbp_gx_cache_for_fig6 if cache_kind == "gx" else run_slbp_sensitivity_cache
+        extra = {"pred_dim": pred_dim} if cache_kind == "gx" else {}
+        data_list = runner(need_model(), input_datas, cache_path, device, force_recompute=force_recompute,
+                           max_windows=max_windows, **extra)
+    mpv, source = summarize_slbp_mpv_cache_for_fig5(data_list, pred_dim=pred_dim)
+    tp, step = _cache_time_points(time_data, sampling_t, windows, len(data_list), sample_window_step, len(mpv))
+    result = dict(time_points=tp, mpv=mpv, pred_future_list=data_list, cache_path=str(cache_path), windows=windows,
+                  pred_len=pred_len, sampling_t=sampling_t, sample_window_step=step, uncertainty_source=source)
+    if compute_prediction_error:
+        if source != "sampling":
+            raise ValueError("prediction_error requires a sampling cache, got '{}'.".format(source))
+        _inp, targets, _tp = build_slbp_sensitivity_windows(torch_time_series, time_data, windows, pred_len, sampling_t, step)
+        _mpv, result["prediction_error"] = summarize_slbp_sensitivity(data_list, targets[: len(data_list)], model=need_model(),
+                                                                      device=device, pred_dim=pred_dim)
+    return result
+
+
+def slbp_raw_window_variance(torch_time_series, time_data, windows=200, sampling_t=100, sample_window_step=10, pred_dim=0):
+    """The classical indicator beside the MPV curve: variance of each raw sliding window (reference :1233-1250)."""
+    series = torch_data_preprocessing_like_slbp(torch_time_series, sampling_t=sampling_t)
+    sampled_time = torch_data_preprocessing_like_slbp(time_data, sampling_t=sampling_t, return_numpy=True)
+    if series.ndim != 2:
+        raise ValueError("SLBP raw series must have shape [T, F].")
+    if pred_dim >= series.shape[1]:
+        raise IndexError("pred_dim {} out of bounds for F={}.".format(pred_dim, series.shape[1]))
+    variances = series[:, pred_dim].unfold(0, windows, sample_window_step).var(dim=1, unbiased=False).cpu().numpy()
+    return {"time_points": sampled_time[windows - 1:: sample_window_step][: len(variances)], "variance": variances,
+            "windows": windows, "sampling_t": sampling_t, "sample_window_step": sample_window_step}
+
+
 _METHOD_ALIASES = {"variance": "sampling", "sampling_variance": "sampling", "pred_future": "sampling", "pred": "sampling",
                    "g": "gx", "preg": "gx", "nsdiff_g": "gx"}
 
