@@ -325,12 +325,6 @@ __device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, un
     // prologue: scale rows (and eps-head rows) of the activated tile, A operands of the first two k-steps
 #pragma unroll
     for (int q = 0; q < 4; ++q) s.gm[q] = LDS_F4(smem, grow + (32 * ja + 8 * q) * 4);
-    if constexpr (EPS) {
-#pragma unroll
-        for (int f = 0; f < F; ++f)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) s.w4[f][q] = LDS_F4(smem, f_base + (LD::W4 - LD::F32) + (f * HID + 32 * ja + 8 * q) * 4);
-    }
     load_a(IC<KS0>{});
     if constexpr (NKS > 1) load_a(IC<KS0 + 1>{});
     SEG_FENCE();
@@ -360,6 +354,11 @@ __device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, un
         static_for<PL::P.start[g], PL::P.start[g + 1]>([&](auto kc) {
             constexpr int kk = decltype(kc)::value;
             constexpr int ST = PL::P.st[kk], E = PL::P.el[kk];
+            if constexpr (EPS && ST == 2 && (E & 3) == 0) {        // eps-head rows of this quad, a few diagonals ahead of use
+#pragma unroll
+                for (int f = 0; f < F; ++f)
+                    s.w4[f][E >> 2] = LDS_F4(smem, f_base + (LD::W4 - LD::F32) + (f * HID + 32 * ja + 8 * (E >> 2)) * 4);
+            }
             if constexpr (ST < 6) act_op<ST, E, F>(s);
             else if constexpr (SPLIT) split_op<ST, E, F>(s);
             else {
@@ -488,6 +487,22 @@ struct StepCtx {                 // everything a step needs besides the chain st
     int h;
 };
 
+// one feature of one chain: finish the two head dot products across the half-waves, sigma's softplus, posterior.
+// With F > 1 this runs out of line, so the step loop holds ONE copy of the division / square-root sequences (the
+// loop body has to stay under the 16 KB instruction-fetch cliff, tools/ubench/ifetch.hip).
+__device__ __forceinline__ float feature_update(const float* cr, float ep, float sp, float b4, float bs, float y, float mu,
+                                                float g, float z, bool last) {
+    const StepCoef c = {cr[0], cr[1], cr[2],  cr[3],  cr[4],  cr[5],  cr[6],  cr[7],  cr[8],
+                        cr[9], cr[10], cr[11], cr[12], cr[13], cr[14], cr[15], cr[16], cr[17]};
+    const float eps = ep + __shfl_xor(ep, 32) + b4;
+    const float sig = softplus_dev(sp + __shfl_xor(sp, 32) + bs);
+    return posterior(c, y, mu, g, eps, sig, z, last);
+}
+__device__ __noinline__ float feature_update_ool(const float* cr, float ep, float sp, float b4, float bs, float y, float mu,
+                                                 float g, float z, bool last) {
+    return feature_update(cr, ep, sp, b4, bs, y, mu, g, z, last);
+}
+
 // ---- sigma / eps heads on h3 = l3 * inv3 in [0,1] and the posterior update (shared by both paths) ---------------
 // eps = W4 h3 + b4 (ea holds W4 l3, un-normalised); sigma = softplus((Ws ln2) softplus(h3)/ln2 + bs)
 template <int F>
@@ -522,17 +537,14 @@ __device__ __forceinline__ Vec<F> heads_posterior(const StepCtx& k, int t, f32x1
             }
         }
     }
-    const StepCoef c = {cr[0], cr[1], cr[2],  cr[3],  cr[4],  cr[5],  cr[6],  cr[7],  cr[8],
-                        cr[9], cr[10], cr[11], cr[12], cr[13], cr[14], cr[15], cr[16], cr[17]};
     const float* hb = reinterpret_cast<const float*>(k.smem + LD::HB);
     Vec<F> out;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         const float ep = ((ea[f][0] + ea[f][1]) + (ea[f][2] + ea[f][3])) * inv;
         const float sp = (sa[f][0] + sa[f][1]) + (sa[f][2] + sa[f][3]);
-        const float eps = ep + __shfl_xor(ep, 32) + hb[f];
-        const float sig = softplus_dev(sp + __shfl_xor(sp, 32) + hb[4 + f]);
-        out.v[f] = posterior(c, y.v[f], mu.v[f], g.v[f], eps, sig, z.v[f], t == 0);
+        if (F == 1) out.v[f] = feature_update(cr, ep, sp, hb[f], hb[4 + f], y.v[f], mu.v[f], g.v[f], z.v[f], t == 0);
+        else out.v[f] = feature_update_ool(cr, ep, sp, hb[f], hb[4 + f], y.v[f], mu.v[f], g.v[f], z.v[f], t == 0);
     }
     return out;
 }
