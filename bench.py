@@ -169,7 +169,7 @@ def main():
                                "trajectory, one trajectory per GPU per step".format(n_windows),
                    "windows_per_step_per_gpu": n_windows, "truncated_for_profiling": args.max_windows is not None, "noise": "on-device Philox4x32-10",
                    "weights": "seeded default init (shipped checkpoints pin T=20)"},
-        "roofline": roofline(args.gemm, achieved, kernel_ms, launches, flop_per_launch),
+        "roofline": roofline(args.gemm, achieved, kernel_ms, launches, flop_per_launch, n_windows),
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -180,7 +180,23 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(gemm, achieved, kernel_ms, launches, flop_per_launch):
+def measured_traffic(kernel, n_windows):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*/pmc_traffic*.json, collected by
+    tools/run_pmc_traffic.sh with the guide's gfx950 corrections); None when no pass matches this workload."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "pmc_traffic*.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                rec = json.load(fh).get(kernel)
+        except (OSError, ValueError):
+            continue
+        if rec and rec.get("windows") == n_windows:
+            return {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": rec["algorithmic_bytes_per_launch"],
+                    "source": os.path.relpath(f, os.path.dirname(os.path.abspath(__file__)))}
+    return None
+
+
+def roofline(gemm, achieved, kernel_ms, launches, flop_per_launch, n_windows):
     """`achieved` = algorithmic TFLOP/s of the chain kernel (256*(256+5F) flop per chain-step)."""
     if gemm == "f32":
         return {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -190,13 +206,16 @@ def roofline(gemm, achieved, kernel_ms, launches, flop_per_launch):
     # split-f16: three f16 MFMA flops are executed per algorithmic flop of the two 128x128 layers, so the
     # matrix-pipe ceiling for ALGORITHMIC flops is the dense f16 peak / 3
     peak = F16_MATRIX_PEAK_TFLOPS / 3.0
+    tr = measured_traffic("nsdiff_chain_f16_kernel<1,true>", n_windows)
     return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": None, "kernel": "nsdiff_chain_f16_kernel<1,true>", "kernel_avg_ms": kernel_ms, "launches": launches,
+            "traffic": (tr or {}).get("hbm_bytes_per_launch"), "traffic_detail": tr, "kernel": "nsdiff_chain_f16_kernel<1,true>",
+            "kernel_avg_ms": kernel_ms, "launches": launches,
             "flop_per_launch": flop_per_launch,
             "peak_source": "dense f16 MFMA peak 2500 TFLOP/s / 3 MFMA products per algorithmic product (f16x3 split)",
             "mfma_executed_tflops": 3.0 * achieved * 65536.0 / 66816.0,
             "vs_fp32_matrix_peak": achieved / FP32_MATRIX_PEAK_TFLOPS,
-            "note": "live bound is VALU/transcendental issue, not the matrix pipe (DESIGN.md 3.1)"}
+            "note": "live bound is vector-instruction issue (about 12.6 k issue cycles per 32-chain step against 6.5 k of matrix "
+                    "pipe, shader clock 1.9 GHz under load), not the matrix pipe: DESIGN.md 3.1 item 3"}
 
 
 def cpu_baseline_and_parity(model, sampled, n_cpu_windows):
