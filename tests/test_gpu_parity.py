@@ -345,3 +345,43 @@ def test_philox_default_mode_statistics_and_repeatability(ckpt_wofx):
     va, vd = a.var(dim=-1, unbiased=False).mean().item(), d.var(dim=-1, unbiased=False).mean().item()
     assert abs(va - vd) / vd < 0.05, (va, vd)
     assert abs(a.mean().item() - d.mean().item()) < 0.05 * d.std().item()
+
+
+# ---- BASELINE configs[1] at full size: properties that do not need the oracle ---------------------------------
+def test_full_size_c2_properties():
+    """100 nodes, windows = pred_len = 100, N = 32, T = 50, 6 windows in one launch (19.2 M chain-steps x 50):
+    finite, bitwise repeatable under the same seed, different under another; the device MPV reduction equals a
+    float64 torch reduction of the very samples it consumed; f16x3 and exact-fp32 GEMM modes agree on identical
+    Philox noise to the parity tolerance."""
+    from mpv_amd import synthetic
+    from mpv_amd.models.models import diffusion_models
+    V, Wn, O, S, Tn, W = 100, 100, 100, 32, 50, 6
+    param = dict(device="cuda:0", dataset_nf=1, windows=Wn, pred_len=O, rolling_length=50, diffusion_steps=Tn,
+                 diffusion_schedule="linear", beta_start=1e-4, beta_end=0.02, n_z_samples=S, parallel_sample=S,
+                 scaler_type="StandardScaler", task_model="NsDiff_model_variants")
+    g = torch.Generator().manual_seed(11)
+    series = (torch.cumsum(torch.randn(V, Wn + 5 * (W - 1), 1, generator=g) * 0.05, dim=1) + 3.0)
+    proto = diffusion_models("NsDiff_model_variants", dict(param, device="cpu"), train_model_select="cond_var")
+    synthetic.seeded_nsdiff_state(proto, series, seed=3)
+    sd = {k: v.clone() for k, v in proto.state_dict().items()}
+    outs = {}
+    for gemm in ("f16x3", "f32"):
+        m = diffusion_models("NsDiff_model_variants", dict(param, gemm_mode=gemm), train_model_select="cond_var")
+        m.load_state_dict(sd)
+        m = m.to("cuda:0").eval()
+        samples, gx = m.sample_windows(series, W, first=0, step=5, scale_input=True, seed=77)
+        outs[gemm] = samples
+        assert tuple(samples.shape) == (W, V, O, 1, S) and bool(torch.isfinite(samples).all())
+        if gemm == "f16x3":
+            again, _ = m.sample_windows(series, W, first=0, step=5, scale_input=True, seed=77)
+            other, _ = m.sample_windows(series, W, first=0, step=5, scale_input=True, seed=78)
+            assert torch.equal(samples, again) and not torch.equal(samples, other)
+            ctx = m.native_context()
+            mpv, pm, _ = ctx.reduce(samples, m.scaler_std, m.scaler_mean)
+            x = samples.double() * m.scaler_std.double().view(1, 1, 1, -1, 1) + m.scaler_mean.double().view(1, 1, 1, -1, 1)
+            want = x.var(dim=-1, unbiased=False).mean(dim=(1, 2, 3))
+            assert rel_err(mpv, want) < 1e-5 and rel_err(pm, x.mean(dim=(1, 2, 3, 4))) < 1e-5
+            assert bool((gx > 0).all())
+    err = rel_err(outs["f16x3"], outs["f32"])
+    print("full-size C2: f16x3 vs exact fp32 on identical Philox noise, max rel err %.3e" % err)
+    assert err < RTOL
