@@ -76,8 +76,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=1, help="windows of the workload timed on the CPU oracle")
-    ap.add_argument("--gemm", choices=("f16x3", "f32"), default="f16x3",
-                    help="evaluation of the two 128x128 layers: split-f16 matrix cores (default) or exact fp32 MFMA")
+    ap.add_argument("--gemm", choices=("f16x3", "f32", "f16x2", "f16"), default="f16x3",
+                    help="evaluation of the two 128x128 layers for the HEADLINE number: split-f16 matrix cores, fp32-equivalent "
+                         "(default), exact fp32 MFMA, or the reduced-precision operand modes f16x2 / f16 (fp32 accumulate)")
+    ap.add_argument("--no-other-modes", action="store_true",
+                    help="skip the extra, separately reported runs of the reduced-precision operand modes (N=1 only)")
     ap.add_argument("--max-windows", type=int, default=None, help="profiling aid: cut the trajectory to this many windows "
                     "(the reported metric is then NOT the BASELINE workload and says so)")
     args = ap.parse_args()
@@ -116,9 +119,9 @@ def main():
     mean_dev, std_dev = model.scaler_mean.float().contiguous(), model.scaler_std.float().contiguous()
     S, P = CFG["n_z"], CFG["parallel_sample"]
 
-    def step(seed):
+    def step(seed, gemm=args.gemm):
         gx = ctx.sigma_head(series_dev, n_windows, 0, CFG["window_step"], mean_dev, std_dev, add_eps=model.EPS)
-        samples = ctx.sample(gx, None, S, P, seed=seed, gemm=args.gemm)
+        samples = ctx.sample(gx, None, S, P, seed=seed, gemm=gemm)
         mpv, pm, _ = ctx.reduce(samples, std_dev, mean_dev)
         curve = torch.stack([mpv, pm])                                                      # [2, W]
         if use_dist:
@@ -162,7 +165,7 @@ def main():
         "metric": "rolling windows/sec (N=32, T=50) + MPV max-abs err vs CPU ref",
         "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.gemm == "f32" else "f32 (128x128 layers as 3x f16 MFMA with fp32 accumulate)",
+        "dtype": DTYPES[args.gemm],
         "data": "synthetic",
         "config": {"workload": "NsDiff cond_var on 100-node BA-graph biomass trajectory (BASELINE configs[1]): "
                                "windows=100, pred_len=100, rolling=50, N=32 samples, T=50 steps, {} windows per "
@@ -172,12 +175,49 @@ def main():
         "roofline": roofline(args.gemm, achieved, kernel_ms, launches, flop_per_launch, n_windows),
     }
 
+    # ---- reduced-precision operand modes, reported separately; never the headline unless --gemm asks
+    others = [] if (world > 1 or args.no_other_modes) else [g for g in ("f16x2", "f16") if g != args.gemm]
+    other_modes = {}
+    for g in others:
+        n_steps = max(1, min(args.steps, 3))
+        step(7, g)
+        ctx.timing_enable(True)
+        ctx.timing()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step(200 + i, g)
+        fence()
+        dt = time.perf_counter() - t0
+        kms, _ = ctx.timing()
+        ctx.timing_enable(False)
+        products = {"f16x2": 2, "f16": 1}[g]
+        other_modes[g] = {"value": n_windows * n_steps / dt, "unit": "windows/s", "steps": n_steps, "ms_per_step": dt / n_steps * 1e3,
+                          "dtype": DTYPES[g], "kernel_avg_ms": kms,
+                          "achieved_tflops": flop_per_launch / (kms * 1e-3) / 1e12 if kms > 0 else 0.0,
+                          "mfma_peak_tflops": F16_MATRIX_PEAK_TFLOPS / products}
+        log("mode %s: %.1f windows/s" % (g, other_modes[g]["value"]))
+    if other_modes:
+        out["other_modes"] = other_modes
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out.update(cpu_baseline_and_parity(model, sampled, args.cpu_windows))
+        parity = cpu_baseline_and_parity(model, sampled, args.cpu_windows, [args.gemm] + others)
+        for g, err in parity.pop("per_mode").items():
+            if g == args.gemm:
+                out.update(err)
+            else:
+                other_modes[g].update(err)
+        out.update(parity)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+DTYPES = {"f32": "f32",
+          "f16x3": "f32 (128x128 layers as 3x f16 MFMA with fp32 accumulate)",
+          "f16x2": "f32 elementwise + accumulate; 128x128 layers with two-term f16 weights and ONE-term f16 activations (2 MFMA products)",
+          "f16": "f32 elementwise + accumulate; 128x128 layers with f16 weights and f16 activations (1 MFMA product)"}
 
 
 def measured_traffic(kernel, n_windows):
@@ -205,6 +245,14 @@ def roofline(gemm, achieved, kernel_ms, launches, flop_per_launch, n_windows):
                 "peak_source": "fp32 matrix pipe (v_mfma_f32_32x32x2_f32)"}
     # split-f16: three f16 MFMA flops are executed per algorithmic flop of the two 128x128 layers, so the
     # matrix-pipe ceiling for ALGORITHMIC flops is the dense f16 peak / 3
+    products = {"f16x3": 3, "f16x2": 2, "f16": 1}[gemm]
+    if products != 3:
+        peak = F16_MATRIX_PEAK_TFLOPS / products
+        return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "kernel": "nsdiff_chain_f16_kernel<1,true,%d>" % products, "kernel_avg_ms": kernel_ms, "launches": launches,
+                "flop_per_launch": flop_per_launch,
+                "peak_source": "dense f16 MFMA peak 2500 TFLOP/s / %d MFMA products per algorithmic product" % products,
+                "note": "reduced-precision operand mode; live bound is vector-instruction issue (DESIGN.md 3.1)"}
     peak = F16_MATRIX_PEAK_TFLOPS / 3.0
     tr = measured_traffic("nsdiff_chain_f16_kernel<1,true>", n_windows)
     return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -218,8 +266,9 @@ def roofline(gemm, achieved, kernel_ms, launches, flop_per_launch, n_windows):
                     "pipe, shader clock 1.9 GHz under load), not the matrix pipe: DESIGN.md 3.1 item 3"}
 
 
-def cpu_baseline_and_parity(model, sampled, n_cpu_windows):
-    """Time the CPU oracle on the first window(s) of the same workload and compare MPV on shared noise."""
+def cpu_baseline_and_parity(model, sampled, n_cpu_windows, modes):
+    """Time the CPU oracle on the first window(s) of the same workload and compare MPV on shared noise, for every
+    GEMM mode in `modes`."""
     from oracle import nsdiff_oracle as O
     cores = cpu_share()
     torch.set_num_threads(cores)
@@ -241,24 +290,30 @@ def cpu_baseline_and_parity(model, sampled, n_cpu_windows):
     log("cpu baseline done in %.1f s" % cpu_s)
     # same windows on the GPU with the very noise the CPU run consumed (reference draw order)
     per = len(rec) // n_cpu_windows
-    gpu_mpv, samp_err = [], 0.0
     ctx = model.native_context()
-    for i, w in enumerate(wins):
-        noise = torch.cat([z.reshape(-1) for z in rec[i * per:(i + 1) * per]])
-        x = O.scale(w, sd["scaler_mean"], sd["scaler_std"])
-        outs, _ = model.evaluation_step(x, noise=noise)
-        samp_err = max(samp_err, float((outs - cpu_out[i]).abs().max() / cpu_out[i].abs().max()))
-        mpv, _, _ = ctx.reduce(outs.to(ctx.device).unsqueeze(0).contiguous(), model.scaler_std.float().contiguous(),
-                               model.scaler_mean.float().contiguous())
-        gpu_mpv.append(float(mpv[0]))
-    cpu_mpv, gpu_mpv = np.array(cpu_mpv), np.array(gpu_mpv)
+    cpu_mpv = np.array(cpu_mpv)
+    per_mode = {}
+    for gemm in modes:
+        model.gemm_mode = gemm
+        gpu_mpv, samp_err = [], 0.0
+        for i, w in enumerate(wins):
+            noise = torch.cat([z.reshape(-1) for z in rec[i * per:(i + 1) * per]])
+            x = O.scale(w, sd["scaler_mean"], sd["scaler_std"])
+            outs, _ = model.evaluation_step(x, noise=noise)
+            samp_err = max(samp_err, float((outs - cpu_out[i]).abs().max() / cpu_out[i].abs().max()))
+            mpv, _, _ = ctx.reduce(outs.to(ctx.device).unsqueeze(0).contiguous(), model.scaler_std.float().contiguous(),
+                                   model.scaler_mean.float().contiguous())
+            gpu_mpv.append(float(mpv[0]))
+        gpu_mpv = np.array(gpu_mpv)
+        per_mode[gemm] = {"mpv_max_abs_err": float(np.abs(gpu_mpv - cpu_mpv).max()),
+                          "mpv_max_rel_err": float((np.abs(gpu_mpv - cpu_mpv) / np.abs(cpu_mpv)).max()),
+                          "samples_max_rel_err": samp_err}
+    model.gemm_mode = modes[0]
     return {
         "cpu_baseline": {"value": n_cpu_windows / cpu_s, "unit": "windows/s", "cores": cores, "kind": "port",
                          "sample": "first {} of the 181 windows, full N=32 x T=50, oracle/nsdiff_oracle.py "
                                    "(torch CPU fp32 port of the reference eager path), {:.1f} s".format(n_cpu_windows, cpu_s)},
-        "mpv_max_abs_err": float(np.abs(gpu_mpv - cpu_mpv).max()),
-        "mpv_max_rel_err": float((np.abs(gpu_mpv - cpu_mpv) / np.abs(cpu_mpv)).max()),
-        "samples_max_rel_err": samp_err,
+        "per_mode": per_mode,
     }
 
 

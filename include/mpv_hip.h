@@ -50,6 +50,12 @@ extern "C" {
  *   MPV_GEMM_F32    v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 FMA chain.                              */
 #define MPV_GEMM_F16X3 0
 #define MPV_GEMM_F32 1
+/* Reduced-precision modes of the same kernel ("bf16 mode reported separately"); fp32 accumulate,
+ * fp32 elementwise work, only the MFMA operands are narrower.  Not fp32-equivalent: report their parity beside the
+ * number.   MPV_GEMM_F16X2: weights two-term f16, activations ONE f16 (round to nearest): two MFMAs per k-step.
+ *           MPV_GEMM_F16  : weights and activations one f16 each: one MFMA per k-step.                       */
+#define MPV_GEMM_F16X2 2
+#define MPV_GEMM_F16 3
 
 typedef struct mpv_ctx mpv_ctx;
 
@@ -120,7 +126,7 @@ typedef struct {
     int32_t pred_len;     /* O                                                                     */
     int32_t n_samples;    /* S = n_z_samples                                                       */
     int32_t chunk;        /* P = parallel_sample; S % P == 0.  Only fixes the noise draw order.   */
-    int32_t gemm;         /* MPV_GEMM_F16X3 (0, default) or MPV_GEMM_F32: how the two 128x128 layers are evaluated */
+    int32_t gemm;         /* MPV_GEMM_F16X3 (0, default), MPV_GEMM_F32, MPV_GEMM_F16X2 or MPV_GEMM_F16: how the two 128x128 layers are evaluated */
     uint64_t seed;        /* Philox key when noise == NULL                                         */
     uint64_t offset;      /* Philox stream offset (counter word 3) when noise == NULL              */
 } mpv_sample_shape;

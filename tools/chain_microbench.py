@@ -29,10 +29,12 @@ flop = W * 100 * 100 * 32 * T * 256 * (256 + 5 * nf)
 print("%-28s %-6s W=%d  %.2f ms/launch  %.3f ms/window  %.1f TFLOP/s (%.1f%% of 157.3)  checksum %.6f" % (
     os.environ.get("MPV_LIB", "default"), GEMM, W, ms, ms / W, flop / ms / 1e9, flop / ms / 1e9 / 157.3 * 100, float(out.double().mean())))
 if os.environ.get("ACC"):
-    a = ctx.sample(gx[:2], None, 32, 32, seed=7, gemm="f16x3").double()
+    a = ctx.sample(gx[:2], None, 32, 32, seed=7, gemm=GEMM).double()
     b = ctx.sample(gx[:2], None, 32, 32, seed=7, gemm="f32").double()
     d = (a - b).abs()
-    print("   f16x3 vs f32 (same Philox noise): max|d|/max|ref| %.3e   mean|d|/mean|ref| %.3e   nan %d/%d" % (
+    mpv_a, mpv_b = a.var(dim=-1, unbiased=False).mean(dim=(1, 2, 3)), b.var(dim=-1, unbiased=False).mean(dim=(1, 2, 3))
+    print("   MPV rel err per window vs f32: %s" % ", ".join("%.2e" % float(v) for v in ((mpv_a - mpv_b).abs() / mpv_b)))
+    print("   " + GEMM + " vs f32 (same Philox noise): max|d|/max|ref| %.3e   mean|d|/mean|ref| %.3e   nan %d/%d" % (
         float(d[~d.isnan()].max() / b[~b.isnan()].abs().max()), float(d[~d.isnan()].mean() / b[~b.isnan()].abs().mean()),
         int(a.isnan().sum()), int(b.isnan().sum())))
 if os.environ.get("TRACE"):

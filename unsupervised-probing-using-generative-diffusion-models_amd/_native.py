@@ -19,7 +19,7 @@ ABI_VERSION = 1
 HIDDEN = 128
 MAX_NF = 4
 COEF_COLS = 20
-GEMM_MODES = {"f16x3": 0, "f32": 1}
+GEMM_MODES = {"f16x3": 0, "f32": 1, "f16x2": 2, "f16": 3}
 
 EXPORTS = (
     "mpv_abi_version", "mpv_ctx_create", "mpv_ctx_destroy", "mpv_ctx_set_stream", "mpv_last_error",

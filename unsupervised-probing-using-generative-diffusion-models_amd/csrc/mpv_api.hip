@@ -285,8 +285,8 @@ int mpv_nsdiff_sample(mpv_ctx* ctx, const mpv_sample_shape* s, const float* y0ha
         return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: negative extent");
     const bool empty = s->n_windows == 0 || s->nodes == 0 || s->pred_len == 0 || s->n_samples == 0;
     if (!empty && (!gx || !samples)) return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: NULL argument");
-    if (s->gemm != MPV_GEMM_F16X3 && s->gemm != MPV_GEMM_F32)
-        return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: gemm must be MPV_GEMM_F16X3 or MPV_GEMM_F32");
+    if (s->gemm < MPV_GEMM_F16X3 || s->gemm > MPV_GEMM_F16)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: gemm must be MPV_GEMM_F16X3, MPV_GEMM_F32, MPV_GEMM_F16X2 or MPV_GEMM_F16");
     if (s->n_samples > 0 && (s->chunk < 1 || s->n_samples % s->chunk != 0))
         return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: n_samples must be a positive multiple of chunk");
     DeviceGuard g(ctx->device);

@@ -58,7 +58,7 @@ int mpv_fail(mpv_ctx* ctx, int code, const std::string& msg);
 int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* gx,
                         const float* noise, float* samples);
 namespace chain { struct ChainArgs; }
-int launch_chain_f16(mpv_ctx* ctx, const chain::ChainArgs& a, bool philox, int grid, int nf);
+int launch_chain_f16(mpv_ctx* ctx, const chain::ChainArgs& a, bool philox, int grid, int nf, int products);
 int launch_tmdm_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* noise, float* samples);
 int launch_philox_dump(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out);
 int launch_sigma_head(mpv_ctx* ctx, const float* series, int V, int64_t L, int n_windows, int64_t first, int64_t step,

@@ -323,8 +323,8 @@ int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0
     }
     int rc;
     const bool philox = (noise == nullptr);
-    if (s.gemm == MPV_GEMM_F16X3) {
-        rc = launch_chain_f16(ctx, a, philox, grid, m.nf);
+    if (s.gemm == MPV_GEMM_F16X3 || s.gemm == MPV_GEMM_F16X2 || s.gemm == MPV_GEMM_F16) {
+        rc = launch_chain_f16(ctx, a, philox, grid, m.nf, s.gemm == MPV_GEMM_F16X3 ? 3 : (s.gemm == MPV_GEMM_F16X2 ? 2 : 1));
     } else
     switch (m.nf) {
         case 1: rc = launch_f<1>(ctx, a, philox, grid); break;

@@ -110,17 +110,23 @@ __device__ __forceinline__ f32x16 mfma16(const f16x8& a, const f16x8& b, const f
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-// one k-step of output tile j: acc += W_lo h_hi + W_hi h_lo + W_hi h_hi   (FIRST: acc starts from zero)
-template <bool FIRST>
+// one k-step of output tile j: acc += W_lo h_hi + W_hi h_lo + W_hi h_hi   (FIRST: acc starts from zero).
+// NP = products kept: 3 = all (fp32-equivalent, >= 21 bits), 2 = W_lo h_hi + W_hi h_hi (activations rounded to f16),
+// 1 = W_hi h_hi (plain f16 operands); accumulation is fp32 in every mode.
+template <bool FIRST, int NP>
 __device__ __forceinline__ void mfma_ks(f32x16& acc, const unsigned char* smem, unsigned wbase, int img_hi, int img_lo, int j,
                                         int ks, const f16x8& bh, const f16x8& bl) {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int off = j * 32 * (HROW * 2) + ks * 32;
     const f16x8 ah = LDS_H8(smem, wbase + img_hi + off);
-    const f16x8 al = LDS_H8(smem, wbase + img_lo + off);
-    acc = mfma16(al, bh, FIRST ? zero : acc);
-    acc = mfma16(ah, bl, acc);
-    acc = mfma16(ah, bh, acc);
+    if (NP >= 2) {
+        const f16x8 al = LDS_H8(smem, wbase + img_lo + off);
+        acc = mfma16(al, bh, FIRST ? zero : acc);
+        if (NP == 3) acc = mfma16(ah, bl, acc);
+        acc = mfma16(ah, bh, acc);
+    } else {
+        acc = mfma16(ah, bh, FIRST ? zero : acc);
+    }
 }
 
 // bias k-slots: A = (b_hi, b_lo, b_hi, 0...) of the lane's row (upper half-wave zero), B = (c_hi, c_hi, c_lo, 0...)
@@ -137,13 +143,13 @@ __device__ __forceinline__ f16x8 bias_operand(float c) {            // c = c_hi 
 }
 
 // all k-steps ks0..ks1-1 of tile j
-template <int KS0, int KS1>
+template <int KS0, int KS1, int NP = 3>
 __device__ __forceinline__ void mfma_tile(f32x16& acc, const unsigned char* smem, unsigned wbase, int img_hi, int img_lo, int j,
                                           const f16x8 (&bh)[8], const f16x8 (&bl)[8]) {
 #pragma unroll
     for (int ks = KS0; ks < KS1; ++ks) {
-        if (ks == 0) mfma_ks<true>(acc, smem, wbase, img_hi, img_lo, j, ks, bh[ks], bl[ks]);
-        else mfma_ks<false>(acc, smem, wbase, img_hi, img_lo, j, ks, bh[ks], bl[ks]);
+        if (ks == 0) mfma_ks<true, NP>(acc, smem, wbase, img_hi, img_lo, j, ks, bh[ks], bl[ks]);
+        else mfma_ks<false, NP>(acc, smem, wbase, img_hi, img_lo, j, ks, bh[ks], bl[ks]);
     }
 }
 
@@ -186,8 +192,17 @@ __device__ __forceinline__ void softplus16(f32x16& a, const unsigned char* smem,
 
 // t = a (* scale when SCALED) -> f16 pair: hi = t with the low 13 significand bits cleared (exact in f16),
 // lo = RTZ_f16(t - hi).  Registers 0..7 of the tile are the B operand of k-step 2j, 8..15 of k-step 2j+1.
-template <bool SCALED>
+template <bool SCALED, bool HI_ONLY = false>
 __device__ __forceinline__ void split16(const f32x16& a, float scale, unsigned mask, f16x8& bh0, f16x8& bh1, f16x8& bl0, f16x8& bl1) {
+    if (HI_ONLY) {                                          // activations as single f16, round to nearest even
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            f16x8& dh = (p < 4) ? bh0 : bh1;
+            dh[2 * (p & 3)] = (_Float16)(SCALED ? a[2 * p] * scale : a[2 * p]);
+            dh[2 * (p & 3) + 1] = (_Float16)(SCALED ? a[2 * p + 1] * scale : a[2 * p + 1]);
+        }
+        return;
+    }
     f32x16 t, hi;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t[i] = SCALED ? a[i] * scale : a[i];
@@ -212,15 +227,16 @@ __device__ __forceinline__ void split16(const f32x16& a, float scale, unsigned m
 
 // ---- one activation tile as a numbered list of single VALU instructions -------------------------------------------
 // Stages of element e (16 per tile): 0 a*=g''  1 a*=m2 (SCALE)  2 exp2  3 +1  4 log2  5 ss+=a^2
-//   SPLIT: 6 hi=a&mask  7 a-=hi  8 cvt(hi pair) (odd e)  9 cvt(lo pair) (odd e)      EPS: 6..6+F-1 ea[f]+=w4*a
+//   split hi+lo: 6 hi=a&mask  7 a-=hi  8 cvt(hi pair) (odd e)  9 cvt(lo pair) (odd e);  hi only: 6 cvt_rne(pair) (odd e)
+//   EPS: 6..6+F-1 ea[f]+=w4*a
 // The list is ordered by diagonals over (stage, quad of 4 elements), the cells of a diagonal interleaved element by
 // element: consecutive instructions are independent, one element's chain advances once per diagonal (>= 4
 // instructions apart), exps and logs are spread out.  It is cut into chunks of equal issue cost (plain 4 cycles,
 // transcendental 8); chunk g is issued right behind MFMA g of the tile being multiplied, starting at MFMA `SKIP`
 // (the first operands are the results of the MFMAs issued just before the segment, ~64 cycles away).
-template <bool SCALE, bool SPLIT, int NEPS, int NM>
+template <bool SCALE, int SPL, int NEPS, int NM>       // SPL: 0 no split, 1 hi + lo, 2 hi only (one RNE cvt per pair)
 struct ActPlan {
-    static constexpr int NST = 6 + (SPLIT ? 4 : 0) + NEPS;
+    static constexpr int NST = 6 + (SPL == 1 ? 4 : (SPL == 2 ? 1 : 0)) + NEPS;
     static constexpr int MAXOPS = 16 * NST;
     static constexpr int SKIP = NM > 8 ? 2 : 0;
     int n;
@@ -236,7 +252,8 @@ struct ActPlan {
                     if (q < 0 || q > 3) continue;
                     const int e = 4 * q + i;
                     if (sg == 1 && !SCALE) continue;
-                    if (SPLIT && (sg == 8 || sg == 9) && !(e & 1)) continue;
+                    if (SPL == 1 && (sg == 8 || sg == 9) && !(e & 1)) continue;
+                    if (SPL == 2 && sg == 6 && !(e & 1)) continue;
                     st[n] = sg; el[n] = e;
                     cost[n] = (sg == 2 || sg == 4) ? 8 : 4;
                     total += cost[n];
@@ -253,9 +270,9 @@ struct ActPlan {
     }
 };
 
-template <bool SCALE, bool SPLIT, int NEPS, int NM>
+template <bool SCALE, int SPL, int NEPS, int NM>
 struct ActPlanOf {
-    static constexpr ActPlan<SCALE, SPLIT, NEPS, NM> P{};
+    static constexpr ActPlan<SCALE, SPL, NEPS, NM> P{};
 };
 
 template <int F>
@@ -285,6 +302,11 @@ __device__ __forceinline__ void act_op(ActState<F>& s) {
     else if constexpr (ST == 3) s.a[E] += 1.0f;
     else if constexpr (ST == 5) s.ss[E & 3] = __builtin_fmaf(s.a[E], s.a[E], s.ss[E & 3]);
 }
+template <int E, int F>
+__device__ __forceinline__ void cvt_op(ActState<F>& s) {     // hi-only mode: the pair (E-1, E) as two RNE halfs
+    const f16x2 c = {(_Float16)s.a[E - 1], (_Float16)s.a[E]};
+    s.ph[E >> 3][(E >> 1) & 3] = __builtin_bit_cast(unsigned, c);
+}
 template <int ST, int E, int F>
 __device__ __forceinline__ void split_op(ActState<F>& s) {
     if constexpr (ST == 6) {
@@ -303,16 +325,17 @@ __device__ __forceinline__ void split_op(ActState<F>& s) {
 
 // One woven segment: MFMAs m = 0..NM-1 of output tile `jt` (k-steps KS0.., three per k-step, then the bias k-slots
 // when BIAS) with chunk m of the activation of another tile behind each.  A operands are read two k-steps ahead.
-template <int F, int KS0, int NKS, bool BIAS, bool SCALE, bool SPLIT, bool EPS>
+template <int F, int NP, int KS0, int NKS, bool BIAS, bool SCALE, bool SPLIT, bool EPS>
 __device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, unsigned wbase, int img_hi, int img_lo, int jt,
                                       const f16x8 (&bh)[8], const f16x8 (&bl)[8], unsigned ab, const f16x8& bone,
                                       f32x16& a, unsigned grow, int ja, float m2, unsigned mask, float (&ss)[4],
                                       unsigned f_base, float (*ea)[4],
                                       f16x8* oh0, f16x8* oh1, f16x8* ol0, f16x8* ol1) {
     using LD = Lds<F>;
-    constexpr int NM = 3 * NKS + (BIAS ? 1 : 0);
+    constexpr int NM = NP * NKS + (BIAS ? 1 : 0);
     constexpr int NEPS = EPS ? F : 0;
-    using PL = ActPlanOf<SCALE, SPLIT, NEPS, NM>;
+    constexpr int SPL = SPLIT ? (NP == 3 ? 1 : 2) : 0;
+    using PL = ActPlanOf<SCALE, SPL, NEPS, NM>;
     ActState<F> s{a, {}, {}, {}, ss, ea, m2, mask, {}, {}};
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     f16x8 ah[3], al[3];                                       // ring: k-step ks lives in slot ks % 3
@@ -320,7 +343,7 @@ __device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, un
         constexpr int ks = decltype(ic)::value;
         const int off = jt * 32 * (HROW * 2) + ks * 32;
         ah[ks % 3] = LDS_H8(smem, wbase + img_hi + off);
-        al[ks % 3] = LDS_H8(smem, wbase + img_lo + off);
+        if constexpr (NP >= 2) al[ks % 3] = LDS_H8(smem, wbase + img_lo + off);
     };
     // prologue: scale rows (and eps-head rows) of the activated tile, A operands of the first two k-steps
 #pragma unroll
@@ -330,23 +353,25 @@ __device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, un
     SEG_FENCE();
     static_for<0, NM>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
-        if constexpr (g < 3 * NKS) {
-            constexpr int ks = KS0 + g / 3, ty = g % 3;
+        if constexpr (g < NP * NKS) {
+            constexpr int ks = KS0 + g / NP;
+            constexpr int ty = (NP == 3) ? g % 3 : (NP == 2 ? 2 * (g % 2) : 2);      // 0: W_lo h_hi, 1: W_hi h_lo, 2: W_hi h_hi
+            constexpr bool first = (ks == 0) && (g % NP == 0);
 #ifndef MPV_ABL_NO_LDSA
-            if constexpr (ty == 0 && g / 3 + 2 < NKS) load_a(IC<ks + 2>{});
+            if constexpr (g % NP == 0 && g / NP + 2 < NKS) load_a(IC<ks + 2>{});
 #endif
 #if defined(MPV_ABL_NO_LDSA)      // ablation: every k-step multiplies the A operands of the first one (results are wrong)
-            if constexpr (ty == 0) acc = mfma16(al[KS0 % 3], bh[ks], (ks == 0) ? zero : acc);
+            if constexpr (ty == 0) acc = mfma16(al[KS0 % 3], bh[ks], first ? zero : acc);
             else if constexpr (ty == 1) acc = mfma16(ah[KS0 % 3], bl[ks], acc);
-            else acc = mfma16(ah[KS0 % 3], bh[ks], acc);
+            else acc = mfma16(ah[KS0 % 3], bh[ks], first ? zero : acc);
 #elif defined(MPV_ABL_ONE_MFMA)     // ablation: one product per k-step (results are wrong)
             if constexpr (ty == 2) acc = mfma16(ah[ks % 3], bh[ks], (ks == 0) ? zero : acc);
 #elif defined(MPV_ABL_NO_MFMA)
             if constexpr (ty == 2 && ks == 0) acc = zero;
 #else
-            if constexpr (ty == 0) acc = mfma16(al[ks % 3], bh[ks], (ks == 0) ? zero : acc);
+            if constexpr (ty == 0) acc = mfma16(al[ks % 3], bh[ks], first ? zero : acc);
             else if constexpr (ty == 1) acc = mfma16(ah[ks % 3], bl[ks], acc);
-            else acc = mfma16(ah[ks % 3], bh[ks], acc);
+            else acc = mfma16(ah[ks % 3], bh[ks], first ? zero : acc);
 #endif
         } else {
             mfma_bias(acc, ab, bone);
@@ -360,7 +385,8 @@ __device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, un
                     s.w4[f][E >> 2] = LDS_F4(smem, f_base + (LD::W4 - LD::F32) + (f * HID + 32 * ja + 8 * (E >> 2)) * 4);
             }
             if constexpr (ST < 6) act_op<ST, E, F>(s);
-            else if constexpr (SPLIT) split_op<ST, E, F>(s);
+            else if constexpr (SPL == 1) split_op<ST, E, F>(s);
+            else if constexpr (SPL == 2) cvt_op<E, F>(s);
             else {
                 constexpr int f = ST - 6;
                 s.ea[f][E & 3] = __builtin_fmaf(s.w4[f][E >> 2][E & 3], s.a[E], s.ea[f][E & 3]);
@@ -370,7 +396,9 @@ __device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, un
     });
     if constexpr (SPLIT) {
         *oh0 = __builtin_bit_cast(f16x8, s.ph[0]); *oh1 = __builtin_bit_cast(f16x8, s.ph[1]);
-        *ol0 = __builtin_bit_cast(f16x8, s.pl[0]); *ol1 = __builtin_bit_cast(f16x8, s.pl[1]);
+        if constexpr (NP == 3) {
+            *ol0 = __builtin_bit_cast(f16x8, s.pl[0]); *ol1 = __builtin_bit_cast(f16x8, s.pl[1]);
+        }
     }
 }
 
@@ -567,7 +595,7 @@ __device__ __forceinline__ void eps_partial(const StepCtx& k, const f32x16& a, i
 // Returns `ok` = every guard passed: layer-1 inputs inside the f16 range of the input split, and for every layer
 // 1 < ||l|| < 2^13 (finite, no exp2 overflow, no all-tiny vector whose direction log2(1+e) would lose, every l and
 // the bias operand inside the f16 range).  Otherwise the kernel re-runs the step through chain_step_safe.
-template <int F>
+template <int F, int NP>
 __device__ __forceinline__ Vec<F> chain_step_fast(const StepCtx& k, int t, const Vec<F>& y, const Vec<F>& mu,
                                                   const Vec<F>& g, const Vec<F>& z, bool& ok TR_PARAMS) {
     using LD = Lds<F>;
@@ -589,40 +617,40 @@ __device__ __forceinline__ Vec<F> chain_step_fast(const StepCtx& k, int t, const
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         softplus16<false, false>(a1[j], k.smem, k.g_base, j, 1.0f, ss);
-        split16<false>(a1[j], 1.0f, k.hi_mask, Ah[2 * j], Ah[2 * j + 1], Al[2 * j], Al[2 * j + 1]);
+        split16<false, (NP < 3)>(a1[j], 1.0f, k.hi_mask, Ah[2 * j], Ah[2 * j + 1], Al[2 * j], Al[2 * j + 1]);
     }
     SEG_FENCE();
     TR(0);
     f32x16 c2[2], l3[4];
     f16x8 bone = {0, 0, 0, 0, 0, 0, 0, 0};
     // ---- layer 2 tile 0, k-steps 0..5  ||  layer-1 activation tile 3
-    woven<F, 0, 6, false, false, true, false>(c2[0], k.smem, k.a_base, LD::W2H, LD::W2L, 0, Ah, Al, 0u, bone, a1[3], k.g_base, 3,
+    woven<F, NP, 0, 6, false, false, true, false>(c2[0], k.smem, k.a_base, LD::W2H, LD::W2L, 0, Ah, Al, 0u, bone, a1[3], k.g_base, 3,
                                               1.0f, k.hi_mask, ss, k.f_base, nullptr, &Ah[6], &Ah[7], &Al[6], &Al[7]);
     TR(1);
     float nrm, inv, nlo, nhi;
     norm_fast(chain_sum(ss), nrm, inv);
     nlo = nhi = nrm;
     bone = bias_operand(nrm * k.kb2);
-    mfma_tile<6, 8>(c2[0], k.smem, k.a_base, LD::W2H, LD::W2L, 0, Ah, Al);
+    mfma_tile<6, 8, NP>(c2[0], k.smem, k.a_base, LD::W2H, LD::W2L, 0, Ah, Al);
     mfma_bias(c2[0], k.ab2[0], bone);
     TR(2);
     ss[0] = ss[1] = ss[2] = ss[3] = 0.0f;
     // ---- layer 2 tile j  ||  layer-2 activation of tile j-1
 #pragma unroll
     for (int j = 1; j < 4; ++j)
-        woven<F, 0, 8, true, true, true, false>(c2[j & 1], k.smem, k.a_base, LD::W2H, LD::W2L, j, Ah, Al, k.ab2[j], bone,
+        woven<F, NP, 0, 8, true, true, true, false>(c2[j & 1], k.smem, k.a_base, LD::W2H, LD::W2L, j, Ah, Al, k.ab2[j], bone,
                                                 c2[(j - 1) & 1], g2, j - 1, inv, k.hi_mask, ss, k.f_base, nullptr,
                                                 &Bh[2 * j - 2], &Bh[2 * j - 1], &Bl[2 * j - 2], &Bl[2 * j - 1]);
     TR(3);
     // ---- layer 3 tile 0, k-steps 0..5  ||  layer-2 activation tile 3
-    woven<F, 0, 6, false, true, true, false>(l3[0], k.smem, k.a_base3, 0, W3REL, 0, Bh, Bl, 0u, bone, c2[1], g2, 3, inv,
+    woven<F, NP, 0, 6, false, true, true, false>(l3[0], k.smem, k.a_base3, 0, W3REL, 0, Bh, Bl, 0u, bone, c2[1], g2, 3, inv,
                                              k.hi_mask, ss, k.f_base, nullptr, &Bh[6], &Bh[7], &Bl[6], &Bl[7]);
     TR(4);
     norm_fast(chain_sum(ss), nrm, inv);
     nlo = fminf(nlo, nrm);
     nhi = fmaxf(nhi, nrm);
     bone = bias_operand(nrm * k.kb3);
-    mfma_tile<6, 8>(l3[0], k.smem, k.a_base3, 0, W3REL, 0, Bh, Bl);
+    mfma_tile<6, 8, NP>(l3[0], k.smem, k.a_base3, 0, W3REL, 0, Bh, Bl);
     mfma_bias(l3[0], k.ab3[0], bone);
     TR(5);
     ss[0] = ss[1] = ss[2] = ss[3] = 0.0f;
@@ -634,7 +662,7 @@ __device__ __forceinline__ Vec<F> chain_step_fast(const StepCtx& k, int t, const
     // ---- layer 3 tile j  ||  layer-3 activation (and eps-head partial sums) of tile j-1
 #pragma unroll
     for (int j = 1; j < 4; ++j)
-        woven<F, 0, 8, true, true, false, true>(l3[j], k.smem, k.a_base3, 0, W3REL, j, Bh, Bl, k.ab3[j], bone, l3[j - 1], g3,
+        woven<F, NP, 0, 8, true, true, false, true>(l3[j], k.smem, k.a_base3, 0, W3REL, j, Bh, Bl, k.ab3[j], bone, l3[j - 1], g3,
                                                 j - 1, inv, k.hi_mask, ss, k.f_base, ea, nullptr, nullptr, nullptr, nullptr);
     TR(6);
     softplus16<false, true>(l3[3], k.smem, g3, 3, inv, ss);
@@ -702,7 +730,7 @@ __device__ __noinline__ Vec<F> chain_step_safe(StepCtx k, int t, Vec<F> y, Vec<F
     return heads_posterior<F>(k, t, a, ea, inv, y, mu, g, z);
 }
 
-template <int F, bool PHILOX>
+template <int F, bool PHILOX, int NP>
 __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using LD = Lds<F>;
@@ -836,7 +864,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
 #endif
             bool ok = true;
             TR(9);
-            Vec<F> yn = chain_step_fast<F>(k, t, y, mu, g, zv, ok TR_ARGS);
+            Vec<F> yn = chain_step_fast<F, NP>(k, t, y, mu, g, zv, ok TR_ARGS);
             if (__builtin_expect(!__all(ok), 0)) yn = chain_step_safe<F>(k, t, y, mu, g, zv);
             y = yn;
             if (t > 0 && lane < 32) {                       // all reads of this step's rows are done (same wave, in order)
@@ -868,10 +896,10 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
 }
 
 // (trace) every wave: its lifetime in 100 MHz ticks -> min in [10], max in [15]
-template <int F>
+template <int F, int NP>
 int launch_f16_f(mpv_ctx* ctx, const ChainArgs& a, bool philox, int grid) {
-    auto kp = nsdiff_chain_f16_kernel<F, true>;
-    auto kn = nsdiff_chain_f16_kernel<F, false>;
+    auto kp = nsdiff_chain_f16_kernel<F, true, NP>;
+    auto kn = nsdiff_chain_f16_kernel<F, false, NP>;
     constexpr int lds = Lds<F>::BYTES;
     if ((size_t)lds > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "device LDS too small for the resident-weight chain kernel");
     MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(philox ? kp : kn),
@@ -898,11 +926,18 @@ extern "C" int mpv_debug_trace(unsigned long long* out16, int reset) {
 }
 #endif
 
-int launch_chain_f16(mpv_ctx* ctx, const chain::ChainArgs& a, bool philox, int grid, int nf) {
-    switch (nf) {
-        case 1: return launch_f16_f<1>(ctx, a, philox, grid);
-        case 2: return launch_f16_f<2>(ctx, a, philox, grid);
-        case 3: return launch_f16_f<3>(ctx, a, philox, grid);
-        default: return mpv_fail(ctx, MPV_EINVAL, "the f16x3 sampler supports nf 1..3 (use MPV_GEMM_F32 for nf = 4)");
+int launch_chain_f16(mpv_ctx* ctx, const chain::ChainArgs& a, bool philox, int grid, int nf, int products) {
+    if (nf < 1 || nf > 3) return mpv_fail(ctx, MPV_EINVAL, "the split-f16 sampler supports nf 1..3 (use MPV_GEMM_F32 for nf = 4)");
+    switch (nf * 10 + products) {
+        case 13: return launch_f16_f<1, 3>(ctx, a, philox, grid);
+        case 23: return launch_f16_f<2, 3>(ctx, a, philox, grid);
+        case 33: return launch_f16_f<3, 3>(ctx, a, philox, grid);
+        case 12: return launch_f16_f<1, 2>(ctx, a, philox, grid);
+        case 22: return launch_f16_f<2, 2>(ctx, a, philox, grid);
+        case 32: return launch_f16_f<3, 2>(ctx, a, philox, grid);
+        case 11: return launch_f16_f<1, 1>(ctx, a, philox, grid);
+        case 21: return launch_f16_f<2, 1>(ctx, a, philox, grid);
+        case 31: return launch_f16_f<3, 1>(ctx, a, philox, grid);
+        default: return mpv_fail(ctx, MPV_EINVAL, "bad product count");
     }
 }

@@ -58,7 +58,8 @@ class _NsDiffBase(nn.Module):
         self.configs = SimpleNamespace(**net_param)
         self.scaler = net_param["scaler_type"]
         self.noise_source = net_param.get("noise_source", "philox")
-        self.gemm_mode = net_param.get("gemm_mode", "f16x3")     # "f16x3" (split-f16 matrix cores) | "f32" (exact)
+        # "f16x3" (split-f16 matrix cores, fp32-equivalent) | "f32" (exact) | "f16x2" / "f16" (reduced-precision operands)
+        self.gemm_mode = net_param.get("gemm_mode", "f16x3")
         if self.noise_source not in ("philox", "torch_cpu"):
             raise ValueError("noise_source must be 'philox' or 'torch_cpu'")
         self.register_buffer("scaler_mean", torch.zeros(self.dataset_nf))
