@@ -12,12 +12,6 @@ constexpr int WROW = 132;  // padded LDS row stride in floats: (33*i) mod 16 dis
 #ifndef MPV_WAVES
 #define MPV_WAVES 8
 #endif
-#ifndef MPV_PRIO_MFMA      // experiment: s_setprio value held during the MFMA layers (-1 = leave alone)
-#define MPV_PRIO_MFMA -1
-#endif
-#ifndef MPV_STAGGER        // experiment: delay the second half of the workgroup's waves once, in s_sleep(127) units
-#define MPV_STAGGER 0
-#endif
 constexpr int WAVES = MPV_WAVES;
 constexpr int THREADS = WAVES * 64;
 constexpr int TILE = 32;   // chains per wave

@@ -130,9 +130,6 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_kernel(const 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r_lane = lane & 31, h_lane = lane >> 5;
-    if (MPV_STAGGER > 0 && __builtin_amdgcn_readfirstlane(wave) >= WAVES / 2) {
-        for (int i = 0; i < MPV_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
 
     for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < p.n_tiles; tile += (long long)gridDim.x * WAVES) {
         const long long n_raw = tile * TILE + r_lane;
@@ -206,13 +203,9 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_kernel(const 
             }
             activate<!TMDM>(hv, p.e1 + (long long)t * HID, h);
             // ---- layers 2, 3 on the fp32 matrix pipe ---------------------------------------
-            if (MPV_PRIO_MFMA >= 0) __builtin_amdgcn_s_setprio(MPV_PRIO_MFMA);
             mfma_layer(lds + L_W2, lds + L_B2, hv, r, h);
-            if (MPV_PRIO_MFMA >= 0) __builtin_amdgcn_s_setprio(MPV_PRIO_MFMA ? 0 : 3);
             activate<!TMDM>(hv, p.e2 + (long long)t * HID, h);
-            if (MPV_PRIO_MFMA >= 0) __builtin_amdgcn_s_setprio(MPV_PRIO_MFMA);
             mfma_layer(lds + L_W3, lds + L_B3, hv, r, h);
-            if (MPV_PRIO_MFMA >= 0) __builtin_amdgcn_s_setprio(MPV_PRIO_MFMA ? 0 : 3);
             activate<!TMDM>(hv, p.e3 + (long long)t * HID, h);
             // ---- heads: eps = W4 h + b4 ; sigma = softplus(Ws softplus(h) + bs) --------------
             float ea[F], sa[F];

@@ -1,17 +1,20 @@
 // NsDiff chain, split-f16 matrix-core variant for gfx950 (the default sampler).
 //
-// Two measured facts about gfx950 shape this kernel (tools/ubench/):
-//  1. v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate and excludes the VALU while it executes, so an
-//     exact-fp32 kernel (nsdiff_chain.hip) is bound by MFMA + VALU in series.  The f16 matrix pipe is 16x
-//     faster and runs beside the VALU, so the 128x128 layers are evaluated as
+// Measured facts about gfx950 that shape this kernel (tools/ubench/):
+//  1. v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate and excludes the VALU while it executes (the exact kernel,
+//     nsdiff_chain.hip, is MFMA + VALU in series).  The f16 matrix pipe is 16x faster, so the 128x128 layers are
 //          W h  =  W_hi h_hi + W_hi h_lo + W_lo h_hi        (three v_mfma_f32_32x32x16_f16, fp32 accumulate)
-//     with x = x_hi + x_lo a two-term fp16 split of the power-of-two-scaled fp32 value (>= 21 significand
-//     bits kept; the dropped lo*lo term is 2^-21 relative): ~1e-6 relative on the samples.
-//  2. A loop body of 16 KB or more is instruction-FETCH bound: it streams at 2 bytes/clk per SIMD (4 cycles
-//     per 8-byte instruction) instead of 2.3 cycles per VALU instruction below 16 KB (ifetch.hip).  The step
-//     loop is therefore written for code SIZE: layer 1 (K = 3F) and every bias ride on the matrix pipe as extra
-//     k-slots, elementwise work uses 4-byte encodings, LDS addresses are base+immediate, and every rarely
-//     needed guard lives in a cold block outside the hot path.
+//     with x = x_hi + x_lo a two-term fp16 split of the fp32 value (>= 21 significand bits kept; the dropped
+//     lo*lo term is 2^-21 relative): ~1e-6 relative on the samples.  Template parameter NP keeps 3, 2 or 1 of the
+//     products (MPV_GEMM_F16X3 / F16X2 / F16; the last two are reduced-precision operand modes).
+//  2. The binding resource is vector-instruction ISSUE: an MFMA holds the issue port 8 of its 32 cycles, a plain VALU
+//     instruction beside MFMAs costs 4, v_exp/v_log 8, and only the SAME wave's instructions fill an MFMA's shadow.
+//     Each layer is therefore software-pipelined by output tile (woven<>): MFMAs of tile j+1 with the activation
+//     of tile j woven behind them, which requires deferring F.normalize into the next layer (see "building blocks").
+//  3. A loop body of 16 KB or more is instruction-FETCH bound (2 bytes/clk per SIMD, ifetch.hip).  The step loop is
+//     written for code SIZE: layer 1 (K = 3F) and every bias ride on the matrix pipe as extra k-slots, elementwise
+//     work uses 4-byte encodings, LDS addresses are base+immediate, per-feature tails and every rarely needed guard
+//     live out of line.
 //
 // Data flow as in nsdiff_chain.hip: a wave owns 32 chains and activations never change lanes.  For
 // v_mfma_f32_32x32x16_f16 the B operand of k-step ks is eight f16 per lane; with k-steps enumerated as
@@ -40,7 +43,6 @@ constexpr int IMG = HID * HROW * 2;             // bytes of one [128][136] image
 constexpr float LOG2E = 1.44269504088896341f;
 constexpr float HALF_LOG2E = 0.72134752044448170f;
 constexpr float LN2 = 0.693147180559945309f;
-constexpr float X1_LIMIT = 11.0f;               // fast layer-1 softplus while |x'| < 11 (|x| < 7.6)
 constexpr float IN_LIMIT = 2048.0f;             // fast layer 1 while every |input| < 2^11 (f16 range after 2^4 scaling)
 
 // layer 1 as k-slots of one (F=1) or two (F=2,3) MFMAs: 3F x (W_hi x_hi), 3F x (W_hi x_lo), 3F x (W_lo x_hi),
@@ -61,13 +63,6 @@ template <int F> struct Lds {                   // byte offsets
     static constexpr int BYTES = GAM + WAVES * 3 * HID * 4;
     static_assert(BYTES <= 160 * 1024, "LDS budget");
 };
-
-// Pass boundaries: left to the scheduler by default (measured 5 % faster than hard fences); -DMPV_HARD_FENCE pins them.
-#ifdef MPV_HARD_FENCE
-#define MPV_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define MPV_FENCE()
-#endif
 
 // All LDS reads go through `smem + 32-bit offset`: the opaque per-step copies of the base OFFSETS keep the
 // loads inside the step loop without turning the pointers into generic (flat) ones.
@@ -858,10 +853,6 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
             }
 #pragma unroll
             for (int f = 0; f < F; ++f) zv.v[f] = z[f];
-#ifdef MPV_PAD_NOPS    // experiment: grow the hot loop by 4*MPV_PAD_NOPS bytes to probe the 16 KB instruction-fetch cliff
-#pragma unroll
-            for (int i = 0; i < MPV_PAD_NOPS; ++i) asm volatile("s_nop 0");
-#endif
             bool ok = true;
             TR(9);
             Vec<F> yn = chain_step_fast<F, NP>(k, t, y, mu, g, zv, ok TR_ARGS);
