@@ -164,6 +164,25 @@ def test_evaluation_step_real_checkpoint(golden_cases, ckpt_wofx, gemm):
 
 
 @pytest.mark.parametrize("gemm", ["f16x3", "f32", "f16x2", "f16"])
+def test_evaluation_step_second_real_checkpoint_against_oracle(ckpt_sim, gemm):
+    """The other shipped sampler checkpoint (real_data/model/simulation: F=1, windows=pred_len=200, rolling 50, T=20,
+    trained weights) against the pinned oracle on shared noise, 3 rows x 4 samples in 2 chunks; MPV too."""
+    model = _variant_model(ckpt_sim, "cond_var", 1, 20, 200, 200, 50, 4, 2, gemm=gemm)
+    cfg = O.NsDiffConfig(200, 200, 1, 50, 20, n_z_samples=4, parallel_sample=2)
+    g = torch.Generator().manual_seed(31)
+    batch = torch.cumsum(torch.randn(3, 200, 1, generator=g) * 0.1, dim=1)
+    rec = []
+    torch.manual_seed(5)
+    want = O.evaluation_step(ckpt_sim, cfg, batch, record=rec)
+    outs, _ = model.evaluation_step(batch, noise=torch.cat([z.reshape(-1) for z in rec]))
+    err = rel_err(outs, want)
+    mpv_w = want.var(dim=-1, unbiased=False).mean()
+    mpv_g = outs.var(dim=-1, unbiased=False).mean()
+    print("evaluation_step simulation ckpt [%s] rel err %.3e, MPV rel err %.3e" % (gemm, err, abs(mpv_g - mpv_w) / mpv_w))
+    assert err < RTOL and abs(mpv_g - mpv_w) / mpv_w < RTOL
+
+
+@pytest.mark.parametrize("gemm", ["f16x3", "f32", "f16x2", "f16"])
 def test_evaluation_step_seeded_and_torch_cpu_noise_stream(golden_cases, gemm):
     """Reduced C2 shape; noise_source='torch_cpu' + the reference's seed == the reference run."""
     sd = O.random_state_dict(1, 50, 100, 100, 50, seed=123)
