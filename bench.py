@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--gemm", choices=("f16x3", "f32", "f16x2", "f16"), default="f16x3",
                     help="evaluation of the two 128x128 layers for the HEADLINE number: split-f16 matrix cores, fp32-equivalent "
                          "(default), exact fp32 MFMA, or the reduced-precision operand modes f16x2 / f16 (fp32 accumulate)")
+    ap.add_argument("--host-data", action="store_true",
+                    help="generate the synthetic trajectory with the numpy Euler-Maruyama on the host instead of the HIP kernel")
     ap.add_argument("--no-other-modes", action="store_true",
                     help="skip the extra, separately reported runs of the reduced-precision operand modes (N=1 only)")
     ap.add_argument("--max-windows", type=int, default=None, help="profiling aid: cut the trajectory to this many windows "
@@ -105,10 +107,20 @@ def main():
 
     # ---- inputs, resident before timing -------------------------------------------------
     log("rank %d/%d on %s: generating trajectory" % (rank, world, device))
-    record = synthetic.biomass_trajectory(CFG["nodes"], CFG["ticks"], seed=1000 + rank)
-    full = H.normalize_time_series(record["ys_dynamic"], dynamic_type="biomass")           # [V, ticks, 1]
-    sampled, _ = H.sample_time_series(full, record["ts_dynamic"], CFG["sampling_t"])        # [V, 1000, 1]
-    sampled = sampled.contiguous()
+    stride = H.sampling_interval_from_t(CFG["sampling_t"])
+    if args.host_data:
+        record = synthetic.biomass_trajectory(CFG["nodes"], CFG["ticks"], seed=1000 + rank)
+        full = H.normalize_time_series(record["ys_dynamic"], dynamic_type="biomass")       # [V, ticks, 1]
+        sampled, _ = H.sample_time_series(full, record["ts_dynamic"], CFG["sampling_t"])    # [V, 1000, 1]
+        sampled = sampled.contiguous()
+    else:                                       # Euler-Maruyama on device, sub-sampling fused (csrc/biomass_sim.hip)
+        from mpv_amd import _native
+        t_gen = time.perf_counter()
+        gen_ctx = _native.Context(device)
+        series_gen, _ = synthetic.biomass_trajectory_device(gen_ctx, CFG["nodes"], CFG["ticks"], seed=1000 + rank, sampling_stride=stride)
+        sampled = series_gen.cpu().contiguous()
+        log("device trajectory: %d ticks x %d nodes in %.3f s" % (CFG["ticks"], CFG["nodes"], time.perf_counter() - t_gen))
+        gen_ctx.close()
     n_windows = H.sliding_window_count(sampled.shape[1], CFG["windows"], CFG["window_step"])
     if args.max_windows is not None:
         n_windows = min(n_windows, args.max_windows)

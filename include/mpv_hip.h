@@ -172,6 +172,25 @@ int mpv_nsdiff_preact_bound(mpv_ctx* ctx, float* bound);
 int mpv_tmdm_load(mpv_ctx* ctx, const mpv_nsdiff_desc* desc, const mpv_nsdiff_weights* host_weights, const float* host_coef);
 int mpv_tmdm_sample(mpv_ctx* ctx, const mpv_sample_shape* shape, const float* y0hat, const float* noise, float* samples);
 
+/* ------------------------------------------------------------------------------------
+ * Synthetic input generation on device (the step before the path)
+ * replaces: the harvested-biomass network simulator dataset/spdata_sde_biomass_dynamic_gene.py:53-68 (drift f, noise g;
+ *           there integrated by torchsde) + normalize_time_series / sample_time_series of the harness
+ *           (diffusion_model_uncertainy.py:106-134): Euler-Maruyama with step dt, burn_ticks at eps_start, then `ticks`
+ *           recorded ticks along a linear ramp eps_start -> eps_end; every `stride`-th recorded tick is stored.
+ * row_ptr / col_idx: dev CSR adjacency of the undirected graph (int32, [nodes+1] / [nnz]); x0 dev [n_traj][nodes];
+ * series_out dev [n_traj][nodes][ceil(ticks/stride)] = the harness's resident layout [V][L][F=1].
+ * Normal of (trajectory, node, tick) = element tick&3 of Philox block (chain = traj*nodes + node, k = tick>>2), the
+ * generator of mpv_nsdiff_philox_normals with offset 0.  nodes <= 1024.
+ * ---------------------------------------------------------------------------------- */
+typedef struct mpv_biomass_desc {
+    int32_t n_trajectories, nodes, ticks, burn_ticks, stride;
+    float r, k, d, eta, dt, eps_start, eps_end;
+    uint64_t seed;
+} mpv_biomass_desc;
+int mpv_biomass_simulate(mpv_ctx* ctx, const mpv_biomass_desc* desc, const int32_t* row_ptr, const int32_t* col_idx,
+                         const float* x0, float* series_out);
+
 /* Debug/validation helper: write the Philox normals mpv_nsdiff_sample would consume, in the
  * dense layout [n_chains][T][F] (chain-major), so a CPU checker can replay them. */
 int mpv_nsdiff_philox_normals(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out_dev);

@@ -1,0 +1,51 @@
+"""CPU restatement of the on-device biomass Euler-Maruyama generator (TEST INFRASTRUCTURE ONLY).
+
+Follows csrc/biomass_sim.hip operation by operation in float32 (drift terms of the reference simulator
+dataset/spdata_sde_biomass_dynamic_gene.py:53-68, noise from oracle/philox.py with the device keying), so the HIP
+trajectory can be compared tick by tick.  Parity status: UNPINNED against the reference simulator (it integrates with
+the absent torchsde package and a different random stream); pinned only as "the same arithmetic as the kernel".
+"""
+import numpy as np
+
+from . import philox as PH
+
+
+def csr(adj: np.ndarray):
+    rows, cols = np.nonzero(adj)
+    row_ptr = np.zeros(adj.shape[0] + 1, dtype=np.int32)
+    np.add.at(row_ptr, rows + 1, 1)
+    return np.cumsum(row_ptr).astype(np.int32), cols.astype(np.int32)
+
+
+def simulate(adj: np.ndarray, x0: np.ndarray, ticks: int, burn_ticks: int, stride: int, r, k, d, eta, dt, eps_start, eps_end,
+             seed: int) -> np.ndarray:
+    """-> [V, ceil(ticks/stride)] float32, trajectory 0 of mpv_biomass_simulate."""
+    f = np.float32
+    V = adj.shape[0]
+    row_ptr, col = csr(adj)
+    total = burn_ticks + ticks
+    z = PH.normals(seed, 0, V, total, 1)[:, :, 0]                       # [V, total]
+    x = x0.astype(f).copy()
+    xc = np.maximum(x, f(0))
+    out = np.empty((V, (ticks + stride - 1) // stride), dtype=f)
+    eps_step = f((f(eps_end) - f(eps_start)) / f(ticks - 1)) if ticks > 1 else f(0)
+    noise_scale = f(f(eta) * np.sqrt(f(dt)))
+    deg = (row_ptr[1:] - row_ptr[:-1]).astype(f)
+    r, k, d, dt = f(r), f(k), f(d), f(dt)
+    for t in range(total):
+        i = t - burn_ticks
+        eps = f(eps_start) if i < 0 else f(f(eps_start) + f(f(i) * eps_step))
+        ax = np.zeros(V, dtype=f)
+        for n in range(V):
+            s = f(0)
+            for j in range(row_ptr[n], row_ptr[n + 1]):
+                s = f(s + xc[col[j]])
+            ax[n] = s
+        logistic = f(r * xc) * (f(1) - xc / k)
+        harvest = f(eps * xc) * xc / (xc * xc + f(1))
+        drift = (logistic - harvest) + d * (ax - deg * xc)
+        x = (x + drift * dt) + noise_scale * z[:, t]
+        xc = np.maximum(x, f(0))
+        if i >= 0 and i % stride == 0:
+            out[:, i // stride] = x
+    return out

@@ -25,6 +25,7 @@ EXPORTS = (
     "mpv_abi_version", "mpv_ctx_create", "mpv_ctx_destroy", "mpv_ctx_set_stream", "mpv_last_error",
     "mpv_nsdiff_load", "mpv_nsdiff_sample", "mpv_nsdiff_preact_bound", "mpv_nsdiff_philox_normals", "mpv_sigma_load", "mpv_sigma_head",
     "mpv_reduce", "mpv_chain_timing", "mpv_chain_timing_enable", "mpv_tmdm_load", "mpv_tmdm_sample",
+    "mpv_biomass_simulate",
 )
 
 
@@ -58,6 +59,12 @@ class SigmaWeights(C.Structure):
     _fields_ = [(n, _F) for n in ("w0", "b0", "ln0_w", "ln0_b", "w1", "b1", "ln1_w", "ln1_b", "w2", "b2")]
 
 
+class BiomassDesc(C.Structure):
+    _fields_ = [("n_trajectories", C.c_int32), ("nodes", C.c_int32), ("ticks", C.c_int32), ("burn_ticks", C.c_int32),
+                ("stride", C.c_int32), ("r", C.c_float), ("k", C.c_float), ("d", C.c_float), ("eta", C.c_float),
+                ("dt", C.c_float), ("eps_start", C.c_float), ("eps_end", C.c_float), ("seed", C.c_uint64)]
+
+
 _lib = None
 
 
@@ -84,6 +91,7 @@ def load_library():
         "mpv_nsdiff_sample": (C.c_int, [vp, C.POINTER(SampleShape), vp, vp, vp, vp]),
         "mpv_tmdm_load": (C.c_int, [vp, C.POINTER(NsdiffDesc), C.POINTER(NsdiffWeights), _F]),
         "mpv_tmdm_sample": (C.c_int, [vp, C.POINTER(SampleShape), vp, vp, vp]),
+        "mpv_biomass_simulate": (C.c_int, [vp, C.POINTER(BiomassDesc), vp, vp, vp, vp]),
         "mpv_nsdiff_philox_normals": (C.c_int, [vp, u64, u64, i64, vp]),
         "mpv_nsdiff_preact_bound": (C.c_int, [vp, C.POINTER(C.c_float)]),
         "mpv_sigma_load": (C.c_int, [vp, C.POINTER(SigmaDesc), C.POINTER(SigmaWeights)]),
@@ -271,6 +279,26 @@ class Context:
         self._check(self.lib.mpv_tmdm_sample(self._h, C.byref(shape), _dev_ptr(y0hat, self.device, "y0hat"),
                                              _dev_ptr(noise, self.device, "noise"),
                                              _dev_ptr(out, self.device, "samples")), "mpv_tmdm_sample")
+        return out
+
+    # ---- synthetic input generation ---------------------------------------------------
+    def biomass_simulate(self, row_ptr: torch.Tensor, col_idx: torch.Tensor, x0: torch.Tensor, ticks: int, burn_ticks: int,
+                         stride: int, r: float, k: float, d: float, eta: float, dt: float, eps_start: float, eps_end: float,
+                         seed: int) -> torch.Tensor:
+        """CSR graph (int32, on device), x0 [n_traj, V] -> sub-sampled trajectories [n_traj, V, ceil(ticks/stride), 1]."""
+        for name, t in (("row_ptr", row_ptr), ("col_idx", col_idx)):
+            if t.device != self.device or t.dtype != torch.int32 or not t.is_contiguous():
+                raise MpvError("{} must be a contiguous int32 tensor on {}".format(name, self.device))
+        n_traj, V = x0.shape
+        if row_ptr.numel() != V + 1:
+            raise MpvError("row_ptr has {} entries, expected nodes + 1 = {}".format(row_ptr.numel(), V + 1))
+        L = (ticks + stride - 1) // stride
+        out = torch.empty((n_traj, V, L, 1), device=self.device, dtype=torch.float32)
+        desc = BiomassDesc(n_traj, V, ticks, burn_ticks, stride, r, k, d, eta, dt, eps_start, eps_end, seed & (2 ** 64 - 1))
+        self._bind_stream()
+        self._check(self.lib.mpv_biomass_simulate(self._h, C.byref(desc), C.c_void_p(row_ptr.data_ptr()),
+                                                  C.c_void_p(col_idx.data_ptr()), _dev_ptr(x0, self.device, "x0"),
+                                                  _dev_ptr(out, self.device, "series_out")), "mpv_biomass_simulate")
         return out
 
     def preact_bound(self) -> float:

@@ -13,7 +13,7 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
-SOURCES = ["mpv_api.hip", "nsdiff_chain.hip", "nsdiff_chain_f16.hip", "sigma_head.hip", "mpv_reduce.hip"]
+SOURCES = ["mpv_api.hip", "nsdiff_chain.hip", "nsdiff_chain_f16.hip", "sigma_head.hip", "mpv_reduce.hip", "biomass_sim.hip"]
 LIB = PKG / "libmpv_hip.so"
 
 

@@ -335,6 +335,17 @@ int mpv_tmdm_sample(mpv_ctx* ctx, const mpv_sample_shape* s, const float* y0hat,
     return launch_tmdm_chain(ctx, *s, y0hat, noise, samples);
 }
 
+int mpv_biomass_simulate(mpv_ctx* ctx, const mpv_biomass_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const float* x0,
+                         float* series_out) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_biomass_simulate: ctx is NULL");
+    if (!d || !row_ptr || !x0 || !series_out) return mpv_fail(ctx, MPV_EINVAL, "mpv_biomass_simulate: NULL argument");
+    if (d->n_trajectories < 1 || d->nodes < 1 || d->nodes > 1024 || d->ticks < 1 || d->burn_ticks < 0 || d->stride < 1)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_biomass_simulate: need n_trajectories >= 1, 1 <= nodes <= 1024, ticks >= 1, burn_ticks >= 0, stride >= 1");
+    if (!(d->dt > 0.0f) || !(d->k != 0.0f)) return mpv_fail(ctx, MPV_EINVAL, "mpv_biomass_simulate: need dt > 0 and k != 0");
+    DeviceGuard g(ctx->device);
+    return launch_biomass_sim(ctx, *d, row_ptr, col_idx, x0, series_out);
+}
+
 int mpv_nsdiff_preact_bound(mpv_ctx* ctx, float* bound) {
     if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nsdiff_preact_bound: ctx is NULL");
     if (!ctx->ns.loaded) return mpv_fail(ctx, MPV_ESTATE, "mpv_nsdiff_preact_bound: call mpv_nsdiff_load first");

@@ -60,6 +60,29 @@ def biomass_trajectory(nodes: int = 100, ticks: int = 100_000, seed: int = 0, r:
             "tp_values": torch.from_numpy(ramp.astype(np.float32))}
 
 
+def adjacency_csr(adj: np.ndarray):
+    """Dense 0/1 adjacency -> (row_ptr [V+1], col_idx [nnz]) int32, neighbours in increasing order."""
+    rows, cols = np.nonzero(adj)
+    row_ptr = np.zeros(adj.shape[0] + 1, dtype=np.int64)
+    np.add.at(row_ptr, rows + 1, 1)
+    return np.cumsum(row_ptr).astype(np.int32), cols.astype(np.int32)
+
+
+def biomass_trajectory_device(ctx, nodes: int = 100, ticks: int = 100_000, seed: int = 0, sampling_stride: int = 1,
+                              r: float = 0.7, k: float = 10.0, d: float = 0.5, eta: float = 0.005, dt: float = 0.1,
+                              burn_ticks: int = 1000, eps_start: float = 0.0, eps_end: float = 2.7, m: int = 3):
+    """Same model and parameters as `biomass_trajectory`, integrated by the HIP kernel csrc/biomass_sim.hip with the
+    sampler's Philox stream; only every `sampling_stride`-th tick is stored, directly as the harness's resident
+    series.  -> (series [V, L, 1] on ctx.device, sampled time stamps [L] numpy)."""
+    adj = ba_graph(nodes, m=m, seed=seed)
+    row_ptr, col_idx = adjacency_csr(adj)
+    x0 = np.random.default_rng(seed).uniform(0.0, 1.0, nodes).astype(np.float32)
+    series = ctx.biomass_simulate(torch.from_numpy(row_ptr).to(ctx.device), torch.from_numpy(col_idx).to(ctx.device),
+                                  torch.from_numpy(x0).to(ctx.device).unsqueeze(0), ticks, burn_ticks, sampling_stride,
+                                  r, k, d, eta, dt, eps_start, eps_end, seed)
+    return series[0], (np.arange(ticks, dtype=np.float32) * np.float32(dt))[::sampling_stride]
+
+
 def slbp_like_series(ticks: int = 50_000, seed: int = 0, dt: float = 0.1):
     rng = np.random.default_rng(seed)
     t = np.arange(ticks) * dt
