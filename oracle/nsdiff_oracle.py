@@ -282,7 +282,7 @@ class NsDiffConfig:
     steps: int
     n_z_samples: int
     parallel_sample: int
-    variant: str = "cond_var"      # cond_var | Guassian (sic) | NsDiff_model (needs y0hat)
+    variant: str = "cond_var"      # cond_var | Guassian (sic) | with y0hat supplied: cond_mean | wo_UANS | NsDiff_model
     schedule: str = "linear"
     beta_start: float = 1e-4
     beta_end: float = 0.02
@@ -310,8 +310,8 @@ def evaluation_step(sd, cfg: NsDiffConfig, batch: torch.Tensor, noise: Optional[
         y0hat = torch.zeros(B, cfg.pred_len, x.shape[2])                 # :442-446
     elif y0hat is None:
         raise ValueError("variant {!r} needs y0hat = f(x) supplied".format(cfg.variant))
-    if cfg.variant == "Guassian":
-        gx = torch.ones(B, cfg.pred_len, x.shape[2])                      # :457-458
+    if cfg.variant in ("Guassian", "cond_mean"):
+        gx = torch.ones(B, cfg.pred_len, x.shape[2])                      # :457-458 (no sigma head: :296-303)
     elif cfg.variant == "NsDiff_model":
         gx = sigma_head(sd, x, cfg.rolling, cfg.pred_len)                 # :223 (no +EPS)
     else:

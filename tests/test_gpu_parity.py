@@ -370,6 +370,47 @@ def test_philox_default_mode_statistics_and_repeatability(ckpt_wofx):
     assert abs(a.mean().item() - d.mean().item()) < 0.05 * d.std().item()
 
 
+@pytest.mark.parametrize("select", ["wo_UANS", "cond_mean", "NsDiff_model"])
+def test_attached_backbone_variants_match_oracle(ckpt_wofx, select):
+    """The f(x)-using selects with a caller-supplied backbone: y_0_hat comes from the attached torch module, the rest
+    (sigma head with/without EPS or gx = 1, sampler around y_0_hat) is native and equals the oracle on shared noise."""
+    from mpv_amd.models.models import diffusion_models
+
+    class Backbone(torch.nn.Module):                       # stand-in f(x): any module with the reference's signature
+        def __init__(self):
+            super().__init__()
+            self.mix = torch.nn.Linear(200 + 300, 200, bias=True)
+
+        def forward(self, x, dec_inp):
+            z = torch.cat([x, dec_inp], dim=1).transpose(1, 2)              # [B, F, 500]
+            return torch.tanh(self.mix(z)).transpose(1, 2) * 0.3, None
+
+    torch.manual_seed(3)
+    f = Backbone()
+    net = dict(device=dev(), scaler_type="StandardScaler", task_model="x", rolling_length=100, diffusion_schedule="linear",
+               diffusion_steps=20, beta_start=1e-4, beta_end=0.02, n_z_samples=4, parallel_sample=2, windows=200, pred_len=200,
+               dataset_nf=2, load_pretrain=False)
+    task = "NsDiff" if select == "NsDiff_model" else "NsDiff_model_variants"
+    m = diffusion_models(task, net, train_model_select=select).to(dev())
+    own = set(m.state_dict())
+    m.load_state_dict({k: v for k, v in ckpt_wofx.items() if k in own})
+    m.attach_backbone(f.to(dev())).eval()
+    g = torch.Generator().manual_seed(8)
+    batch = torch.randn(2, 200, 2, generator=g) * 0.5
+    cfg = O.NsDiffConfig(200, 200, 2, 100, 20, n_z_samples=4, parallel_sample=2, variant=select)
+    with torch.no_grad():
+        dec = torch.cat([batch[:, -100:, :], torch.zeros(2, 200, 2)], dim=1)
+        y0 = f.cpu()(batch, dec)[0]
+    f.to(dev())
+    rec = []
+    torch.manual_seed(6)
+    want = O.evaluation_step(ckpt_wofx, cfg, batch, y0hat=y0, record=rec)
+    outs, _ = m.evaluation_step(batch, noise=torch.cat([z.reshape(-1) for z in rec]))
+    err = rel_err(outs, want)
+    print("attached backbone [%s] rel err %.3e" % (select, err))
+    assert err < RTOL
+
+
 # ---- BASELINE configs[1] at full size: properties that do not need the oracle ---------------------------------
 def test_full_size_c2_properties():
     """100 nodes, windows = pred_len = 100, N = 32, T = 50, 6 windows in one launch (19.2 M chain-steps x 50):

@@ -32,10 +32,10 @@ from .native_handle import NativeHandle
 
 _F_BACKBONE_MSG = (
     "train_model_select={!r} needs the non-stationary-transformer mean backbone f(x) "
-    "(reference NsDiff/mu_backbone.py, built on the absent torch_timeseries package); it is the next "
-    "row of the scope table (SURVEY.md 8f.1) and is not built yet.  Variants without f(x) "
-    "('cond_var', 'Guassian', 'pretrain_g') are supported, and evaluation_step accepts a "
-    "precomputed y_0_hat via `y0hat=`.")
+    "(reference NsDiff/mu_backbone.py, built on the absent torch_timeseries package); that row of the scope "
+    "table (SURVEY.md 8f.1) has no HIP implementation.  Either pass a precomputed y_0_hat (`y0hat=`) or attach "
+    "your own backbone module with the reference's call signature `(batch_x, dec_inp) -> (y_0_hat, _)` via "
+    "`attach_backbone(module)`; everything after f(x) -- sigma head, sampler, reduction -- runs natively.")
 
 
 def _draw_seed() -> int:
@@ -67,6 +67,29 @@ class _NsDiffBase(nn.Module):
         object.__setattr__(self, "_native", NativeHandle())
         self._native.bind(self)
 
+    # ---- f(x): a user-supplied torch module (the backbone itself is not part of this library) -----------
+    needs_backbone = False
+
+    def attach_backbone(self, module: nn.Module):
+        """Install f(x) as `cond_pred_model` (same attribute name as the reference, so its checkpoint entries
+        `cond_pred_model.*` load).  Call signature: module(batch_x [B, windows, F], dec_inp [B, label_len+pred_len, F])
+        -> (y_0_hat [B, pred_len, F], anything)  (reference NsDiff_model.py:222, mu_backbone.py:150-183)."""
+        self.cond_pred_model = module
+        return self
+
+    def _decoder_input(self, batch_x):
+        zeros = torch.zeros(batch_x.size(0), self.pred_len, self.dataset_nf, device=batch_x.device, dtype=batch_x.dtype)
+        return torch.cat([batch_x[:, -self.label_len:, :], zeros], dim=1)                  # reference :195-199
+
+    def _backbone_mean(self, batch_x):
+        """y_0_hat of already scaled windows [B, windows, F] through the attached backbone (torch, caller's module)."""
+        if getattr(self, "cond_pred_model", None) is None:
+            raise NotImplementedError(_F_BACKBONE_MSG.format(getattr(self, "train_model_select", None)))
+        dev = next(self.cond_pred_model.parameters(), torch.zeros(0, device=self.scaler_mean.device)).device
+        with torch.no_grad():
+            y0hat, _ = self.cond_pred_model(batch_x.to(dev), self._decoder_input(batch_x.to(dev)))
+        return y0hat
+
     # ---- scaler (reference :100-110) ------------------------------------------------
     def scaler_fit(self, data):
         std = data.std(axis=0)
@@ -81,8 +104,12 @@ class _NsDiffBase(nn.Module):
         return (data * self.scaler_std) + self.scaler_mean
 
     # ---- keep the device copy of the weights coherent ------------------------------------
-    def load_state_dict(self, *args, **kwargs):
-        out = super().load_state_dict(*args, **kwargs)
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """Strict by default, like the reference loader.  Entries of an f(x) backbone (`cond_pred_model.*`) are
+        dropped while no backbone is attached: the sampler and sigma head load, f(x) stays the caller's business."""
+        if getattr(self, "cond_pred_model", None) is None:
+            state_dict = {k: v for k, v in state_dict.items() if not k.startswith("cond_pred_model.")}
+        out = super().load_state_dict(state_dict, *args, **kwargs)
         self._native.mark_dirty()
         return out
 
@@ -149,6 +176,12 @@ class _NsDiffBase(nn.Module):
         ctx = self._native.context()
         series = series.to(device=ctx.device, dtype=torch.float32).contiguous()
         gx = self._prior_variance(ctx, series, n_windows, first, step, scale_input)
+        if y0hat is None and self.needs_backbone:
+            idx = first + step * torch.arange(n_windows, device=series.device).view(-1, 1) + torch.arange(self.windows, device=series.device)
+            wins = series[:, idx, :].permute(1, 0, 2, 3).reshape(n_windows * series.shape[0], self.windows, -1)
+            if scale_input:
+                wins = (wins - self.scaler_mean.to(wins.device)) / self.scaler_std.to(wins.device)
+            y0hat = self._backbone_mean(wins)
         if y0hat is not None:
             y0hat = y0hat.to(device=ctx.device, dtype=torch.float32).contiguous().reshape(gx.shape)
         if noise is None and self.noise_source == "torch_cpu":
@@ -187,12 +220,11 @@ class NsDiff_model_variants(_NsDiffBase):
         self.train_model_select = train_model_select
         if train_model_select not in ("Guassian", "cond_mean", "cond_var", "wo_UANS"):
             raise ValueError("train_model_select should be in Guassian/cond_mean/cond_var")
-        if train_model_select in ("cond_mean", "wo_UANS"):
-            raise NotImplementedError(_F_BACKBONE_MSG.format(train_model_select))
+        self.needs_backbone = train_model_select in ("cond_mean", "wo_UANS")      # f(x): attach_backbone() or y0hat=
         self.model = NsDiff_net(self.configs, self.device)
         self.cond_pred_model = None
         self.cond_pred_model_g = None
-        if train_model_select == "cond_var":
+        if train_model_select in ("cond_var", "wo_UANS"):
             self.cond_pred_model_g = G.SigmaEstimation(self.windows, self.pred_len, self.dataset_nf, 512,
                                                        self.rolling_length, native=self._native)
 
@@ -203,8 +235,10 @@ class NsDiff_model_variants(_NsDiffBase):
         std = self.scaler_std if scale_input else None
         return ctx.sigma_head(series, n_windows, first, step, mean, std, add_eps=self.EPS)     # + EPS (:450)
 
-    def evaluation_step(self, batch, noise: Optional[torch.Tensor] = None):
-        return self._evaluation_step(batch, None, noise)
+    def evaluation_step(self, batch, noise: Optional[torch.Tensor] = None, y0hat: Optional[torch.Tensor] = None):
+        if self.needs_backbone and y0hat is None and self.cond_pred_model is None:
+            raise NotImplementedError(_F_BACKBONE_MSG.format(self.train_model_select))
+        return self._evaluation_step(batch, y0hat, noise)
 
 
 class NsDiff_model(_NsDiffBase):
@@ -219,10 +253,16 @@ class NsDiff_model(_NsDiffBase):
         self.train_model_select = train_model_select
         self.load_pretrain = net_param.get("load_pretrain", False)
         self.freeze_pretrain = net_param.get("freeze_pretrain", False)
+        self.cond_pred_model = None
         if train_model_select == "pretrain_g":
             self.cond_pred_model_g = G.SigmaEstimation(self.windows, self.pred_len, self.dataset_nf, 512,
                                                        self.rolling_length, native=self._native)
-        elif train_model_select in ("NsDiff_model", "pretrain_f"):
+        elif train_model_select == "NsDiff_model":                 # f(x) attached by the caller, g(x) and sampler native
+            self.needs_backbone = True
+            self.model = NsDiff_net(self.configs, self.device)
+            self.cond_pred_model_g = G.SigmaEstimation(self.windows, self.pred_len, self.dataset_nf, 512,
+                                                       self.rolling_length, native=self._native)
+        elif train_model_select == "pretrain_f":
             raise NotImplementedError(_F_BACKBONE_MSG.format(train_model_select))
         else:
             raise ValueError("train_model_select should be in ['NsDiff_model', 'pretrain_f', 'pretrain_g']")
@@ -233,6 +273,8 @@ class NsDiff_model(_NsDiffBase):
         return ctx.sigma_head(series, n_windows, first, step, mean, std, add_eps=0.0)           # no EPS (:223)
 
     def evaluation_step(self, batch, y0hat: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
-        if y0hat is None:
+        if getattr(self, "model", None) is None:
+            raise RuntimeError("train_model_select={!r} has no diffusion network to sample from".format(self.train_model_select))
+        if y0hat is None and self.cond_pred_model is None:
             raise NotImplementedError(_F_BACKBONE_MSG.format(self.train_model_select))
         return self._evaluation_step(batch, y0hat, noise)
