@@ -98,6 +98,8 @@ def main():
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("MPV_BENCH_FORCE_DIST") == "1"     # force: smoke the RCCL path on one GPU
     if use_dist:
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":    # keeps RCCL's version banner off stdout: rank 0 prints
+            del os.environ["NCCL_DEBUG"]                             # exactly one line there, the JSON record
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
