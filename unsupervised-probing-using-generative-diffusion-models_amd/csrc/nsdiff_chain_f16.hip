@@ -228,12 +228,15 @@ __device__ __forceinline__ void split16(const f32x16& a, float scale, unsigned m
 // element: consecutive instructions are independent, one element's chain advances once per diagonal (>= 4
 // instructions apart), exps and logs are spread out.  It is cut into chunks of equal issue cost (plain 4 cycles,
 // transcendental 8); chunk g is issued right behind MFMA g of the tile being multiplied, starting at MFMA `SKIP`
-// (the first operands are the results of the MFMAs issued just before the segment, ~64 cycles away).
+// (0 measured best: an even spread matters more than the distance to the MFMAs that produced the first operands).
 template <bool SCALE, int SPL, int NEPS, int NM>       // SPL: 0 no split, 1 hi + lo, 2 hi only (one RNE cvt per pair)
 struct ActPlan {
     static constexpr int NST = 6 + (SPL == 1 ? 4 : (SPL == 2 ? 1 : 0)) + NEPS;
     static constexpr int MAXOPS = 16 * NST;
-    static constexpr int SKIP = NM > 8 ? 2 : 0;
+#ifndef MPV_SKIP
+#define MPV_SKIP 0
+#endif
+    static constexpr int SKIP = NM > 8 ? MPV_SKIP : 0;
     int n;
     int st[MAXOPS], el[MAXOPS];
     int start[NM + 1];
@@ -333,18 +336,21 @@ __device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, un
     using PL = ActPlanOf<SCALE, SPL, NEPS, NM>;
     ActState<F> s{a, {}, {}, {}, ss, ea, m2, mask, {}, {}};
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    f16x8 ah[3], al[3];                                       // ring: k-step ks lives in slot ks % 3
+#ifndef MPV_RING
+#define MPV_RING 3
+#endif
+    constexpr int RING = MPV_RING, AHEAD = RING - 1;
+    f16x8 ah[RING], al[RING];                                 // ring: k-step ks lives in slot ks % RING
     auto load_a = [&](auto ic) {
         constexpr int ks = decltype(ic)::value;
         const int off = jt * 32 * (HROW * 2) + ks * 32;
-        ah[ks % 3] = LDS_H8(smem, wbase + img_hi + off);
-        if constexpr (NP >= 2) al[ks % 3] = LDS_H8(smem, wbase + img_lo + off);
+        ah[ks % RING] = LDS_H8(smem, wbase + img_hi + off);
+        if constexpr (NP >= 2) al[ks % RING] = LDS_H8(smem, wbase + img_lo + off);
     };
     // prologue: scale rows (and eps-head rows) of the activated tile, A operands of the first two k-steps
 #pragma unroll
     for (int q = 0; q < 4; ++q) s.gm[q] = LDS_F4(smem, grow + (32 * ja + 8 * q) * 4);
-    load_a(IC<KS0>{});
-    if constexpr (NKS > 1) load_a(IC<KS0 + 1>{});
+    static_for<0, (AHEAD < NKS ? AHEAD : NKS)>([&](auto ic) { load_a(IC<KS0 + decltype(ic)::value>{}); });
     SEG_FENCE();
     static_for<0, NM>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
@@ -353,20 +359,20 @@ __device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, un
             constexpr int ty = (NP == 3) ? g % 3 : (NP == 2 ? 2 * (g % 2) : 2);      // 0: W_lo h_hi, 1: W_hi h_lo, 2: W_hi h_hi
             constexpr bool first = (ks == 0) && (g % NP == 0);
 #ifndef MPV_ABL_NO_LDSA
-            if constexpr (g % NP == 0 && g / NP + 2 < NKS) load_a(IC<ks + 2>{});
+            if constexpr (g % NP == 0 && g / NP + AHEAD < NKS) load_a(IC<ks + AHEAD>{});
 #endif
 #if defined(MPV_ABL_NO_LDSA)      // ablation: every k-step multiplies the A operands of the first one (results are wrong)
-            if constexpr (ty == 0) acc = mfma16(al[KS0 % 3], bh[ks], first ? zero : acc);
-            else if constexpr (ty == 1) acc = mfma16(ah[KS0 % 3], bl[ks], acc);
-            else acc = mfma16(ah[KS0 % 3], bh[ks], first ? zero : acc);
+            if constexpr (ty == 0) acc = mfma16(al[KS0 % RING], bh[ks], first ? zero : acc);
+            else if constexpr (ty == 1) acc = mfma16(ah[KS0 % RING], bl[ks], acc);
+            else acc = mfma16(ah[KS0 % RING], bh[ks], first ? zero : acc);
 #elif defined(MPV_ABL_ONE_MFMA)     // ablation: one product per k-step (results are wrong)
-            if constexpr (ty == 2) acc = mfma16(ah[ks % 3], bh[ks], (ks == 0) ? zero : acc);
+            if constexpr (ty == 2) acc = mfma16(ah[ks % RING], bh[ks], (ks == 0) ? zero : acc);
 #elif defined(MPV_ABL_NO_MFMA)
             if constexpr (ty == 2 && ks == 0) acc = zero;
 #else
-            if constexpr (ty == 0) acc = mfma16(al[ks % 3], bh[ks], first ? zero : acc);
-            else if constexpr (ty == 1) acc = mfma16(ah[ks % 3], bl[ks], acc);
-            else acc = mfma16(ah[ks % 3], bh[ks], first ? zero : acc);
+            if constexpr (ty == 0) acc = mfma16(al[ks % RING], bh[ks], first ? zero : acc);
+            else if constexpr (ty == 1) acc = mfma16(ah[ks % RING], bl[ks], acc);
+            else acc = mfma16(ah[ks % RING], bh[ks], first ? zero : acc);
 #endif
         } else {
             mfma_bias(acc, ab, bone);
