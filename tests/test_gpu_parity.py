@@ -412,14 +412,16 @@ def test_attached_backbone_variants_match_oracle(ckpt_wofx, select):
 
 
 # ---- BASELINE configs[1] at full size: properties that do not need the oracle ---------------------------------
-def test_full_size_c2_properties():
-    """100 nodes, windows = pred_len = 100, N = 32, T = 50, 6 windows in one launch (19.2 M chain-steps x 50):
+@pytest.mark.parametrize("V,S,W", [(100, 32, 6), (500, 64, 2)])
+def test_full_size_c2_properties(V, S, W):
+    """BASELINE configs[1] (100 nodes, N = 32) and configs[3] (500 nodes, N = 64) per-GPU shapes, windows = pred_len = 100,
+    T = 50, several windows in one launch:
     finite, bitwise repeatable under the same seed, different under another; the device MPV reduction equals a
     float64 torch reduction of the very samples it consumed; f16x3 and exact-fp32 GEMM modes agree on identical
     Philox noise to the parity tolerance."""
     from mpv_amd import synthetic
     from mpv_amd.models.models import diffusion_models
-    V, Wn, O, S, Tn, W = 100, 100, 100, 32, 50, 6
+    Wn, O, Tn = 100, 100, 50
     param = dict(device="cuda:0", dataset_nf=1, windows=Wn, pred_len=O, rolling_length=50, diffusion_steps=Tn,
                  diffusion_schedule="linear", beta_start=1e-4, beta_end=0.02, n_z_samples=S, parallel_sample=S,
                  scaler_type="StandardScaler", task_model="NsDiff_model_variants")
