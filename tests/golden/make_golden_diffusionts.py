@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Golden vectors for the DiffusionTS oracle, recorded from the reference's own package.
+
+Build container only.  `models.Diffusion_model.DiffusionTS` imports without stand-ins.  Two seeded small models (one
+with the 1-tap and one with the 5-tap circular `combine_s`), for each: the state dict, transformer outputs at several t,
+one `model_predictions`, a complete `fast_sample_infill` and `evaluation_step` with every normal draw recorded
+(torch.randn AND torch.randn_like are tapped: the sampler uses both).
+
+    python tests/golden/make_golden_diffusionts.py
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+import make_golden as G                       # noqa: E402
+
+
+class Tap:
+    def __enter__(self):
+        self.draws = []
+        self._r, self._rl = torch.randn, torch.randn_like
+
+        def randn(*a, **k):
+            z = self._r(*a, **k)
+            self.draws.append(z.detach().clone())
+            return z
+
+        def randn_like(x, *a, **k):
+            z = self._rl(x, *a, **k)
+            self.draws.append(z.detach().clone())
+            return z
+
+        torch.randn, torch.randn_like = randn, randn_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.randn_like = self._r, self._rl
+
+    def flat(self):
+        return np.concatenate([d.reshape(-1).numpy() for d in self.draws])
+
+
+def main():
+    sys.meta_path.append(G._AbsentFinder())
+    sys.path.insert(0, str(G.REF))
+    from models.Diffusion_model.DiffusionTS.DiffusionTS_model import DiffusionTS_model
+    out = {}
+    cases = {"small": dict(windows=12, pred_len=8, dataset_nf=2, d_model=16, n_layer_enc=1, n_layer_dec=2, n_heads=2, timesteps=20,
+                           diffusion_steps=6, n_z_samples=4, parallel_sample=2),
+             "wide": dict(windows=40, pred_len=30, dataset_nf=1, d_model=16, n_layer_enc=1, n_layer_dec=1, n_heads=4, timesteps=30,
+                          diffusion_steps=30, n_z_samples=2, parallel_sample=2)}
+    for tag, par in cases.items():
+        torch.manual_seed({"small": 5, "wide": 6}[tag])
+        m = DiffusionTS_model(dict(par, device="cpu", scaler_type="StandardScaler")).eval()
+        for k, v in m.state_dict().items():
+            out["sd_%s_%s" % (tag, k)] = G.npy(v)
+        out["cfg_%s" % tag] = np.array([par[k] for k in ("windows", "pred_len", "dataset_nf", "d_model", "n_layer_enc", "n_layer_dec",
+                                                            "n_heads", "timesteps", "diffusion_steps", "n_z_samples", "parallel_sample")], dtype=np.int64)
+        g = torch.Generator().manual_seed(9)
+        L, nf = par["windows"] + par["pred_len"], par["dataset_nf"]
+        x = torch.randn(3, L, nf, generator=g) * 0.7
+        out["x_%s" % tag] = G.npy(x)
+        with torch.no_grad():
+            for t in (0, par["timesteps"] // 2, par["timesteps"] - 1):
+                tt = torch.full((3,), t, dtype=torch.long)
+                trend, season = m.model.model(x, tt)
+                out["tf_%s_t%d_trend" % (tag, t)] = G.npy(trend)
+                out["tf_%s_t%d_season" % (tag, t)] = G.npy(season)
+            tt = torch.full((3,), par["timesteps"] // 3, dtype=torch.long)
+            pn, xs = m.model.model_predictions(x, tt, clip_x_start=True)
+            out["mp_%s_noise" % tag], out["mp_%s_x0" % tag] = G.npy(pn), G.npy(xs)
+        batch = torch.randn(2, par["windows"], nf, generator=g) * 0.5
+        out["batch_%s" % tag] = G.npy(batch)
+        torch.manual_seed(77)
+        with Tap() as tap:
+            outs, by = m.evaluation_step(batch.clone())
+        assert by is None
+        out["eval_%s_out" % tag], out["eval_%s_noise" % tag] = G.npy(outs), tap.flat()
+        out["eval_%s_ndraws" % tag] = np.array([d.numel() for d in tap.draws], dtype=np.int64)
+    np.savez_compressed(HERE / "diffusionts_cases.npz", **out)
+    f = HERE / "diffusionts_cases.npz"
+    print("%-28s %8.1f KiB" % (f.name, f.stat().st_size / 1024))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    main()

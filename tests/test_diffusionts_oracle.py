@@ -1,0 +1,71 @@
+"""Pin oracle/diffusionts_oracle.py (no HIP path yet) against vectors recorded from the
+reference's own DiffusionTS package (tests/golden/make_golden_diffusionts.py)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffusionts_oracle as D
+
+GOLD = Path(__file__).resolve().parent / "golden" / "diffusionts_cases.npz"
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def case(gold, tag):
+    pre = "sd_%s_" % tag
+    sd = {k[len(pre):]: T(gold[k]) for k in gold.files if k.startswith(pre)}
+    w, o, nf, d, le, ld, nh, ts, steps, nz, par = (int(v) for v in gold["cfg_%s" % tag])
+    cfg = D.DTSConfig(windows=w, pred_len=o, nf=nf, d_model=d, n_layer_enc=le, n_layer_dec=ld, n_heads=nh, timesteps=ts,
+                      sampling_timesteps=steps, n_z_samples=nz, parallel_sample=par)
+    return sd, cfg
+
+
+def replay(flat, sizes):
+    chunks = list(torch.split(T(np.ascontiguousarray(flat)), [int(s) for s in sizes]))
+    it = iter(chunks)
+    return lambda shape: next(it).reshape(shape)
+
+
+@pytest.mark.parametrize("tag", ["small", "wide"])
+def test_schedule_buffers_bit_exact(gold, tag):
+    sd, cfg = case(gold, tag)
+    tb = D.schedule_tables(cfg.timesteps)
+    for name, val in tb.items():
+        assert torch.equal(val, sd["model." + name]), name
+
+
+@pytest.mark.parametrize("tag", ["small", "wide"])
+def test_transformer_and_model_predictions(gold, tag):
+    sd, cfg = case(gold, tag)
+    x = T(gold["x_%s" % tag])
+    with torch.no_grad():
+        for t in (0, cfg.timesteps // 2, cfg.timesteps - 1):
+            trend, season = D.transformer(sd, cfg, x, torch.full((3,), t, dtype=torch.long))
+            np.testing.assert_allclose(trend.numpy(), gold["tf_%s_t%d_trend" % (tag, t)], rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(season.numpy(), gold["tf_%s_t%d_season" % (tag, t)], rtol=2e-5, atol=2e-6)
+        tb = D.schedule_tables(cfg.timesteps)
+        pn, x0 = D.model_predictions(sd, cfg, tb, x, torch.full((3,), cfg.timesteps // 3, dtype=torch.long), clip_x_start=True)
+    np.testing.assert_allclose(x0.numpy(), gold["mp_%s_x0" % tag], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(pn.numpy(), gold["mp_%s_noise" % tag], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["small", "wide"])
+def test_evaluation_step_with_the_reference_noise_stream(gold, tag):
+    """DDIM + Langevin infill + the sample-major / node-major tiling quirk, on the reference's recorded draws."""
+    sd, cfg = case(gold, tag)
+    used = []
+    out = D.evaluation_step(sd, cfg, T(gold["batch_%s" % tag]), replay(gold["eval_%s_noise" % tag], gold["eval_%s_ndraws" % tag]), record=used)
+    want = gold["eval_%s_out" % tag]
+    assert tuple(out.shape) == want.shape and len(used) == len(gold["eval_%s_ndraws" % tag])
+    err = float(np.abs(out.detach().numpy() - want).max() / np.abs(want).max())
+    print("DiffusionTS oracle evaluation_step [%s]: max rel err %.3e over %d draws" % (tag, err, len(used)))
+    assert err < 2e-4
+    with pytest.raises(ValueError):
+        D.evaluation_step(sd, D.DTSConfig(cfg.windows, cfg.pred_len, cfg.nf, n_z_samples=5, parallel_sample=2), T(gold["batch_%s" % tag]),
+                          lambda s: torch.zeros(s))
