@@ -86,7 +86,7 @@ __global__ __launch_bounds__(RD_THREADS) void mpv_partial_kernel(const ReduceArg
         }
     }
     __syncthreads();
-    if (threadIdx.x < p.F * 2) {
+    if ((int)threadIdx.x < p.F * 2) {
         const int k = threadIdx.x >> 1, c = threadIdx.x & 1;
         double t = 0.0;
         for (int i = 0; i < RD_THREADS / 64; ++i) t += red[i][k][c];
