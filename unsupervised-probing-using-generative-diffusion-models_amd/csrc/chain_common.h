@@ -48,6 +48,7 @@ struct ChainArgs {
     long long noise_kstride;   // B*P*O*F
     int T, B, O, S, P, C;
     unsigned seed_lo, seed_hi, off_lo;
+    unsigned long long* tile_counter;   // f16 kernel: next unclaimed tile (waves pull tiles, so both waves of a SIMD stay busy to the end)
 };
 
 // ---- softplus(x) = x > 20 ? x : log1p(exp(x))  (torch.nn.functional.softplus defaults) ----

@@ -133,6 +133,7 @@ void mpv_ctx_destroy(mpv_ctx* ctx) {
     if (ctx->tm.blob) (void)hipFree(ctx->tm.blob);
     if (ctx->sg.blob) (void)hipFree(ctx->sg.blob);
     if (ctx->reduce_ws) (void)hipFree(ctx->reduce_ws);
+    if (ctx->tile_counter) (void)hipFree(ctx->tile_counter);
     delete ctx;
 }
 

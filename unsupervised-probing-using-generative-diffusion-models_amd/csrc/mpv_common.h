@@ -37,6 +37,7 @@ struct mpv_ctx {
     NsdiffModel tm;                // TMDM sampler weights (fp32 fields only)
     SigmaModel sg;
     double* reduce_ws = nullptr;   // partial sums of mpv_reduce
+    unsigned long long* tile_counter = nullptr;   // work queue head of the split-f16 chain kernel (zeroed per launch)
     size_t reduce_ws_bytes = 0;
     // chain-kernel timing (HIP events on the launch stream)
     bool timing = false;
