@@ -114,6 +114,16 @@ __device__ __forceinline__ void step_normals(unsigned long long chain, unsigned 
     }
 }
 
+// Next unclaimed 32-chain tile (wave-uniform).  Waves PULL tiles: the older wave of a SIMD wins issue arbitration and runs
+// ~2x faster than its partner, so a static split leaves every SIMD with a single wave for the last third of a launch.
+// Every wave's claims eventually land at or beyond n_tiles, so the grid always drains.
+__device__ __forceinline__ long long claim_tile(unsigned long long* counter, int lane) {
+    unsigned long long claim = 0;
+    if (lane == 0) claim = atomicAdd(counter, 1ull);
+    return (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(claim >> 32)) << 32) |
+                       __builtin_amdgcn_readfirstlane((unsigned)claim));
+}
+
 // hidden-unit index of register (4q+e) of out-tile j in half-wave h is 32j + 8q + 4h + e
 __device__ __forceinline__ int hbase(int j, int q, int h) { return 32 * j + 8 * q + 4 * h; }
 

@@ -93,6 +93,12 @@ int mpv_fail(mpv_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
+int mpv_reset_tile_counter(mpv_ctx* ctx) {
+    if (!ctx->tile_counter) MPV_HIP_TRY(ctx, hipMalloc(&ctx->tile_counter, sizeof(unsigned long long)));
+    MPV_HIP_TRY(ctx, hipMemsetAsync(ctx->tile_counter, 0, sizeof(unsigned long long), ctx->stream));
+    return MPV_OK;
+}
+
 extern "C" {
 
 int mpv_abi_version(void) { return MPV_ABI_VERSION; }

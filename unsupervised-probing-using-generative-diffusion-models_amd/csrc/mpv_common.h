@@ -47,6 +47,7 @@ struct mpv_ctx {
 };
 
 int mpv_fail(mpv_ctx* ctx, int code, const std::string& msg);
+int mpv_reset_tile_counter(mpv_ctx* ctx);   // allocate on first use, zero it on the context's stream
 
 #define MPV_HIP_TRY(ctx, expr)                                                                  \
     do {                                                                                        \

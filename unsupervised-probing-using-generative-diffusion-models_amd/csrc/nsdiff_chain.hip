@@ -131,7 +131,9 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_kernel(const 
     const int wave = threadIdx.x >> 6;
     const int r_lane = lane & 31, h_lane = lane >> 5;
 
-    for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < p.n_tiles; tile += (long long)gridDim.x * WAVES) {
+    for (;;) {
+        const long long tile = claim_tile(p.tile_counter, lane);
+        if (tile >= p.n_tiles) break;
         const long long n_raw = tile * TILE + r_lane;
         const bool valid = n_raw < p.n_chains;
         const long long n = valid ? n_raw : p.n_chains - 1;
@@ -275,10 +277,13 @@ int launch_f(mpv_ctx* ctx, const ChainArgs& a, bool philox, int grid) {
     auto kn = nsdiff_chain_kernel<F, false, TMDM>;
     MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(philox ? kp : kn),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (int rc = mpv_reset_tile_counter(ctx)) return rc;
+    ChainArgs q = a;
+    q.tile_counter = ctx->tile_counter;
     if (philox)
-        hipLaunchKernelGGL(kp, dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, a);
+        hipLaunchKernelGGL(kp, dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, q);
     else
-        hipLaunchKernelGGL(kn, dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, a);
+        hipLaunchKernelGGL(kn, dim3(grid), dim3(THREADS), lds_bytes, ctx->stream, q);
     MPV_HIP_TRY(ctx, hipGetLastError());
     return MPV_OK;
 }

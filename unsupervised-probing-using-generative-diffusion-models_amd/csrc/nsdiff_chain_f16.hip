@@ -788,14 +788,8 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
     unsigned char* const gam_w = smem + LD::GAM + wave * (3 * HID * 4);
     const int gl = (lane & 31) * 16;                                              // scale-row staging: 16 B per lane
 
-    // Waves PULL tiles from a global counter: the older wave of a SIMD wins issue arbitration and runs ~2x faster than
-    // its partner, so a static split would leave every SIMD with a single wave for the last third of the launch.
-    // Every wave leaves the loop (its claim lands at or beyond n_tiles), so the grid always drains.
     for (;;) {
-        unsigned long long claim = 0;
-        if (lane == 0) claim = atomicAdd(p.tile_counter, 1ull);
-        const long long tile = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(claim >> 32)) << 32) |
-                                           __builtin_amdgcn_readfirstlane((unsigned)claim));
+        const long long tile = claim_tile(p.tile_counter, lane);
         if (tile >= p.n_tiles) break;
         const long long n_raw = tile * TILE + r_lane;
         const bool valid = n_raw < p.n_chains;
@@ -909,8 +903,7 @@ int launch_f16_f(mpv_ctx* ctx, const ChainArgs& a, bool philox, int grid) {
     if ((size_t)lds > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "device LDS too small for the resident-weight chain kernel");
     MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(philox ? kp : kn),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    if (!ctx->tile_counter) MPV_HIP_TRY(ctx, hipMalloc(&ctx->tile_counter, sizeof(unsigned long long)));
-    MPV_HIP_TRY(ctx, hipMemsetAsync(ctx->tile_counter, 0, sizeof(unsigned long long), ctx->stream));
+    if (int rc = mpv_reset_tile_counter(ctx)) return rc;
     ChainArgs q = a;
     q.tile_counter = ctx->tile_counter;
     if (philox)
