@@ -451,3 +451,35 @@ def test_full_size_c2_properties(V, S, W):
     err = rel_err(outs["f16x3"], outs["f32"])
     print("full-size C2: f16x3 vs exact fp32 on identical Philox noise, max rel err %.3e" % err)
     assert err < RTOL
+
+
+def test_c_abi_error_paths():
+    """Return codes and messages of the C ABI itself (ctypes, no Python-side validation in the way)."""
+    import ctypes as C
+    from mpv_amd import _native
+    lib = _native.load_library()
+    assert lib.mpv_nsdiff_sample(None, None, None, None, None, None) < 0                      # NULL ctx
+    assert b"ctx is NULL" in (lib.mpv_last_error(None) or b"")
+    h = C.c_void_p()
+    assert lib.mpv_ctx_create(9999, None, C.byref(h)) < 0 and not h.value                     # bad device ordinal
+    assert lib.mpv_ctx_create(0, None, C.byref(h)) == 0 and h.value
+    shape = _native.SampleShape(1, 1, 4, 4, 4, 0, 1, 0)
+    assert lib.mpv_nsdiff_sample(h, C.byref(shape), None, None, None, None) < 0               # nothing loaded
+    assert b"mpv_nsdiff_load first" in lib.mpv_last_error(h)
+    sd = O.random_state_dict(1, 10, 100, 100, 50, seed=5)
+    ctx = make_ctx(sd, 1, 10)
+    gx = torch.ones(1, 1, 4, 1, device=dev())
+    out = torch.empty(1, 1, 4, 1, 4, device=dev())
+    for bad, msg in ((_native.SampleShape(1, 1, 4, 4, 4, 7, 1, 0), b"gemm must be"),
+                     (_native.SampleShape(1, 1, 4, 6, 4, 0, 1, 0), b"multiple of chunk"),
+                     (_native.SampleShape(-1, 1, 4, 4, 4, 0, 1, 0), b"negative extent")):
+        rc = lib.mpv_nsdiff_sample(ctx._h, C.byref(bad), None, C.c_void_p(gx.data_ptr()), None, C.c_void_p(out.data_ptr()))
+        assert rc < 0 and msg in lib.mpv_last_error(ctx._h), (rc, lib.mpv_last_error(ctx._h))
+    ok = _native.SampleShape(1, 1, 4, 4, 4, 0, 1, 0)
+    assert lib.mpv_nsdiff_sample(ctx._h, C.byref(ok), None, None, None, C.c_void_p(out.data_ptr())) < 0   # gx NULL, non-empty
+    assert lib.mpv_nsdiff_sample(ctx._h, C.byref(ok), None, C.c_void_p(gx.data_ptr()), None, C.c_void_p(out.data_ptr())) == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
+    d = _native.NsdiffDesc(0, 1)
+    assert lib.mpv_nsdiff_load(ctx._h, C.byref(d), None, None) < 0
+    lib.mpv_ctx_destroy(h)
