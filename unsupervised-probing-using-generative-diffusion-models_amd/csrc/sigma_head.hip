@@ -5,15 +5,18 @@
 // those the replicate padding never enters the window, so v[i] = Var_pop(x[i+1 .. i+k]),
 // i = 0..T-k-1.  torch's CPU variance accumulates in double (Welford); so do we (two-pass).
 //
-// This kernel runs once per window (<1% of the path's time); it is HBM/L2-bound on the
-// 1.6 MB of MLP weights, which every workgroup streams once for GROUPS (window,node) rows
-// from the transposed [in][out] copy (coalesced across the threads of a workgroup).
+// This kernel runs once per window (<1% of the sampling path's time, all of the gx-only indicator's); it is L2-bound
+// on the 1.6 MB of MLP weights, which every workgroup streams once for G (window,node) rows from the transposed
+// [in][out] copy (coalesced across the threads of a workgroup).  G is as large as the accumulator registers allow
+// (G*F = 16 dot products per thread): 16 rows per workgroup at F = 1 cuts the weight traffic 4x against the first
+// version (4 rows) -- 18 100 rows: 2.55 ms -> see DESIGN.md 3.2.
 #include "mpv_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int SG_THREADS = 256;
-constexpr int GROUPS = 4;   // (window,node) rows per workgroup
 
 struct SigmaArgs {
     const float *w0t, *b0, *ln0w, *ln0b, *w1t, *b1, *ln1w, *ln1b, *w2t, *b2;
@@ -47,33 +50,42 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 
 __device__ __forceinline__ float softplus_acc(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
-// out[g][f][j] = act(bias[j] + sum_k in[g][f][k] * Wt[k][j])   for j < N
-template <bool RELU>
-__device__ __forceinline__ void dense(const float* __restrict__ Wt, const float* __restrict__ bias, const float* in,
-                                      int in_stride_f, int in_stride_g, float* out, int out_stride_f, int out_stride_g,
-                                      int K, int N, int F, int ng) {
-    for (int j = threadIdx.x; j < N; j += SG_THREADS) {
-        float acc[GROUPS][MPV_MAX_NF];
+// out[r][j] = act(bias[j] + sum_k in[r][k] * Wt[k][j])   for j < N, r = g*F + f over the R = G*F rows of the workgroup
+// (rows beyond the live ones hold zeros and are computed but never stored: no divergence in the inner loop).
+// `in` rows are 16-byte aligned (stride a multiple of 4 floats): one broadcast ds_read_b128 feeds four FMAs.
+template <int R>
+__device__ __forceinline__ void dot_rows(const float* __restrict__ Wt, const float* in, int in_stride, int K, int N, int j, float (&acc)[R]) {
+    int k = 0;
+    for (; k + 4 <= K; k += 4) {
+        const float w0 = Wt[(long long)k * N + j], w1 = Wt[(long long)(k + 1) * N + j];
+        const float w2 = Wt[(long long)(k + 2) * N + j], w3 = Wt[(long long)(k + 3) * N + j];
 #pragma unroll
-        for (int g = 0; g < GROUPS; ++g)
-#pragma unroll
-            for (int f = 0; f < MPV_MAX_NF; ++f) acc[g][f] = bias[j];
-        for (int k = 0; k < K; ++k) {
-            const float w = Wt[(long long)k * N + j];
-#pragma unroll
-            for (int g = 0; g < GROUPS; ++g)
-#pragma unroll
-                for (int f = 0; f < MPV_MAX_NF; ++f)
-                    if (g < ng && f < F) acc[g][f] = __builtin_fmaf(in[g * in_stride_g + f * in_stride_f + k], w, acc[g][f]);
+        for (int r = 0; r < R; ++r) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(in + r * in_stride + k);
+            acc[r] = __builtin_fmaf(x[0], w0, acc[r]);
+            acc[r] = __builtin_fmaf(x[1], w1, acc[r]);
+            acc[r] = __builtin_fmaf(x[2], w2, acc[r]);
+            acc[r] = __builtin_fmaf(x[3], w3, acc[r]);
         }
+    }
+    for (; k < K; ++k) {
+        const float w = Wt[(long long)k * N + j];
 #pragma unroll
-        for (int g = 0; g < GROUPS; ++g)
+        for (int r = 0; r < R; ++r) acc[r] = __builtin_fmaf(in[r * in_stride + k], w, acc[r]);
+    }
+}
+
+template <bool RELU, int R>
+__device__ __forceinline__ void dense(const float* __restrict__ Wt, const float* __restrict__ bias, const float* in, int in_stride,
+                                      float* out, int out_stride, int K, int N, int live_rows) {
+    for (int j = threadIdx.x; j < N; j += SG_THREADS) {
+        float acc[R];
 #pragma unroll
-            for (int f = 0; f < MPV_MAX_NF; ++f)
-                if (g < ng && f < F) {
-                    const float v = acc[g][f];
-                    out[g * out_stride_g + f * out_stride_f + j] = RELU ? fmaxf(v, 0.0f) : v;
-                }
+        for (int r = 0; r < R; ++r) acc[r] = bias[j];
+        dot_rows<R>(Wt, in, in_stride, K, N, j, acc);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (r < live_rows) out[r * out_stride + j] = RELU ? fmaxf(acc[r], 0.0f) : acc[r];
     }
 }
 
@@ -99,35 +111,43 @@ __device__ __forceinline__ void layer_norm(float* h, int stride_g, const float* 
     __syncthreads();
 }
 
+template <int F, int GROUPS>
 __global__ __launch_bounds__(SG_THREADS) void sigma_head_kernel(const SigmaArgs p) {
+    constexpr int R = GROUPS * F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* red = reinterpret_cast<double*>(smem);                 // 8 doubles
     float* xw = reinterpret_cast<float*>(smem + 64);              // [GROUPS][F][Tw]
-    float* v = xw + GROUPS * p.F * p.Tw;                           // [GROUPS][F][K0]
-    float* h1 = v + GROUPS * p.F * p.K0;                           // [GROUPS][F][H]
-    float* h2 = h1 + GROUPS * p.F * p.H;                           // [GROUPS][F][H]
+    const int K0p = (p.K0 + 3) & ~3;                               // row stride of v: 16-byte aligned rows
+    const int Twp = (p.Tw + 3) & ~3;
+    float* v = xw + GROUPS * F * Twp;                              // [GROUPS][F][K0p]
+    float* h1 = v + GROUPS * F * K0p;                              // [GROUPS][F][H]
+    float* h2 = h1 + GROUPS * F * p.H;                             // [GROUPS][F][H]
 
     const long long g0 = (long long)blockIdx.x * GROUPS;
     const long long left = p.n_groups - g0;
     const int ng = (int)(left < GROUPS ? left : GROUPS);
+    if (ng < GROUPS) {                                             // rows of a ragged last workgroup: zeros, never stored
+        for (int i = threadIdx.x; i < R * K0p; i += SG_THREADS) v[i] = 0.0f;
+        for (int i = threadIdx.x; i < R * p.H; i += SG_THREADS) h1[i] = h2[i] = 0.0f;
+    }
 
     // ---- gather + scale the windows: xw[g][f][t] --------------------------------------
-    for (int i = threadIdx.x; i < ng * p.Tw * p.F; i += SG_THREADS) {
-        const int f = i % p.F;
-        const int t = (i / p.F) % p.Tw;
-        const int g = i / (p.F * p.Tw);
+    for (int i = threadIdx.x; i < ng * p.Tw * F; i += SG_THREADS) {
+        const int f = i % F;
+        const int t = (i / F) % p.Tw;
+        const int g = i / (F * p.Tw);
         const long long gi = g0 + g;
         const long long w = gi / p.V;
         const int node = (int)(gi % p.V);
-        float x = p.series[((long long)node * p.L + p.first + w * p.step + t) * p.F + f];
+        float x = p.series[((long long)node * p.L + p.first + w * p.step + t) * F + f];
         if (p.mean) x = (x - p.mean[f]) / p.std[f];
-        xw[(g * p.F + f) * p.Tw + t] = x;
+        xw[(g * F + f) * Twp + t] = x;
     }
     __syncthreads();
     // ---- trailing population variance of the last K0 positions, + 10e-8 ----------------
-    for (int i = threadIdx.x; i < ng * p.F * p.K0; i += SG_THREADS) {
+    for (int i = threadIdx.x; i < ng * F * p.K0; i += SG_THREADS) {
         const int pos = i % p.K0;
-        const float* x = xw + (i / p.K0) * p.Tw + pos + 1;
+        const float* x = xw + (i / p.K0) * Twp + pos + 1;
         double s = 0.0;
         for (int j = 0; j < p.k; ++j) s += (double)x[j];
         const double m = s / p.k;
@@ -136,37 +156,38 @@ __global__ __launch_bounds__(SG_THREADS) void sigma_head_kernel(const SigmaArgs 
             const double d = (double)x[j] - m;
             q += d * d;
         }
-        v[i] = (float)(q / p.k) + 10e-8f;
+        v[(i / p.K0) * K0p + pos] = (float)(q / p.k) + 10e-8f;
     }
     __syncthreads();
     // ---- MLP --------------------------------------------------------------------------
-    dense<true>(p.w0t, p.b0, v, p.K0, p.F * p.K0, h1, p.H, p.F * p.H, p.K0, p.H, p.F, ng);
+    dense<true, R>(p.w0t, p.b0, v, K0p, h1, p.H, p.K0, p.H, ng * F);
     __syncthreads();
-    layer_norm(h1, p.F * p.H, p.ln0w, p.ln0b, p.F, p.H, ng, red);
-    dense<true>(p.w1t, p.b1, h1, p.H, p.F * p.H, h2, p.H, p.F * p.H, p.H, p.H, p.F, ng);
+    layer_norm(h1, F * p.H, p.ln0w, p.ln0b, F, p.H, ng, red);
+    dense<true, R>(p.w1t, p.b1, h1, p.H, h2, p.H, p.H, p.H, ng * F);
     __syncthreads();
-    layer_norm(h2, p.F * p.H, p.ln1w, p.ln1b, p.F, p.H, ng, red);
+    layer_norm(h2, F * p.H, p.ln1w, p.ln1b, F, p.H, ng, red);
     // last layer straight to HBM: gx[gi][o][f] = softplus(.) + add_eps
     for (int j = threadIdx.x; j < p.O; j += SG_THREADS) {
-        float acc[GROUPS][MPV_MAX_NF];
+        float acc[R];
 #pragma unroll
-        for (int g = 0; g < GROUPS; ++g)
+        for (int r = 0; r < R; ++r) acc[r] = p.b2[j];
+        dot_rows<R>(p.w2t, h2, p.H, p.H, p.O, j, acc);
 #pragma unroll
-            for (int f = 0; f < MPV_MAX_NF; ++f) acc[g][f] = p.b2[j];
-        for (int k = 0; k < p.H; ++k) {
-            const float w = p.w2t[(long long)k * p.O + j];
-#pragma unroll
-            for (int g = 0; g < GROUPS; ++g)
-#pragma unroll
-                for (int f = 0; f < MPV_MAX_NF; ++f)
-                    if (g < ng && f < p.F) acc[g][f] = __builtin_fmaf(h2[(g * p.F + f) * p.H + k], w, acc[g][f]);
-        }
-#pragma unroll
-        for (int g = 0; g < GROUPS; ++g)
-#pragma unroll
-            for (int f = 0; f < MPV_MAX_NF; ++f)
-                if (g < ng && f < p.F) p.gx[((g0 + g) * p.O + j) * p.F + f] = softplus_acc(acc[g][f]) + p.add_eps;
+        for (int r = 0; r < R; ++r)
+            if (r < ng * F) p.gx[((g0 + r / F) * p.O + j) * F + (r % F)] = softplus_acc(acc[r]) + p.add_eps;
     }
+}
+
+template <int F, int GROUPS>
+int launch_sigma_fg(mpv_ctx* ctx, const SigmaArgs& a) {
+    const size_t lds = 64 + sizeof(float) * (size_t)GROUPS * F * (((a.Tw + 3) & ~3) + ((a.K0 + 3) & ~3) + 2 * a.H);
+    if (lds > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "sigma head: window too long for LDS staging");
+    MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sigma_head_kernel<F, GROUPS>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long long blocks = (a.n_groups + GROUPS - 1) / GROUPS;
+    hipLaunchKernelGGL((sigma_head_kernel<F, GROUPS>), dim3((unsigned)blocks), dim3(SG_THREADS), lds, ctx->stream, a);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
 }
 
 }  // namespace
@@ -182,12 +203,11 @@ int launch_sigma_head(mpv_ctx* ctx, const float* series, int V, int64_t L, int n
     a.V = V; a.Tw = m.d.seq_len; a.k = m.d.rolling; a.K0 = m.d.seq_len - m.d.rolling; a.O = m.d.pred_len;
     a.F = m.d.nf; a.H = m.d.hidden; a.add_eps = add_eps;
     if (a.n_groups == 0) return MPV_OK;
-    const size_t lds = 64 + sizeof(float) * (size_t)GROUPS * a.F * (a.Tw + a.K0 + 2 * a.H);
-    if (lds > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "sigma head: window too long for LDS staging");
-    MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sigma_head_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const long long blocks = (a.n_groups + GROUPS - 1) / GROUPS;
-    hipLaunchKernelGGL(sigma_head_kernel, dim3((unsigned)blocks), dim3(SG_THREADS), lds, ctx->stream, a);
-    MPV_HIP_TRY(ctx, hipGetLastError());
-    return MPV_OK;
+    switch (a.F) {                                  // G*F = 16 accumulators per thread (8 for F = 3)
+        case 1: return launch_sigma_fg<1, 16>(ctx, a);
+        case 2: return launch_sigma_fg<2, 8>(ctx, a);
+        case 3: return launch_sigma_fg<3, 4>(ctx, a);
+        case 4: return launch_sigma_fg<4, 4>(ctx, a);
+        default: return mpv_fail(ctx, MPV_EINVAL, "sigma head: nf must be 1..4");
+    }
 }
