@@ -39,7 +39,8 @@ struct ReduceArgs {
     int W, F, S, nblk;
 };
 
-template <int SEG>
+// SEG lanes share a row; each lane reads VEC consecutive samples per slot (VEC = 4: one 16-byte load, S % 4 == 0)
+template <int SEG, int VEC>
 __global__ __launch_bounds__(RD_THREADS) void mpv_partial_kernel(const ReduceArgs p) {
     __shared__ double red[RD_THREADS / 64][MPV_MAX_NF][2];
     const int w = blockIdx.y;
@@ -59,13 +60,29 @@ __global__ __launch_bounds__(RD_THREADS) void mpv_partial_kernel(const ReduceArg
         const int f = live ? (int)(q % p.F) : 0;
         const float sc = p.std ? p.std[f] : 1.0f, sh = p.mean ? p.mean[f] : 0.0f;
         const float* x = base + (live ? q : 0) * p.S;
-        float s1 = 0.0f;
-        for (int s = ls; s < p.S; s += SEG) s1 += live ? (x[s] * sc + sh) : 0.0f;
+        float s1 = 0.0f, s2 = 0.0f;
+        if (VEC == 4) {
+            for (int s = ls * 4; s < p.S; s += SEG * 4) {
+                const float4 t = live ? *reinterpret_cast<const float4*>(x + s) : make_float4(0.f, 0.f, 0.f, 0.f);
+                s1 += live ? ((t.x * sc + sh) + (t.y * sc + sh)) + ((t.z * sc + sh) + (t.w * sc + sh)) : 0.0f;
+            }
+        } else {
+            for (int s = ls; s < p.S; s += SEG) s1 += live ? (x[s] * sc + sh) : 0.0f;
+        }
         const float m = seg_sum<SEG>(s1) * inv_s;
-        float s2 = 0.0f;
-        for (int s = ls; s < p.S; s += SEG) {
-            const float d = live ? (x[s] * sc + sh) - m : 0.0f;
-            s2 += d * d;
+        if (VEC == 4) {
+            for (int s = ls * 4; s < p.S; s += SEG * 4) {
+                if (live) {
+                    const float4 t = *reinterpret_cast<const float4*>(x + s);          // second pass hits L1/L2
+                    const float d0 = (t.x * sc + sh) - m, d1 = (t.y * sc + sh) - m, d2 = (t.z * sc + sh) - m, d3 = (t.w * sc + sh) - m;
+                    s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+            }
+        } else {
+            for (int s = ls; s < p.S; s += SEG) {
+                const float d = live ? (x[s] * sc + sh) - m : 0.0f;
+                s2 += d * d;
+            }
         }
         const float var = seg_sum<SEG>(s2) * inv_s;
         if (live && ls == 0) {
@@ -129,17 +146,23 @@ int launch_mpv_reduce(mpv_ctx* ctx, const float* samples, int W, int64_t R, int 
     }
     ReduceArgs a{samples, std, mean, ctx->reduce_ws, (long long)R, W, F, S, nblk};
     const dim3 grid(nblk, W), block(RD_THREADS);
+    const bool vec = (S % 4 == 0) && (reinterpret_cast<uintptr_t>(samples) % 16 == 0);
+    const int slots = vec ? S / 4 : S;                        // lanes a row can keep busy
     int seg = 1;
-    while (seg < S && seg < 64) seg <<= 1;
+    while (seg < slots && seg < 64) seg <<= 1;
+#define MPV_RD_LAUNCH(SEG_)                                                                                   \
+    if (vec) hipLaunchKernelGGL((mpv_partial_kernel<SEG_, 4>), grid, block, 0, ctx->stream, a);              \
+    else hipLaunchKernelGGL((mpv_partial_kernel<SEG_, 1>), grid, block, 0, ctx->stream, a)
     switch (seg) {
-        case 1: hipLaunchKernelGGL(mpv_partial_kernel<1>, grid, block, 0, ctx->stream, a); break;
-        case 2: hipLaunchKernelGGL(mpv_partial_kernel<2>, grid, block, 0, ctx->stream, a); break;
-        case 4: hipLaunchKernelGGL(mpv_partial_kernel<4>, grid, block, 0, ctx->stream, a); break;
-        case 8: hipLaunchKernelGGL(mpv_partial_kernel<8>, grid, block, 0, ctx->stream, a); break;
-        case 16: hipLaunchKernelGGL(mpv_partial_kernel<16>, grid, block, 0, ctx->stream, a); break;
-        case 32: hipLaunchKernelGGL(mpv_partial_kernel<32>, grid, block, 0, ctx->stream, a); break;
-        default: hipLaunchKernelGGL(mpv_partial_kernel<64>, grid, block, 0, ctx->stream, a); break;
+        case 1: MPV_RD_LAUNCH(1); break;
+        case 2: MPV_RD_LAUNCH(2); break;
+        case 4: MPV_RD_LAUNCH(4); break;
+        case 8: MPV_RD_LAUNCH(8); break;
+        case 16: MPV_RD_LAUNCH(16); break;
+        case 32: MPV_RD_LAUNCH(32); break;
+        default: MPV_RD_LAUNCH(64); break;
     }
+#undef MPV_RD_LAUNCH
     MPV_HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(mpv_finalize_kernel, dim3((W + 63) / 64), dim3(64), 0, ctx->stream, ctx->reduce_ws, W, nblk, F,
                        (long long)R, mpv, pred_mean, mpv_feat);
