@@ -166,8 +166,8 @@ int mpv_nsdiff_preact_bound(mpv_ctx* ctx, float* bound);
  *       3..5 gamma_0..2, 6 sqrt(beta_hat_t)  (tmdm_diffusion_utils.py:69-88), rest 0.
  * mpv_tmdm_sample: shape->pred_len is the SEQUENCE length the sampler runs on (label_len + pred_len);
  * y0hat dev [W][B][L][F]; noise as in mpv_nsdiff_sample (draw 0 = z_T, then one per step t = T-1..1);
- * samples dev [W][B][L][F][S]; shape->gemm must be MPV_GEMM_F32 (activations are not normalised, so the
- * split-f16 path does not apply).
+ * samples dev [W][B][L][F][S]; shape->gemm is MPV_GEMM_F16X3 (nf <= 3; the same tile-pipelined kernel as NsDiff with
+ * the normalisation switched off) or MPV_GEMM_F32.
  * ---------------------------------------------------------------------------------- */
 int mpv_tmdm_load(mpv_ctx* ctx, const mpv_nsdiff_desc* desc, const mpv_nsdiff_weights* host_weights, const float* host_coef);
 int mpv_tmdm_sample(mpv_ctx* ctx, const mpv_sample_shape* shape, const float* y0hat, const float* noise, float* samples);

@@ -239,16 +239,17 @@ def test_fast_and_guarded_activation_paths_are_both_exercised(ckpt_wofx):
     sd = O.random_state_dict(1, 10, 100, 100, 50, seed=5)
     ctx = make_ctx(sd, 1, 10)
     assert ctx.preact_bound() < 4.0
-    big = dict(sd)
+    big, huge = dict(sd), dict(sd)
     for i in (2, 3):
         big[O.EPS_NET + "lin%d.lin.weight" % i] = sd[O.EPS_NET + "lin%d.lin.weight" % i] * 60.0
-    ctx_big = make_ctx(big, 1, 10)
-    assert ctx_big.preact_bound() > 20.0
+        huge[O.EPS_NET + "lin%d.lin.weight" % i] = sd[O.EPS_NET + "lin%d.lin.weight" % i] * 400.0     # 2^x' overflows fp32
+    ctx_big, ctx_huge = make_ctx(big, 1, 10), make_ctx(huge, 1, 10)
+    assert ctx_big.preact_bound() > 20.0 and ctx_huge.preact_bound() > 128.0
     g = torch.Generator().manual_seed(9)
     gx = (torch.rand(1, 4, 6, 1, generator=g) + 0.1)
     noise = torch.randn(10, 4, 6, 1, generator=g)
     tb = O.schedule_tables(10)
-    for c, w in ((ctx, sd), (ctx_big, big)):
+    for c, w in ((ctx, sd), (ctx_big, big), (ctx_huge, huge)):
         want = O.sample_loop(w, tb, torch.zeros(4, 6, 1), gx[0], torch.zeros(4, 6, 1), 10, O.replay_noise(list(noise)))
         for gemm in ("f16x3", "f32", "f16x2", "f16"):
             got = c.sample(gx.to(dev()), None, 1, 1, noise=noise.to(dev()), gemm=gemm)[0, :, :, :, 0].cpu()

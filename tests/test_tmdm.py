@@ -140,22 +140,24 @@ def make_ctx(sd, nf, steps):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gemm", ["f16x3", "f32"])
 @pytest.mark.parametrize("tag,nf,steps", CASES)
-def test_gpu_chain_matches_reference_loop(golden_tmdm, tag, nf, steps):
+def test_gpu_chain_matches_reference_loop(golden_tmdm, tag, nf, steps, gemm):
     ctx = make_ctx(state(golden_tmdm, tag), nf, steps)
     y0 = T(golden_tmdm["in_%s_y0" % tag]).to(dev())[None].contiguous()               # [1, 6, 9, F]
     noise = T(np.ascontiguousarray(golden_tmdm["loop_%s_noise" % tag])).to(dev())     # [T, 6, 9, F]
-    out = ctx.sample_tmdm(y0, 1, 1, noise=noise)[0, :, :, :, 0]
+    out = ctx.sample_tmdm(y0, 1, 1, noise=noise, gemm=gemm)[0, :, :, :, 0]
     err = rel_err(out, golden_tmdm["loop_%s_out" % tag])
-    print("tmdm chain %s rel err %.3e" % (tag, err))
+    print("tmdm chain %s [%s] rel err %.3e" % (tag, gemm, err))
     assert err < RTOL
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gemm", ["f16x3", "f32"])
 @pytest.mark.parametrize("tag,nf,steps", CASES)
-def test_gpu_evaluation_step_replays_reference_noise_stream(golden_tmdm, tag, nf, steps):
+def test_gpu_evaluation_step_replays_reference_noise_stream(golden_tmdm, tag, nf, steps, gemm):
     """TMDM_model.evaluation_step under the reference's torch.manual_seed reproduces the reference's outs."""
-    m = _model(golden_tmdm, tag, nf, steps, device="cuda:0", noise_source="torch_cpu")
+    m = _model(golden_tmdm, tag, nf, steps, device="cuda:0", noise_source="torch_cpu", gemm_mode=gemm)
     B, label_len, pred_len, n_z, par = (int(v) for v in golden_tmdm["eval_%s_dims" % tag])
     prior = T(golden_tmdm["eval_%s_prior" % tag])
     batch = torch.zeros(B, 2 * label_len, nf)
@@ -163,7 +165,7 @@ def test_gpu_evaluation_step_replays_reference_noise_stream(golden_tmdm, tag, nf
     outs, batch_y = m.evaluation_step(batch, y_0_hat=prior)
     assert batch_y is None and tuple(outs.shape) == (B, pred_len, nf, n_z) and outs.device.type == "cpu"
     err = rel_err(outs, golden_tmdm["eval_%s_out" % tag])
-    print("tmdm evaluation_step %s rel err %.3e" % (tag, err))
+    print("tmdm evaluation_step %s [%s] rel err %.3e" % (tag, gemm, err))
     assert err < RTOL
     torch.manual_seed(99)
     outs2, _ = m.evaluation_step(batch, y_0_hat=prior[:, -pred_len:, :])                # pre-cut prior: same result
@@ -192,14 +194,35 @@ def test_gpu_philox_mode_and_ragged_shapes(golden_tmdm):
         assert np.abs(z.numpy() - PH.normals(41, 3, n, steps, nf)).max() < 5e-5
         g = torch.Generator().manual_seed(W)
         prior = torch.randn(W, B, L, nf, generator=g) * 0.3
-        got = ctx.sample_tmdm(prior.to(dev()), S, S, seed=41, offset=3).cpu()
         rows = prior.reshape(-1, 1, nf).repeat_interleave(S, dim=0)
         draws = [z[:, k, :].reshape(n, 1, nf) for k in range(steps)]
         want = TO.sample_loop(sd, tb, rows, rows, steps, _replay(torch.stack(draws).numpy()))
         want = want.reshape(W, B, L, S, nf).permute(0, 1, 2, 4, 3)
-        assert rel_err(got, want) < RTOL
+        for gemm in ("f16x3", "f32"):
+            got = ctx.sample_tmdm(prior.to(dev()), S, S, seed=41, offset=3, gemm=gemm).cpu()
+            assert rel_err(got, want) < RTOL, gemm
     out = ctx.sample_tmdm(torch.zeros(0, 3, 4, nf, device=dev()), 4, 4, seed=1)
     assert tuple(out.shape) == (0, 3, 4, nf, 4)
     from mpv_amd._native import MpvError
     with pytest.raises(MpvError):
         ctx.sample_tmdm(torch.zeros(1, 1, 4, nf, device=dev()), 6, 4, seed=1)
+
+
+@pytest.mark.gpu
+def test_gpu_guarded_path_with_large_activations(golden_tmdm):
+    """Scaled-up weights push the un-normalised activations past the f16 range of the fast path: the step re-runs
+    through the exact routine (normalised B operands) and still matches the oracle; both GEMM modes."""
+    nf, steps = 2, 10
+    sd = dict(state(golden_tmdm, "f2t10"))
+    for i in (2, 3):
+        sd[TO.EPS_NET + "lin%d.lin.weight" % i] = sd[TO.EPS_NET + "lin%d.lin.weight" % i] * 400.0
+    ctx = make_ctx(sd, nf, steps)
+    g = torch.Generator().manual_seed(4)
+    prior = torch.randn(1, 3, 5, nf, generator=g) * 0.3
+    noise = torch.randn(1, 1, steps, 3, 5, nf, generator=g)
+    rows = prior[0]
+    want = TO.sample_loop(sd, TO.schedule_tables(steps), rows, rows, steps, _replay(noise[0, 0].numpy()))
+    assert bool(torch.isfinite(want).all())
+    for gemm in ("f16x3", "f32"):
+        got = ctx.sample_tmdm(prior.to(dev()), 1, 1, noise=noise.to(dev()), gemm=gemm)[0, :, :, :, 0].cpu()
+        assert rel_err(got, want) < RTOL, gemm

@@ -262,7 +262,7 @@ class Context:
         self.tmdm = (steps, nf)
 
     def sample_tmdm(self, y0hat: torch.Tensor, n_samples: int, chunk: int, noise: Optional[torch.Tensor] = None,
-                    seed: int = 0, offset: int = 0) -> torch.Tensor:
+                    seed: int = 0, offset: int = 0, gemm: str = "f16x3") -> torch.Tensor:
         """y0hat [W, B, L, F] on device -> samples [W, B, L, F, S]."""
         if self.tmdm is None:
             raise MpvError("TMDM weights not loaded")
@@ -274,7 +274,11 @@ class Context:
             if noise.numel() != need:
                 raise MpvError("noise has {} elements, the draw order needs {}".format(noise.numel(), need))
         out = torch.empty((W, B, L, F, n_samples), device=self.device, dtype=torch.float32)
-        shape = SampleShape(W, B, L, n_samples, chunk, GEMM_MODES["f32"], seed & (2 ** 64 - 1), offset & (2 ** 64 - 1))
+        if gemm not in ("f16x3", "f32"):
+            raise MpvError("the TMDM sampler supports gemm 'f16x3' and 'f32'")
+        if gemm == "f16x3" and F > 3:
+            gemm = "f32"                                       # the split-f16 kernel is built for nf <= 3
+        shape = SampleShape(W, B, L, n_samples, chunk, GEMM_MODES[gemm], seed & (2 ** 64 - 1), offset & (2 ** 64 - 1))
         self._bind_stream()
         self._check(self.lib.mpv_tmdm_sample(self._h, C.byref(shape), _dev_ptr(y0hat, self.device, "y0hat"),
                                              _dev_ptr(noise, self.device, "noise"),

@@ -36,6 +36,7 @@ struct ChainArgs {
     const unsigned short* w1img;   // layer 1 as MFMA k-slots: [128][16*NK] f16 (nsdiff_chain_f16.hip::L1)
     const unsigned *b2p, *b3p;     // layer 2/3 biases, (hi | lo << 16) f16 pairs of b * 2^sB
     const float *g1, *g2, *g3, *wsl;
+    const float* w4h;              // eps head as the split-f16 kernel stages it (x ln2 for TMDM, whose activations are not normalised)
     float bone2, bone3;            // bias k-slot constant of layers 2, 3: 2^(sW - sB)  (x the B-operand scale)
     float l1_scale;                // 2^(s1 + 4): scale of the layer-1 accumulators
     unsigned hi_mask;              // 0xFFFFE000: keeps the 11 leading significand bits of an fp32
@@ -151,5 +152,48 @@ __device__ __forceinline__ float posterior(const StepCoef& c, float y, float mu,
     return g0 * y0r + g1 * y + g2 * mu + sqrtf(sig) * z;
 }
 
+
+// TMDM / CARD reverse step (reference TMDM/tmdm_diffusion_utils.py:57-90, 94-104): every coefficient is a
+// per-step scalar.  Columns: 0 invr = 1/sqrt(abar_t), 1 omr = 1 - sqrt(abar_t), 2 s = sqrt(1 - abar_t),
+// 3..5 gamma_0..2, 6 sqrt(beta_hat_t)
+__device__ __forceinline__ float posterior_tmdm(const float* cr, float y, float mu, float eps, float z, bool last) {
+#pragma clang fp contract(off)
+    const float y0r = cr[0] * (y - cr[1] * mu - eps * cr[2]);
+    if (last) return y0r;
+    return cr[3] * y0r + cr[4] * y + cr[5] * mu + cr[6] * z;
+}
+
+// acc = bias + W . hin on the fp32 matrix pipe; result copied back over hin
+__device__ __forceinline__ void mfma_layer(const float* __restrict__ Ws, const float* __restrict__ bias,
+                                           float (&hv)[64], int r, int h) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + hbase(j, q, h));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j][q * 4 + e] = b[e];
+        }
+    }
+    const float* wrow = Ws + r * WROW + 4 * h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(wrow + 32 * j * WROW + 32 * jt + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], hv[jt * 16 + q * 4 + e], acc[j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) hv[j * 16 + i] = acc[j][i];
+}
 
 }  // namespace chain

@@ -93,6 +93,138 @@ int mpv_fail(mpv_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
+// Shared by mpv_nsdiff_load and mpv_tmdm_load: fp32 blob for the exact kernel + every derived table of the split-f16 one.
+// `w` is in the NsDiff layout (lin_w[0] = [128][3F]); TMDM passes zero columns for g and a zero sigma head.
+static int load_chain_model(mpv_ctx* ctx, NsdiffModel& m, int T, int F, const mpv_nsdiff_weights* w, const float* coef, float act_scale) {
+    DeviceGuard g(ctx->device);
+    MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // nothing in flight may still read the old blob
+    const int H = MPV_HIDDEN;
+    const std::vector<float> w1t = transposed(w->lin_w[0], H, 3 * F);   // [3F][128]
+    std::vector<const float*> dev;
+    m.loaded = false;
+    int rc = upload_blob(ctx,
+                         {{w1t.data(), (size_t)3 * F * H}, {w->lin_w[1], (size_t)H * H}, {w->lin_w[2], (size_t)H * H},
+                          {w->lin_b[0], H}, {w->lin_b[1], H}, {w->lin_b[2], H},
+                          {w->embed[0], (size_t)T * H}, {w->embed[1], (size_t)T * H}, {w->embed[2], (size_t)T * H},
+                          {w->eps_w, (size_t)F * H}, {w->sig_w, (size_t)F * H}, {w->eps_b, (size_t)F}, {w->sig_b, (size_t)F},
+                          {coef, (size_t)T * MPV_COEF_COLS}},
+                         &m.blob, &dev);
+    if (rc != MPV_OK) return rc;
+    m.w1t = dev[0]; m.w2 = dev[1]; m.w3 = dev[2]; m.b1 = dev[3]; m.b2 = dev[4]; m.b3 = dev[5];
+    m.e1 = dev[6]; m.e2 = dev[7]; m.e3 = dev[8]; m.w4 = dev[9]; m.ws = dev[10]; m.b4 = dev[11]; m.bs = dev[12];
+    m.coef = dev[13];
+    // ---- split-f16 variant (nsdiff_chain_f16.hip): scaled/split weights, biases as MFMA k-slots, folded
+    // per-step scale rows, layer-1 pre-activation bound coefficients
+    const float LOG2E = 1.44269504088896341f, LN2 = 0.693147180559945309f;
+    const int INS = 4;                                    // layer-1 inputs scaled 2^4
+    auto f16bits = [](float x) { const _Float16 h = (_Float16)x; unsigned short u; std::memcpy(&u, &h, 2); return u; };
+    auto f16val = [](float x) { return (float)(_Float16)x; };
+    // layers 2/3: one power-of-two scale per matrix, chosen over {W, b/4} so the bias fits beside it.  The kernel
+    // feeds B = c l with a per-chain scalar c (1 on the hot path, 2^12/||l|| on the exact path) and a bias k-slot
+    // worth c ||l|| 2^(sW-sB) b 2^sB, so acc = 2^sW c ||l|| (W h + b) and x' = (gamma log2e 2^-sW) acc / (c ||l||)
+    // act_scale: the kernel's activations are l = softplus/ln2.  NsDiff normalises them (scale free, act_scale = 1);
+    // TMDM feeds softplus itself to the next layer, so its W2, W3 and eps-head images carry the factor ln2.
+    std::vector<float> wl[3];
+    for (int L = 1; L <= 2; ++L) {
+        wl[L].assign(w->lin_w[L], w->lin_w[L] + (size_t)H * H);
+        for (float& x : wl[L]) x *= act_scale;
+    }
+    std::vector<float> w4s(w->eps_w, w->eps_w + (size_t)F * H);
+    for (float& x : w4s) x *= act_scale;
+    int sW[3] = {0, 0, 0}, sB[3] = {0, 0, 0};
+    for (int L = 1; L <= 2; ++L) {
+        std::vector<float> joint(wl[L]);
+        for (int i = 0; i < H; ++i) joint.push_back(w->lin_b[L][i] * 0.25f);
+        sW[L] = scale_log2(joint.data(), joint.size());
+        int s = scale_log2(w->lin_b[L], (size_t)H);
+        sB[L] = std::max(sW[L] - 2, std::min(s, sW[L] + 10));
+    }
+    std::vector<unsigned short> w2h, w2l, w3h, w3l;
+    split_weights(wl[1].data(), sW[1], &w2h, &w2l);
+    split_weights(wl[2].data(), sW[2], &w3h, &w3l);
+    std::vector<unsigned> bp[3];
+    for (int L = 1; L <= 2; ++L) {
+        bp[L].resize(H);
+        for (int i = 0; i < H; ++i) {
+            const float x = std::ldexp(w->lin_b[L][i], sB[L]);
+            const float hi = f16val(x);
+            bp[L][i] = (unsigned)f16bits(hi) | ((unsigned)f16bits(x - hi) << 16);
+        }
+    }
+    m.bone2 = std::ldexp(1.0f, sW[1] - sB[1]);
+    m.bone3 = std::ldexp(1.0f, sW[2] - sB[2]);
+    // layer 1: one scale over {W1, b1}; k-slots: 3F x W_hi (x_hi), 3F x W_hi (x_lo), 3F x W_lo (x_hi), b_hi, b_lo
+    std::vector<float> joint1(w->lin_w[0], w->lin_w[0] + (size_t)H * 3 * F);
+    joint1.insert(joint1.end(), w->lin_b[0], w->lin_b[0] + H);
+    const int s1 = scale_log2(joint1.data(), joint1.size());
+    const int nk1 = (9 * F + 2 + 15) / 16;
+    std::vector<unsigned short> w1img((size_t)H * 16 * nk1, 0);
+    for (int j = 0; j < H; ++j) {
+        for (int c = 0; c < 3 * F; ++c) {
+            const float x = std::ldexp(w->lin_w[0][(size_t)j * 3 * F + c], s1);
+            const float hi = f16val(x);
+            w1img[(size_t)j * 16 * nk1 + c] = f16bits(hi);
+            w1img[(size_t)j * 16 * nk1 + 3 * F + c] = f16bits(hi);
+            w1img[(size_t)j * 16 * nk1 + 6 * F + c] = f16bits(x - hi);
+        }
+        const float b = std::ldexp(w->lin_b[0][j], s1);
+        const float bhi = f16val(b);
+        w1img[(size_t)j * 16 * nk1 + 9 * F] = f16bits(bhi);
+        w1img[(size_t)j * 16 * nk1 + 9 * F + 1] = f16bits(b - bhi);
+    }
+    m.l1_scale = std::ldexp(1.0f, s1 + INS);
+    std::vector<float> g1((size_t)T * H), g2((size_t)T * H), g3((size_t)T * H), wsl((size_t)F * H);
+    for (size_t i = 0; i < (size_t)T * H; ++i) {
+        g1[i] = std::ldexp(w->embed[0][i] * LOG2E, -(s1 + INS));
+        g2[i] = std::ldexp(w->embed[1][i] * LOG2E, -sW[1]);
+        g3[i] = std::ldexp(w->embed[2][i] * LOG2E, -sW[2]);
+    }
+    for (size_t i = 0; i < (size_t)F * H; ++i) wsl[i] = w->sig_w[i] * LN2;
+    // |x_j| = |gamma_tj (W_j . h + b_j)| <= |gamma_tj| (||W_j||_2 + |b_j|) because the layer input has unit 2-norm
+    float bound = 0.0f;
+    for (int L = 1; L <= 2; ++L)
+        for (int j = 0; j < H; ++j) {
+            double n2 = 0.0;
+            for (int k = 0; k < H; ++k) n2 += (double)wl[L][(size_t)j * H + k] * wl[L][(size_t)j * H + k];
+            const float reach = (float)std::sqrt(n2) + std::fabs(w->lin_b[L][j]);
+            for (int t = 0; t < T; ++t) bound = std::fmax(bound, std::fabs(w->embed[L][(size_t)t * H + j]) * reach);
+        }
+    m.preact_bound23 = std::isfinite(bound) ? bound : 1e30f;
+    // layer 1 (inputs unbounded): |x'_j| <= K1_t + K2_t * sum_c |in_c| in log2 units -> coefficient columns 18, 19
+    std::vector<float> coef2(coef, coef + (size_t)T * MPV_COEF_COLS);
+    for (int t = 0; t < T; ++t) {
+        float k1 = 0.0f, k2 = 0.0f;
+        for (int j = 0; j < H; ++j) {
+            const float gl = std::fabs(w->embed[0][(size_t)t * H + j]) * LOG2E;
+            float wm = 0.0f;
+            for (int c = 0; c < 3 * F; ++c) wm = std::fmax(wm, std::fabs(w->lin_w[0][(size_t)j * 3 * F + c]));
+            k1 = std::fmax(k1, gl * std::fabs(w->lin_b[0][j]));
+            k2 = std::fmax(k2, gl * wm);
+        }
+        coef2[(size_t)t * MPV_COEF_COLS + 18] = std::isfinite(k1) ? k1 * 1.0001f : 1e30f;
+        coef2[(size_t)t * MPV_COEF_COLS + 19] = std::isfinite(k2) ? k2 * 1.0001f : 1e30f;
+    }
+    auto as_f32 = [](const void* v) { return reinterpret_cast<const float*>(v); };
+    std::vector<const float*> d16;
+    rc = upload_blob(ctx,
+                     {{as_f32(w2h.data()), (size_t)H * H / 2}, {as_f32(w2l.data()), (size_t)H * H / 2},
+                      {as_f32(w3h.data()), (size_t)H * H / 2}, {as_f32(w3l.data()), (size_t)H * H / 2},
+                      {as_f32(w1img.data()), w1img.size() / 2}, {as_f32(bp[1].data()), (size_t)H}, {as_f32(bp[2].data()), (size_t)H},
+                      {g1.data(), (size_t)T * H}, {g2.data(), (size_t)T * H}, {g3.data(), (size_t)T * H},
+                      {wsl.data(), (size_t)F * H}, {coef2.data(), coef2.size()}, {w4s.data(), (size_t)F * H}},
+                     &m.blob16, &d16);
+    if (rc != MPV_OK) return rc;
+    m.w2h = reinterpret_cast<const unsigned short*>(d16[0]); m.w2l = reinterpret_cast<const unsigned short*>(d16[1]);
+    m.w3h = reinterpret_cast<const unsigned short*>(d16[2]); m.w3l = reinterpret_cast<const unsigned short*>(d16[3]);
+    m.w1img = reinterpret_cast<const unsigned short*>(d16[4]);
+    m.b2p = reinterpret_cast<const unsigned*>(d16[5]); m.b3p = reinterpret_cast<const unsigned*>(d16[6]);
+    m.g1 = d16[7]; m.g2 = d16[8]; m.g3 = d16[9]; m.wsl = d16[10];
+    m.coef = d16[11];                                     // same rows as given + columns 18, 19
+    m.w4h = d16[12];                                      // eps head as the split-f16 kernel reads it (x act_scale)
+    m.steps = T; m.nf = F; m.loaded = true;
+    return MPV_OK;
+}
+
 int mpv_reset_tile_counter(mpv_ctx* ctx) {
     if (!ctx->tile_counter) MPV_HIP_TRY(ctx, hipMalloc(&ctx->tile_counter, sizeof(unsigned long long)));
     MPV_HIP_TRY(ctx, hipMemsetAsync(ctx->tile_counter, 0, sizeof(unsigned long long), ctx->stream));
@@ -163,124 +295,7 @@ int mpv_nsdiff_load(mpv_ctx* ctx, const mpv_nsdiff_desc* d, const mpv_nsdiff_wei
     for (int i = 0; i < 3; ++i)
         if (!w->lin_w[i] || !w->lin_b[i] || !w->embed[i]) return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_load: NULL weight");
     if (!w->eps_w || !w->eps_b || !w->sig_w || !w->sig_b) return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_load: NULL head");
-    DeviceGuard g(ctx->device);
-    MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // nothing in flight may still read the old blob
-    const int T = d->steps, F = d->nf, H = MPV_HIDDEN;
-    const std::vector<float> w1t = transposed(w->lin_w[0], H, 3 * F);   // [3F][128]
-    std::vector<const float*> dev;
-    ctx->ns.loaded = false;
-    int rc = upload_blob(ctx,
-                         {{w1t.data(), (size_t)3 * F * H}, {w->lin_w[1], (size_t)H * H}, {w->lin_w[2], (size_t)H * H},
-                          {w->lin_b[0], H}, {w->lin_b[1], H}, {w->lin_b[2], H},
-                          {w->embed[0], (size_t)T * H}, {w->embed[1], (size_t)T * H}, {w->embed[2], (size_t)T * H},
-                          {w->eps_w, (size_t)F * H}, {w->sig_w, (size_t)F * H}, {w->eps_b, (size_t)F}, {w->sig_b, (size_t)F},
-                          {coef, (size_t)T * MPV_COEF_COLS}},
-                         &ctx->ns.blob, &dev);
-    if (rc != MPV_OK) return rc;
-    NsdiffModel& m = ctx->ns;
-    m.w1t = dev[0]; m.w2 = dev[1]; m.w3 = dev[2]; m.b1 = dev[3]; m.b2 = dev[4]; m.b3 = dev[5];
-    m.e1 = dev[6]; m.e2 = dev[7]; m.e3 = dev[8]; m.w4 = dev[9]; m.ws = dev[10]; m.b4 = dev[11]; m.bs = dev[12];
-    m.coef = dev[13];
-    // ---- split-f16 variant (nsdiff_chain_f16.hip): scaled/split weights, biases as MFMA k-slots, folded
-    // per-step scale rows, layer-1 pre-activation bound coefficients
-    const float LOG2E = 1.44269504088896341f, LN2 = 0.693147180559945309f;
-    const int INS = 4;                                    // layer-1 inputs scaled 2^4
-    auto f16bits = [](float x) { const _Float16 h = (_Float16)x; unsigned short u; std::memcpy(&u, &h, 2); return u; };
-    auto f16val = [](float x) { return (float)(_Float16)x; };
-    // layers 2/3: one power-of-two scale per matrix, chosen over {W, b/4} so the bias fits beside it.  The kernel
-    // feeds B = c l with a per-chain scalar c (1 on the hot path, 2^12/||l|| on the exact path) and a bias k-slot
-    // worth c ||l|| 2^(sW-sB) b 2^sB, so acc = 2^sW c ||l|| (W h + b) and x' = (gamma log2e 2^-sW) acc / (c ||l||)
-    int sW[3] = {0, 0, 0}, sB[3] = {0, 0, 0};
-    for (int L = 1; L <= 2; ++L) {
-        std::vector<float> joint(w->lin_w[L], w->lin_w[L] + (size_t)H * H);
-        for (int i = 0; i < H; ++i) joint.push_back(w->lin_b[L][i] * 0.25f);
-        sW[L] = scale_log2(joint.data(), joint.size());
-        int s = scale_log2(w->lin_b[L], (size_t)H);
-        sB[L] = std::max(sW[L] - 2, std::min(s, sW[L] + 10));
-    }
-    std::vector<unsigned short> w2h, w2l, w3h, w3l;
-    split_weights(w->lin_w[1], sW[1], &w2h, &w2l);
-    split_weights(w->lin_w[2], sW[2], &w3h, &w3l);
-    std::vector<unsigned> bp[3];
-    for (int L = 1; L <= 2; ++L) {
-        bp[L].resize(H);
-        for (int i = 0; i < H; ++i) {
-            const float x = std::ldexp(w->lin_b[L][i], sB[L]);
-            const float hi = f16val(x);
-            bp[L][i] = (unsigned)f16bits(hi) | ((unsigned)f16bits(x - hi) << 16);
-        }
-    }
-    m.bone2 = std::ldexp(1.0f, sW[1] - sB[1]);
-    m.bone3 = std::ldexp(1.0f, sW[2] - sB[2]);
-    // layer 1: one scale over {W1, b1}; k-slots: 3F x W_hi (x_hi), 3F x W_hi (x_lo), 3F x W_lo (x_hi), b_hi, b_lo
-    std::vector<float> joint1(w->lin_w[0], w->lin_w[0] + (size_t)H * 3 * F);
-    joint1.insert(joint1.end(), w->lin_b[0], w->lin_b[0] + H);
-    const int s1 = scale_log2(joint1.data(), joint1.size());
-    const int nk1 = (9 * F + 2 + 15) / 16;
-    std::vector<unsigned short> w1img((size_t)H * 16 * nk1, 0);
-    for (int j = 0; j < H; ++j) {
-        for (int c = 0; c < 3 * F; ++c) {
-            const float x = std::ldexp(w->lin_w[0][(size_t)j * 3 * F + c], s1);
-            const float hi = f16val(x);
-            w1img[(size_t)j * 16 * nk1 + c] = f16bits(hi);
-            w1img[(size_t)j * 16 * nk1 + 3 * F + c] = f16bits(hi);
-            w1img[(size_t)j * 16 * nk1 + 6 * F + c] = f16bits(x - hi);
-        }
-        const float b = std::ldexp(w->lin_b[0][j], s1);
-        const float bhi = f16val(b);
-        w1img[(size_t)j * 16 * nk1 + 9 * F] = f16bits(bhi);
-        w1img[(size_t)j * 16 * nk1 + 9 * F + 1] = f16bits(b - bhi);
-    }
-    m.l1_scale = std::ldexp(1.0f, s1 + INS);
-    std::vector<float> g1((size_t)T * H), g2((size_t)T * H), g3((size_t)T * H), wsl((size_t)F * H);
-    for (size_t i = 0; i < (size_t)T * H; ++i) {
-        g1[i] = std::ldexp(w->embed[0][i] * LOG2E, -(s1 + INS));
-        g2[i] = std::ldexp(w->embed[1][i] * LOG2E, -sW[1]);
-        g3[i] = std::ldexp(w->embed[2][i] * LOG2E, -sW[2]);
-    }
-    for (size_t i = 0; i < (size_t)F * H; ++i) wsl[i] = w->sig_w[i] * LN2;
-    // |x_j| = |gamma_tj (W_j . h + b_j)| <= |gamma_tj| (||W_j||_2 + |b_j|) because the layer input has unit 2-norm
-    float bound = 0.0f;
-    for (int L = 1; L <= 2; ++L)
-        for (int j = 0; j < H; ++j) {
-            double n2 = 0.0;
-            for (int k = 0; k < H; ++k) n2 += (double)w->lin_w[L][(size_t)j * H + k] * w->lin_w[L][(size_t)j * H + k];
-            const float reach = (float)std::sqrt(n2) + std::fabs(w->lin_b[L][j]);
-            for (int t = 0; t < T; ++t) bound = std::fmax(bound, std::fabs(w->embed[L][(size_t)t * H + j]) * reach);
-        }
-    m.preact_bound23 = std::isfinite(bound) ? bound : 1e30f;
-    // layer 1 (inputs unbounded): |x'_j| <= K1_t + K2_t * sum_c |in_c| in log2 units -> coefficient columns 18, 19
-    std::vector<float> coef2(coef, coef + (size_t)T * MPV_COEF_COLS);
-    for (int t = 0; t < T; ++t) {
-        float k1 = 0.0f, k2 = 0.0f;
-        for (int j = 0; j < H; ++j) {
-            const float gl = std::fabs(w->embed[0][(size_t)t * H + j]) * LOG2E;
-            float wm = 0.0f;
-            for (int c = 0; c < 3 * F; ++c) wm = std::fmax(wm, std::fabs(w->lin_w[0][(size_t)j * 3 * F + c]));
-            k1 = std::fmax(k1, gl * std::fabs(w->lin_b[0][j]));
-            k2 = std::fmax(k2, gl * wm);
-        }
-        coef2[(size_t)t * MPV_COEF_COLS + 18] = std::isfinite(k1) ? k1 * 1.0001f : 1e30f;
-        coef2[(size_t)t * MPV_COEF_COLS + 19] = std::isfinite(k2) ? k2 * 1.0001f : 1e30f;
-    }
-    auto as_f32 = [](const void* v) { return reinterpret_cast<const float*>(v); };
-    std::vector<const float*> d16;
-    rc = upload_blob(ctx,
-                     {{as_f32(w2h.data()), (size_t)H * H / 2}, {as_f32(w2l.data()), (size_t)H * H / 2},
-                      {as_f32(w3h.data()), (size_t)H * H / 2}, {as_f32(w3l.data()), (size_t)H * H / 2},
-                      {as_f32(w1img.data()), w1img.size() / 2}, {as_f32(bp[1].data()), (size_t)H}, {as_f32(bp[2].data()), (size_t)H},
-                      {g1.data(), (size_t)T * H}, {g2.data(), (size_t)T * H}, {g3.data(), (size_t)T * H},
-                      {wsl.data(), (size_t)F * H}, {coef2.data(), coef2.size()}},
-                     &ctx->ns.blob16, &d16);
-    if (rc != MPV_OK) return rc;
-    m.w2h = reinterpret_cast<const unsigned short*>(d16[0]); m.w2l = reinterpret_cast<const unsigned short*>(d16[1]);
-    m.w3h = reinterpret_cast<const unsigned short*>(d16[2]); m.w3l = reinterpret_cast<const unsigned short*>(d16[3]);
-    m.w1img = reinterpret_cast<const unsigned short*>(d16[4]);
-    m.b2p = reinterpret_cast<const unsigned*>(d16[5]); m.b3p = reinterpret_cast<const unsigned*>(d16[6]);
-    m.g1 = d16[7]; m.g2 = d16[8]; m.g3 = d16[9]; m.wsl = d16[10];
-    m.coef = d16[11];                                     // same rows as given + columns 18, 19
-    m.steps = T; m.nf = F; m.loaded = true;
-    return MPV_OK;
+    return load_chain_model(ctx, ctx->ns, d->steps, d->nf, w, coef, 1.0f);
 }
 
 int mpv_nsdiff_sample(mpv_ctx* ctx, const mpv_sample_shape* s, const float* y0hat, const float* gx, const float* noise,
@@ -307,24 +322,16 @@ int mpv_tmdm_load(mpv_ctx* ctx, const mpv_nsdiff_desc* d, const mpv_nsdiff_weigh
     for (int i = 0; i < 3; ++i)
         if (!w->lin_w[i] || !w->lin_b[i] || !w->embed[i]) return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_load: NULL weight");
     if (!w->eps_w || !w->eps_b) return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_load: NULL head");
-    DeviceGuard g(ctx->device);
-    MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const int T = d->steps, F = d->nf, H = MPV_HIDDEN;
-    const std::vector<float> w1t = transposed(w->lin_w[0], H, 2 * F);   // [2F][128]
-    std::vector<const float*> dev;
-    ctx->tm.loaded = false;
-    int rc = upload_blob(ctx,
-                         {{w1t.data(), (size_t)2 * F * H}, {w->lin_w[1], (size_t)H * H}, {w->lin_w[2], (size_t)H * H},
-                          {w->lin_b[0], H}, {w->lin_b[1], H}, {w->lin_b[2], H},
-                          {w->embed[0], (size_t)T * H}, {w->embed[1], (size_t)T * H}, {w->embed[2], (size_t)T * H},
-                          {w->eps_w, (size_t)F * H}, {w->eps_b, (size_t)F}, {coef, (size_t)T * MPV_COEF_COLS}},
-                         &ctx->tm.blob, &dev);
-    if (rc != MPV_OK) return rc;
-    NsdiffModel& m = ctx->tm;
-    m.w1t = dev[0]; m.w2 = dev[1]; m.w3 = dev[2]; m.b1 = dev[3]; m.b2 = dev[4]; m.b3 = dev[5];
-    m.e1 = dev[6]; m.e2 = dev[7]; m.e3 = dev[8]; m.w4 = dev[9]; m.b4 = dev[10]; m.coef = dev[11];
-    m.steps = T; m.nf = F; m.loaded = true;
-    return MPV_OK;
+    // same kernels, NsDiff weight layout: the third input group (g) gets zero columns, the sigma head is zero
+    const int F = d->nf, H = MPV_HIDDEN;
+    std::vector<float> w1((size_t)H * 3 * F, 0.0f), zero_w((size_t)F * H, 0.0f), zero_b((size_t)F, 0.0f);
+    for (int j = 0; j < H; ++j)
+        for (int c = 0; c < 2 * F; ++c) w1[(size_t)j * 3 * F + c] = w->lin_w[0][(size_t)j * 2 * F + c];
+    mpv_nsdiff_weights x = *w;
+    x.lin_w[0] = w1.data();
+    x.sig_w = zero_w.data();
+    x.sig_b = zero_b.data();
+    return load_chain_model(ctx, ctx->tm, d->steps, F, &x, coef, 0.693147180559945309f);
 }
 
 int mpv_tmdm_sample(mpv_ctx* ctx, const mpv_sample_shape* s, const float* y0hat, const float* noise, float* samples) {
@@ -335,7 +342,10 @@ int mpv_tmdm_sample(mpv_ctx* ctx, const mpv_sample_shape* s, const float* y0hat,
         return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: negative extent");
     const bool empty = s->n_windows == 0 || s->nodes == 0 || s->pred_len == 0 || s->n_samples == 0;
     if (!empty && (!y0hat || !samples)) return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: NULL argument");
-    if (s->gemm != MPV_GEMM_F32) return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: gemm must be MPV_GEMM_F32");
+    if (s->gemm != MPV_GEMM_F32 && s->gemm != MPV_GEMM_F16X3)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: gemm must be MPV_GEMM_F16X3 or MPV_GEMM_F32");
+    if (s->gemm == MPV_GEMM_F16X3 && ctx->tm.nf > 3)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: the split-f16 sampler supports nf 1..3 (use MPV_GEMM_F32 for nf = 4)");
     if (s->n_samples > 0 && (s->chunk < 1 || s->n_samples % s->chunk != 0))
         return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: n_samples must be a positive multiple of chunk");
     DeviceGuard g(ctx->device);

@@ -16,7 +16,7 @@ struct NsdiffModel {
     float* blob16 = nullptr;
     const unsigned short *w2h, *w2l, *w3h, *w3l, *w1img;
     const unsigned *b2p, *b3p;
-    const float *g1, *g2, *g3, *wsl;
+    const float *g1, *g2, *g3, *wsl, *w4h;
     float bone2 = 1.0f, bone3 = 1.0f, l1_scale = 1.0f;
     float preact_bound23 = 1e30f;   // max over t, unit of |gamma| (||W_row||_2 + |b|) for layers 2 and 3
 };
@@ -60,7 +60,7 @@ int mpv_reset_tile_counter(mpv_ctx* ctx);   // allocate on first use, zero it on
 int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* gx,
                         const float* noise, float* samples);
 namespace chain { struct ChainArgs; }
-int launch_chain_f16(mpv_ctx* ctx, const chain::ChainArgs& a, bool philox, int grid, int nf, int products);
+int launch_chain_f16(mpv_ctx* ctx, const chain::ChainArgs& a, bool philox, int grid, int nf, int products, bool tmdm);
 int launch_tmdm_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* noise, float* samples);
 int launch_biomass_sim(mpv_ctx* ctx, const mpv_biomass_desc& d, const int32_t* row_ptr, const int32_t* col_idx, const float* x0,
                        float* series_out);

@@ -55,49 +55,6 @@ __device__ __forceinline__ void activate(float (&v)[64], const float* __restrict
     for (int i = 0; i < 64; ++i) v[i] *= inv;
 }
 
-// TMDM / CARD reverse step (reference TMDM/tmdm_diffusion_utils.py:57-90, 94-104): every coefficient is a
-// per-step scalar.  Columns: 0 invr = 1/sqrt(abar_t), 1 omr = 1 - sqrt(abar_t), 2 s = sqrt(1 - abar_t),
-// 3..5 gamma_0..2, 6 sqrt(beta_hat_t)
-__device__ __forceinline__ float posterior_tmdm(const float* cr, float y, float mu, float eps, float z, bool last) {
-#pragma clang fp contract(off)
-    const float y0r = cr[0] * (y - cr[1] * mu - eps * cr[2]);
-    if (last) return y0r;
-    return cr[3] * y0r + cr[4] * y + cr[5] * mu + cr[6] * z;
-}
-
-// acc = bias + W . hin on the fp32 matrix pipe; result copied back over hin
-__device__ __forceinline__ void mfma_layer(const float* __restrict__ Ws, const float* __restrict__ bias,
-                                           float (&hv)[64], int r, int h) {
-    f32x16 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + hbase(j, q, h));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[j][q * 4 + e] = b[e];
-        }
-    }
-    const float* wrow = Ws + r * WROW + 4 * h;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(wrow + 32 * j * WROW + 32 * jt + 8 * q);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], hv[jt * 16 + q * 4 + e], acc[j], 0, 0, 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) hv[j * 16 + i] = acc[j][i];
-}
-
 // TMDM = false: NsDiff (inputs y, y0hat, g; normalised activations; eps and sigma heads; quadratic posterior).
 // TMDM = true : the CARD-style sampler of TMDM (inputs y, y0hat; plain softplus; eps head; scalar posterior).
 template <int F, bool PHILOX, bool TMDM>
@@ -290,15 +247,19 @@ int launch_f(mpv_ctx* ctx, const ChainArgs& a, bool philox, int grid) {
 
 }  // namespace
 
+static void fill_model_args(ChainArgs& a, const NsdiffModel& m) {
+    a.w1t = m.w1t; a.w2 = m.w2; a.w3 = m.w3; a.b1 = m.b1; a.b2 = m.b2; a.b3 = m.b3;
+    a.e1 = m.e1; a.e2 = m.e2; a.e3 = m.e3; a.w4 = m.w4; a.ws = m.ws; a.b4 = m.b4; a.bs = m.bs; a.coef = m.coef;
+    a.w2h = m.w2h; a.w2l = m.w2l; a.w3h = m.w3h; a.w3l = m.w3l;
+    a.w1img = m.w1img; a.b2p = m.b2p; a.b3p = m.b3p; a.g1 = m.g1; a.g2 = m.g2; a.g3 = m.g3; a.wsl = m.wsl; a.w4h = m.w4h;
+    a.bone2 = m.bone2; a.bone3 = m.bone3; a.l1_scale = m.l1_scale; a.hi_mask = 0xFFFFE000u;
+}
+
 int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* gx,
                         const float* noise, float* samples) {
     const NsdiffModel& m = ctx->ns;
     ChainArgs a{};
-    a.w1t = m.w1t; a.w2 = m.w2; a.w3 = m.w3; a.b1 = m.b1; a.b2 = m.b2; a.b3 = m.b3;
-    a.e1 = m.e1; a.e2 = m.e2; a.e3 = m.e3; a.w4 = m.w4; a.ws = m.ws; a.b4 = m.b4; a.bs = m.bs; a.coef = m.coef;
-    a.w2h = m.w2h; a.w2l = m.w2l; a.w3h = m.w3h; a.w3l = m.w3l;
-    a.w1img = m.w1img; a.b2p = m.b2p; a.b3p = m.b3p; a.g1 = m.g1; a.g2 = m.g2; a.g3 = m.g3; a.wsl = m.wsl;
-    a.bone2 = m.bone2; a.bone3 = m.bone3; a.l1_scale = m.l1_scale; a.hi_mask = 0xFFFFE000u;
+    fill_model_args(a, m);
     a.y0hat = y0hat; a.gx = gx; a.noise = noise; a.samples = samples;
     a.T = m.steps; a.B = s.nodes; a.O = s.pred_len; a.S = s.n_samples; a.P = s.chunk; a.C = s.n_samples / s.chunk;
     a.n_chains = (long long)s.n_windows * s.nodes * s.pred_len * s.n_samples;
@@ -322,7 +283,7 @@ int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0
     int rc;
     const bool philox = (noise == nullptr);
     if (s.gemm == MPV_GEMM_F16X3 || s.gemm == MPV_GEMM_F16X2 || s.gemm == MPV_GEMM_F16) {
-        rc = launch_chain_f16(ctx, a, philox, grid, m.nf, s.gemm == MPV_GEMM_F16X3 ? 3 : (s.gemm == MPV_GEMM_F16X2 ? 2 : 1));
+        rc = launch_chain_f16(ctx, a, philox, grid, m.nf, s.gemm == MPV_GEMM_F16X3 ? 3 : (s.gemm == MPV_GEMM_F16X2 ? 2 : 1), false);
     } else
     switch (m.nf) {
         case 1: rc = launch_f<1>(ctx, a, philox, grid); break;
@@ -343,9 +304,7 @@ int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0
 int launch_tmdm_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* noise, float* samples) {
     const NsdiffModel& m = ctx->tm;
     ChainArgs a{};
-    a.w1t = m.w1t; a.w2 = m.w2; a.w3 = m.w3; a.b1 = m.b1; a.b2 = m.b2; a.b3 = m.b3;
-    a.e1 = m.e1; a.e2 = m.e2; a.e3 = m.e3; a.w4 = m.w4; a.b4 = m.b4; a.coef = m.coef;
-    a.ws = m.w4; a.bs = m.b4;                               // unused by the TMDM instantiation
+    fill_model_args(a, m);
     a.y0hat = y0hat; a.gx = nullptr; a.noise = noise; a.samples = samples;
     a.T = m.steps; a.B = s.nodes; a.O = s.pred_len; a.S = s.n_samples; a.P = s.chunk; a.C = s.n_samples / s.chunk;
     a.n_chains = (long long)s.n_windows * s.nodes * s.pred_len * s.n_samples;
@@ -360,6 +319,7 @@ int launch_tmdm_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0ha
     if ((size_t)L_FLOATS * sizeof(float) > ctx->max_lds)
         return mpv_fail(ctx, MPV_EINVAL, "device LDS too small for the resident-weight chain kernel");
     const bool philox = (noise == nullptr);
+    if (s.gemm == MPV_GEMM_F16X3) return launch_chain_f16(ctx, a, philox, grid, m.nf, 3, true);
     switch (m.nf) {
         case 1: return launch_f<1, true>(ctx, a, philox, grid);
         case 2: return launch_f<2, true>(ctx, a, philox, grid);

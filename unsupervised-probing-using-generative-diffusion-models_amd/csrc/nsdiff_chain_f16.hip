@@ -519,22 +519,25 @@ struct StepCtx {                 // everything a step needs besides the chain st
 // one feature of one chain: finish the two head dot products across the half-waves, sigma's softplus, posterior.
 // With F > 1 this runs out of line, so the step loop holds ONE copy of the division / square-root sequences (the
 // loop body has to stay under the 16 KB instruction-fetch cliff, tools/ubench/ifetch.hip).
+template <bool NORM>
 __device__ __forceinline__ float feature_update(const float* cr, float ep, float sp, float b4, float bs, float y, float mu,
                                                 float g, float z, bool last) {
+    const float eps = ep + __shfl_xor(ep, 32) + b4;
+    if (!NORM) return posterior_tmdm(cr, y, mu, eps, z, last);           // TMDM: eps head only, scalar CARD posterior
     const StepCoef c = {cr[0], cr[1], cr[2],  cr[3],  cr[4],  cr[5],  cr[6],  cr[7],  cr[8],
                         cr[9], cr[10], cr[11], cr[12], cr[13], cr[14], cr[15], cr[16], cr[17]};
-    const float eps = ep + __shfl_xor(ep, 32) + b4;
     const float sig = softplus_dev(sp + __shfl_xor(sp, 32) + bs);
     return posterior(c, y, mu, g, eps, sig, z, last);
 }
+template <bool NORM>
 __device__ __noinline__ float feature_update_ool(const float* cr, float ep, float sp, float b4, float bs, float y, float mu,
                                                  float g, float z, bool last) {
-    return feature_update(cr, ep, sp, b4, bs, y, mu, g, z, last);
+    return feature_update<NORM>(cr, ep, sp, b4, bs, y, mu, g, z, last);
 }
 
 // ---- sigma / eps heads on h3 = l3 * inv3 in [0,1] and the posterior update (shared by both paths) ---------------
 // eps = W4 h3 + b4 (ea holds W4 l3, un-normalised); sigma = softplus((Ws ln2) softplus(h3)/ln2 + bs)
-template <int F>
+template <int F, bool NORM>
 __device__ __forceinline__ Vec<F> heads_posterior(const StepCtx& k, int t, f32x16 (&l3)[4], float (&ea)[F][4], float inv,
                                                   const Vec<F>& y, const Vec<F>& mu, const Vec<F>& g, const Vec<F>& z) {
     using LD = Lds<F>;
@@ -544,25 +547,27 @@ __device__ __forceinline__ Vec<F> heads_posterior(const StepCtx& k, int t, f32x1
     for (int f = 0; f < F; ++f)
 #pragma unroll
         for (int i = 0; i < 4; ++i) sa[f][i] = 0.0f;
-    const float inv_l2e = inv * LOG2E;
+    if (NORM) {                                                           // sigma head (NsDiff only)
+        const float inv_l2e = inv * LOG2E;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f32x16 sp;
+        for (int j = 0; j < 4; ++j) {
+            f32x16 sp;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sp[i] = l3[j][i] * inv_l2e;
+            for (int i = 0; i < 16; ++i) sp[i] = l3[j][i] * inv_l2e;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sp[i] = __builtin_amdgcn_exp2f(sp[i]);       // 1 + e^h in [2, 3.72]: no
-#pragma unroll                                                                      //   small-argument or
-        for (int i = 0; i < 16; ++i) sp[i] += 1.0f;                                 //   overflow cases
+            for (int i = 0; i < 16; ++i) sp[i] = __builtin_amdgcn_exp2f(sp[i]);   // 1 + e^h in [2, 3.72]: no
+#pragma unroll                                                                  //   small-argument or
+            for (int i = 0; i < 16; ++i) sp[i] += 1.0f;                             //   overflow cases
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sp[i] = __builtin_amdgcn_logf(sp[i]);
+            for (int i = 0; i < 16; ++i) sp[i] = __builtin_amdgcn_logf(sp[i]);
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
+            for (int f = 0; f < F; ++f) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 wsg = LDS_F4(k.smem, k.f_base + (LD::WSL - LD::F32) + (f * HID + 32 * j + 8 * q) * 4);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 wsg = LDS_F4(k.smem, k.f_base + (LD::WSL - LD::F32) + (f * HID + 32 * j + 8 * q) * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sa[f][e] = __builtin_fmaf(wsg[e], sp[q * 4 + e], sa[f][e]);
+                    for (int e = 0; e < 4; ++e) sa[f][e] = __builtin_fmaf(wsg[e], sp[q * 4 + e], sa[f][e]);
+                }
             }
         }
     }
@@ -570,10 +575,10 @@ __device__ __forceinline__ Vec<F> heads_posterior(const StepCtx& k, int t, f32x1
     Vec<F> out;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-        const float ep = ((ea[f][0] + ea[f][1]) + (ea[f][2] + ea[f][3])) * inv;
+        const float ep = ((ea[f][0] + ea[f][1]) + (ea[f][2] + ea[f][3])) * (NORM ? inv : 1.0f);
         const float sp = (sa[f][0] + sa[f][1]) + (sa[f][2] + sa[f][3]);
-        if (F == 1) out.v[f] = feature_update(cr, ep, sp, hb[f], hb[4 + f], y.v[f], mu.v[f], g.v[f], z.v[f], t == 0);
-        else out.v[f] = feature_update_ool(cr, ep, sp, hb[f], hb[4 + f], y.v[f], mu.v[f], g.v[f], z.v[f], t == 0);
+        if (F == 1) out.v[f] = feature_update<NORM>(cr, ep, sp, hb[f], hb[4 + f], y.v[f], mu.v[f], g.v[f], z.v[f], t == 0);
+        else out.v[f] = feature_update_ool<NORM>(cr, ep, sp, hb[f], hb[4 + f], y.v[f], mu.v[f], g.v[f], z.v[f], t == 0);
     }
     return out;
 }
@@ -596,7 +601,10 @@ __device__ __forceinline__ void eps_partial(const StepCtx& k, const f32x16& a, i
 // Returns `ok` = every guard passed: layer-1 inputs inside the f16 range of the input split, and for every layer
 // 1 < ||l|| < 2^13 (finite, no exp2 overflow, no all-tiny vector whose direction log2(1+e) would lose, every l and
 // the bias operand inside the f16 range).  Otherwise the kernel re-runs the step through chain_step_safe.
-template <int F, int NP>
+// NORM = true: NsDiff (normalised activations, eps and sigma heads).  NORM = false: the TMDM epsilon network (plain
+// softplus, reference TMDM/tmdm_model.py:38-64): the same weave with no 1/||l|| factor and a constant bias operand;
+// sum(l^2) is still accumulated, only as the f16-range guard of the un-normalised B operands.
+template <int F, int NP, bool NORM>
 __device__ __forceinline__ Vec<F> chain_step_fast(const StepCtx& k, int t, const Vec<F>& y, const Vec<F>& mu,
                                                   const Vec<F>& g, const Vec<F>& z, bool& ok TR_PARAMS) {
     using LD = Lds<F>;
@@ -628,10 +636,12 @@ __device__ __forceinline__ Vec<F> chain_step_fast(const StepCtx& k, int t, const
     woven<F, NP, 0, 6, false, false, true, false>(c2[0], k.smem, k.a_base, LD::W2H, LD::W2L, 0, Ah, Al, 0u, bone, a1[3], k.g_base, 3,
                                               1.0f, k.hi_mask, ss, k.f_base, nullptr, &Ah[6], &Ah[7], &Al[6], &Al[7]);
     TR(1);
-    float nrm, inv, nlo, nhi;
+    // every layer: lo < ||l|| < 2^13, written as comparisons that a NaN fails (min/max would skip it)
+    constexpr float NRM_LO = NORM ? 1.0f : -1.0f;
+    float nrm, inv;
     norm_fast(chain_sum(ss), nrm, inv);
-    nlo = nhi = nrm;
-    bone = bias_operand(nrm * k.kb2);
+    ok = ok && (nrm > NRM_LO) && (nrm < 8192.0f);
+    bone = bias_operand((NORM ? nrm : 1.0f) * k.kb2);
     mfma_tile<6, 8, NP>(c2[0], k.smem, k.a_base, LD::W2H, LD::W2L, 0, Ah, Al);
     mfma_bias(c2[0], k.ab2[0], bone);
     TR(2);
@@ -639,18 +649,17 @@ __device__ __forceinline__ Vec<F> chain_step_fast(const StepCtx& k, int t, const
     // ---- layer 2 tile j  ||  layer-2 activation of tile j-1
 #pragma unroll
     for (int j = 1; j < 4; ++j)
-        woven<F, NP, 0, 8, true, true, true, false>(c2[j & 1], k.smem, k.a_base, LD::W2H, LD::W2L, j, Ah, Al, k.ab2[j], bone,
+        woven<F, NP, 0, 8, true, NORM, true, false>(c2[j & 1], k.smem, k.a_base, LD::W2H, LD::W2L, j, Ah, Al, k.ab2[j], bone,
                                                 c2[(j - 1) & 1], g2, j - 1, inv, k.hi_mask, ss, k.f_base, nullptr,
                                                 &Bh[2 * j - 2], &Bh[2 * j - 1], &Bl[2 * j - 2], &Bl[2 * j - 1]);
     TR(3);
     // ---- layer 3 tile 0, k-steps 0..5  ||  layer-2 activation tile 3
-    woven<F, NP, 0, 6, false, true, true, false>(l3[0], k.smem, k.a_base3, 0, W3REL, 0, Bh, Bl, 0u, bone, c2[1], g2, 3, inv,
+    woven<F, NP, 0, 6, false, NORM, true, false>(l3[0], k.smem, k.a_base3, 0, W3REL, 0, Bh, Bl, 0u, bone, c2[1], g2, 3, inv,
                                              k.hi_mask, ss, k.f_base, nullptr, &Bh[6], &Bh[7], &Bl[6], &Bl[7]);
     TR(4);
     norm_fast(chain_sum(ss), nrm, inv);
-    nlo = fminf(nlo, nrm);
-    nhi = fmaxf(nhi, nrm);
-    bone = bias_operand(nrm * k.kb3);
+    ok = ok && (nrm > NRM_LO) && (nrm < 8192.0f);
+    bone = bias_operand((NORM ? nrm : 1.0f) * k.kb3);
     mfma_tile<6, 8, NP>(l3[0], k.smem, k.a_base3, 0, W3REL, 0, Bh, Bl);
     mfma_bias(l3[0], k.ab3[0], bone);
     TR(5);
@@ -663,24 +672,24 @@ __device__ __forceinline__ Vec<F> chain_step_fast(const StepCtx& k, int t, const
     // ---- layer 3 tile j  ||  layer-3 activation (and eps-head partial sums) of tile j-1
 #pragma unroll
     for (int j = 1; j < 4; ++j)
-        woven<F, NP, 0, 8, true, true, false, true>(l3[j], k.smem, k.a_base3, 0, W3REL, j, Bh, Bl, k.ab3[j], bone, l3[j - 1], g3,
+        woven<F, NP, 0, 8, true, NORM, false, true>(l3[j], k.smem, k.a_base3, 0, W3REL, j, Bh, Bl, k.ab3[j], bone, l3[j - 1], g3,
                                                 j - 1, inv, k.hi_mask, ss, k.f_base, ea, nullptr, nullptr, nullptr, nullptr);
     TR(6);
-    softplus16<false, true>(l3[3], k.smem, g3, 3, inv, ss);
+    softplus16<false, NORM>(l3[3], k.smem, g3, 3, inv, ss);
     eps_partial<F>(k, l3[3], 3, ea);
     norm_fast(chain_sum(ss), nrm, inv);
-    nlo = fminf(nlo, nrm);
-    nhi = fmaxf(nhi, nrm);
-    ok = ok && (nlo > 1.0f) && (nhi < 8192.0f);              // NaN fails both
+    ok = ok && (nrm > NRM_LO) && (nrm < 8192.0f);
     TR(7);
-    const Vec<F> out = heads_posterior<F>(k, t, l3, ea, inv, y, mu, g, z);
+    const Vec<F> out = heads_posterior<F, NORM>(k, t, l3, ea, inv, y, mu, g, z);
     TR(8);
     return out;
 }
 
 // ---- cold path: the exact evaluation (fp32 VALU layer 1, guarded softplus, normalised B operands) ---------------
 // Same weight images and scale rows: B = (l/||l||) 2^12, bias operand 2^12 kb, x' = g'' acc 2^-12.
-template <int F>
+// NORM = false (TMDM): a = W l + b without normalisation; B is still l/||l|| 2^12 (always inside the f16 range), the
+// bias operand 2^12 kb / ||l|| and x' = g'' acc ||l|| 2^-12.
+template <int F, bool NORM>
 __device__ __noinline__ Vec<F> chain_step_safe(StepCtx k, int t, Vec<F> y, Vec<F> mu, Vec<F> g, Vec<F> z) {
     using LD = Lds<F>;
     constexpr int W3REL = LD::W3L - LD::W3H;
@@ -695,10 +704,11 @@ __device__ __noinline__ Vec<F> chain_step_safe(StepCtx k, int t, Vec<F> y, Vec<F
     float ss[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) softplus16<true, false>(a[j], k.smem, k.g_base, j, 1.0f, ss);
-    float inv = 1.0f / fmaxf(sqrtf(chain_sum(ss)), 1e-12f / LN2);          // 1 / max(||l||, F.normalize eps / ln2)
+    float nrm = fmaxf(sqrtf(chain_sum(ss)), 1e-12f / LN2);                  // max(||l||, F.normalize eps / ln2)
+    float inv = 1.0f / nrm;
 #pragma unroll
     for (int j = 0; j < 4; ++j) split16<true>(a[j], inv * 4096.0f, k.hi_mask, bh[2 * j], bh[2 * j + 1], bl[2 * j], bl[2 * j + 1]);
-    f16x8 bone = bias_operand(4096.0f * k.kb2);
+    f16x8 bone = bias_operand(4096.0f * (NORM ? 1.0f : inv) * k.kb2);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         mfma_tile<0, 8>(c[j], k.smem, k.a_base, LD::W2H, LD::W2L, j, bh, bl);
@@ -706,11 +716,12 @@ __device__ __noinline__ Vec<F> chain_step_safe(StepCtx k, int t, Vec<F> y, Vec<F
     }
     ss[0] = ss[1] = ss[2] = ss[3] = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) softplus16<true, true>(c[j], k.smem, k.g_base + HID * 4, j, 1.0f / 4096.0f, ss);
-    inv = 1.0f / fmaxf(sqrtf(chain_sum(ss)), 1e-12f / LN2);
+    for (int j = 0; j < 4; ++j) softplus16<true, true>(c[j], k.smem, k.g_base + HID * 4, j, (NORM ? 1.0f : nrm) / 4096.0f, ss);
+    nrm = fmaxf(sqrtf(chain_sum(ss)), 1e-12f / LN2);
+    inv = 1.0f / nrm;
 #pragma unroll
     for (int j = 0; j < 4; ++j) split16<true>(c[j], inv * 4096.0f, k.hi_mask, bh[2 * j], bh[2 * j + 1], bl[2 * j], bl[2 * j + 1]);
-    bone = bias_operand(4096.0f * k.kb3);
+    bone = bias_operand(4096.0f * (NORM ? 1.0f : inv) * k.kb3);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         mfma_tile<0, 8>(a[j], k.smem, k.a_base3, 0, W3REL, j, bh, bl);
@@ -724,14 +735,14 @@ __device__ __noinline__ Vec<F> chain_step_safe(StepCtx k, int t, Vec<F> y, Vec<F
         for (int i = 0; i < 4; ++i) ea[f][i] = 0.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        softplus16<true, true>(a[j], k.smem, k.g_base + 2 * HID * 4, j, 1.0f / 4096.0f, ss);
+        softplus16<true, true>(a[j], k.smem, k.g_base + 2 * HID * 4, j, (NORM ? 1.0f : nrm) / 4096.0f, ss);
         eps_partial<F>(k, a[j], j, ea);
     }
     inv = 1.0f / fmaxf(sqrtf(chain_sum(ss)), 1e-12f / LN2);
-    return heads_posterior<F>(k, t, a, ea, inv, y, mu, g, z);
+    return heads_posterior<F, NORM>(k, t, a, ea, inv, y, mu, g, z);
 }
 
-template <int F, bool PHILOX, int NP>
+template <int F, bool PHILOX, int NP, bool NORM>
 __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using LD = Lds<F>;
@@ -750,7 +761,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
     {
         float* f = reinterpret_cast<float*>(smem);
         for (int i = threadIdx.x; i < F * HID; i += THREADS) {
-            f[LD::W4 / 4 + i] = p.w4[i];
+            f[LD::W4 / 4 + i] = p.w4h[i];
             f[LD::WSL / 4 + i] = p.wsl[i];
         }
         if (threadIdx.x < F) {
@@ -805,7 +816,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
         float z[4], zc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-            g.v[f] = p.gx[row * F + f];
+            g.v[f] = NORM ? p.gx[row * F + f] : 1.0f;          // TMDM: y_T = z + mean (tmdm_diffusion_utils.py:109-110)
             mu.v[f] = p.y0hat ? p.y0hat[row * F + f] : 0.0f;
         }
         long long nbase = 0;
@@ -863,8 +874,8 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
             for (int f = 0; f < F; ++f) zv.v[f] = z[f];
             bool ok = true;
             TR(9);
-            Vec<F> yn = chain_step_fast<F, NP>(k, t, y, mu, g, zv, ok TR_ARGS);
-            if (__builtin_expect(!__all(ok), 0)) yn = chain_step_safe<F>(k, t, y, mu, g, zv);
+            Vec<F> yn = chain_step_fast<F, NP, NORM>(k, t, y, mu, g, zv, ok TR_ARGS);
+            if (__builtin_expect(!__all(ok), 0)) yn = chain_step_safe<F, NORM>(k, t, y, mu, g, zv);
             y = yn;
             if (t > 0 && lane < 32) {                       // all reads of this step's rows are done (same wave, in order)
                 *reinterpret_cast<f32x4*>(gam_w + gl) = nx1;
@@ -895,10 +906,10 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
 }
 
 // (trace) every wave: its lifetime in 100 MHz ticks -> min in [10], max in [15]
-template <int F, int NP>
+template <int F, int NP, bool NORM = true>
 int launch_f16_f(mpv_ctx* ctx, const ChainArgs& a, bool philox, int grid) {
-    auto kp = nsdiff_chain_f16_kernel<F, true, NP>;
-    auto kn = nsdiff_chain_f16_kernel<F, false, NP>;
+    auto kp = nsdiff_chain_f16_kernel<F, true, NP, NORM>;
+    auto kn = nsdiff_chain_f16_kernel<F, false, NP, NORM>;
     constexpr int lds = Lds<F>::BYTES;
     if ((size_t)lds > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "device LDS too small for the resident-weight chain kernel");
     MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(philox ? kp : kn),
@@ -928,8 +939,16 @@ extern "C" int mpv_debug_trace(unsigned long long* out16, int reset) {
 }
 #endif
 
-int launch_chain_f16(mpv_ctx* ctx, const chain::ChainArgs& a, bool philox, int grid, int nf, int products) {
+int launch_chain_f16(mpv_ctx* ctx, const chain::ChainArgs& a, bool philox, int grid, int nf, int products, bool tmdm) {
     if (nf < 1 || nf > 3) return mpv_fail(ctx, MPV_EINVAL, "the split-f16 sampler supports nf 1..3 (use MPV_GEMM_F32 for nf = 4)");
+    if (tmdm) {
+        if (products != 3) return mpv_fail(ctx, MPV_EINVAL, "the TMDM sampler supports MPV_GEMM_F16X3 and MPV_GEMM_F32");
+        switch (nf) {
+            case 1: return launch_f16_f<1, 3, false>(ctx, a, philox, grid);
+            case 2: return launch_f16_f<2, 3, false>(ctx, a, philox, grid);
+            default: return launch_f16_f<3, 3, false>(ctx, a, philox, grid);
+        }
+    }
     switch (nf * 10 + products) {
         case 13: return launch_f16_f<1, 3>(ctx, a, philox, grid);
         case 23: return launch_f16_f<2, 3>(ctx, a, philox, grid);

@@ -44,6 +44,7 @@ class TMDM_model(nn.Module):
         self.parallel_sample = net_param.get("parallel_sample", min(10, self.n_z_samples))
         self.scaler = net_param.get("scaler_type", None)
         self.k_z = net_param.get("k_z", 0.01)
+        self.gemm_mode = net_param.get("gemm_mode", "f16x3")         # "f16x3" (split-f16 matrix cores, fp32-equivalent) | "f32" (exact)
         self.noise_source = net_param.get("noise_source", "philox")
         if self.noise_source not in ("philox", "torch_cpu"):
             raise ValueError("noise_source must be 'philox' or 'torch_cpu'")
@@ -134,7 +135,7 @@ class TMDM_model(nn.Module):
             noise = noise.to(device=ctx.device, dtype=torch.float32).contiguous()
         elif seed is None:
             seed = _draw_seed()
-        return ctx.sample_tmdm(prior, S, P, noise=noise, seed=seed or 0, offset=offset)
+        return ctx.sample_tmdm(prior, S, P, noise=noise, seed=seed or 0, offset=offset, gemm=self.gemm_mode)
 
     def evaluation_step(self, batch, y_0_hat: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
         batch_x = batch[:, : self.windows, :]
