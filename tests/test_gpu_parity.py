@@ -233,6 +233,28 @@ def test_philox_mode_replays_through_oracle(nf, steps):
     assert not torch.equal(got, other)
 
 
+@pytest.mark.parametrize("nf,gemms", [(3, ("f16x3", "f32", "f16x2", "f16")), (4, ("f32",))])
+def test_three_and_four_feature_series_against_oracle(nf, gemms):
+    """F = 3 (split-f16 and exact kernels) and F = 4 (exact kernel only; the split-f16 one refuses it) on seeded weights,
+    injected noise, y0hat supplied."""
+    steps = 12
+    sd = O.random_state_dict(nf, steps, 40, 24, 16, seed=77)
+    ctx = make_ctx(sd, nf, steps)
+    g = torch.Generator().manual_seed(2)
+    B, Ol = 5, 7
+    gx = torch.rand(1, B, Ol, nf, generator=g) + 0.1
+    y0 = torch.randn(1, B, Ol, nf, generator=g) * 0.2
+    noise = torch.randn(steps, B, Ol, nf, generator=g)
+    want = O.sample_loop(sd, O.schedule_tables(steps), y0[0], gx[0], y0[0], steps, O.replay_noise(list(noise)))
+    for gemm in gemms:
+        got = ctx.sample(gx.to(dev()), y0.to(dev()), 1, 1, noise=noise.to(dev()), gemm=gemm)[0, :, :, :, 0].cpu()
+        assert rel_err(got, want) < RTOL, (nf, gemm)
+    if nf == 4:
+        from mpv_amd._native import MpvError
+        with pytest.raises(MpvError, match="nf 1..3"):
+            ctx.sample(gx.to(dev()), y0.to(dev()), 1, 1, noise=noise.to(dev()), gemm="f16x3")
+
+
 def test_fast_and_guarded_activation_paths_are_both_exercised(ckpt_wofx):
     """Seeded-init weights prove |pre-activation| < 4 (fast epilogue); scaled-up weights force the guarded one,
     including pre-activations beyond torch's softplus threshold (x > 20)."""
