@@ -226,3 +226,27 @@ def test_gpu_guarded_path_with_large_activations(golden_tmdm):
     for gemm in ("f16x3", "f32"):
         got = ctx.sample_tmdm(prior.to(dev()), 1, 1, noise=noise.to(dev()), gemm=gemm)[0, :, :, :, 0].cpu()
         assert rel_err(got, want) < RTOL, gemm
+
+
+@pytest.mark.gpu
+def test_gpu_harness_window_loop_with_attached_prior(golden_tmdm, tmp_path):
+    """run_evaluation_cache / summarize_pred_future_list drive a TMDM model whose prior is an attached torch module:
+    per-window evaluation_step on the native sampler, MPV from the device reduction == float64 torch on the cache."""
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+    nf, steps = 2, 10
+    m = _model(golden_tmdm, "f2t10", nf, steps, device="cuda:0")
+
+    class Prior(torch.nn.Module):                      # reference call signature (tmdm_adapter.py:122-123)
+        def forward(self, x, x_mark, dec_inp, dec_mark):
+            return None, dec_inp * 0.0 + x.mean(dim=1, keepdim=True), None, None
+
+    m.cond_pred_model = Prior().to("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    series = torch.randn(4, 60, nf, generator=g)
+    wins, tp = H.build_sliding_windows(series, np.arange(60) * 0.1, m.windows, 10)
+    preds = H.run_evaluation_cache(m, list(wins), m.pred_len, tmp_path / "c.pt", torch.device("cuda", 0), force_recompute=True)
+    assert len(preds) == len(wins) and tuple(preds[0].shape) == (4, m.pred_len, nf, m.n_z_samples)
+    pm, ews = H.summarize_pred_future_list(preds, model=m)
+    want = torch.stack([p.double().var(dim=-1, unbiased=False).mean() for p in preds])
+    assert rel_err(torch.tensor(np.array(ews, dtype=np.float64)), want) < 1e-5
+    assert len(H._load_tensor_list(tmp_path / "c.pt")) == len(wins)

@@ -307,6 +307,25 @@ def _sample_stacked(model, window_list, pred_len, scale: bool):
     lo, hi = dist_utils.shard_bounds(len(window_list))
     preds: List[torch.Tensor] = []
     mpv_parts, mean_parts = [], []
+    if not hasattr(model, "_prior_variance"):
+        # a model family without the stacked NsDiff entry (TMDM: its prior is the caller's torch module): the reference's
+        # own window loop, one evaluation_step per window (still the native sampler), then the device reduction
+        inv_std = model.scaler_std.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
+        inv_mean = model.scaler_mean.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
+        for w in window_list[lo:hi]:
+            x = torch.as_tensor(w).float()
+            if scale:
+                x = model.scaler_transform(x.to(model.scaler_mean.device))
+            outs, _ = model.evaluation_step(x)
+            outs = outs[:, -pred_len:].contiguous()
+            mpv, pm, _ = ctx.reduce(outs.to(ctx.device).unsqueeze(0).contiguous(), inv_std, inv_mean)
+            mpv_parts.append(mpv)
+            mean_parts.append(pm)
+            preds.append(outs.cpu())
+        mpv_local = torch.cat(mpv_parts) if mpv_parts else torch.zeros(0, device=ctx.device)
+        mean_local = torch.cat(mean_parts) if mean_parts else torch.zeros(0, device=ctx.device)
+        mpv_all, mean_all = dist_utils.gather_curve(len(window_list), lo, hi, mpv_local, mean_local)
+        return preds, mpv_all, mean_all
     chunk = _windows_per_launch(model, V)
     inv_std = model.scaler_std.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
     inv_mean = model.scaler_mean.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
