@@ -267,3 +267,36 @@ def test_backbone_plumbing_without_gpu(ckpt_wofx):
             m.evaluation_step(batch)
     with pytest.raises(NotImplementedError):
         diffusion_models("NsDiff", dict(net, load_pretrain=False), train_model_select="pretrain_f")
+
+
+def test_model_hook_runs_before_the_state_dict_is_loaded(tmp_path, ckpt_wofx):
+    """utils.MODEL_HOOK / model_hook=: attach a backbone first, then its checkpoint entries load strictly."""
+    from mpv_amd.models.models import diffusion_models
+    from mpv_amd.utils import utils as U
+    net = dict(device="cpu", scaler_type="StandardScaler", task_model="NsDiff_model_variants", rolling_length=100,
+               diffusion_schedule="linear", diffusion_steps=20, beta_start=1e-4, beta_end=0.02, n_z_samples=4, parallel_sample=2,
+               windows=200, pred_len=200, dataset_nf=2)
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.projection = torch.nn.Linear(8, 2, bias=False)
+
+    m = diffusion_models("NsDiff_model_variants", dict(net), train_model_select="wo_UANS").attach_backbone(Stub())
+    with torch.no_grad():
+        m.cond_pred_model.projection.weight.fill_(0.25)
+    own = set(m.state_dict())
+    m.load_state_dict({**{k: v for k, v in ckpt_wofx.items() if k in own}, "cond_pred_model.projection.weight": torch.full((2, 8), 0.25)})
+    U.save_checkpoint(str(tmp_path), "model_trained", m, dict(net))
+    seen = []
+    hook = lambda model: (seen.append(type(model).__name__), model.attach_backbone(Stub()))
+    got, _ = U.load_diffusion_model(str(tmp_path / "model_trained"), "cpu", train_model_select="wo_UANS", model_hook=hook)
+    assert seen == ["NsDiff_model_variants"] and float(got.cond_pred_model.projection.weight.mean()) == 0.25
+    U.MODEL_HOOK = hook
+    try:
+        got2, _ = U.load_diffusion_model(str(tmp_path / "model_trained"), "cpu", train_model_select="wo_UANS")
+        assert float(got2.cond_pred_model.projection.weight.mean()) == 0.25
+    finally:
+        U.MODEL_HOOK = None
+    plain, _ = U.load_diffusion_model(str(tmp_path / "model_trained"), "cpu", train_model_select="wo_UANS")    # no hook: entries dropped
+    assert plain.cond_pred_model is None

@@ -11,12 +11,18 @@ def save_checkpoint(path: str, model_name: str, model, net_param):
     torch.save({"net_param": net_param, "state_dict": model.state_dict()}, os.path.join(path, model_name))
 
 
+# Optional callable(model) run after construction and BEFORE the state dict is loaded -- the place to attach a
+# caller-supplied f(x) backbone (`model.attach_backbone(...)`) so that its `cond_pred_model.*` checkpoint entries load too.
+# Module-level so that the harness entry points (which load models internally) pick it up without new arguments.
+MODEL_HOOK = None
+
+
 def load_diffusion_model(path: str, device, infer_para=None, dataparallel=True, **kwargs):
     """Checkpoint file -> (model on `device`, merged net_param).
 
     `infer_para` is merged into net_param BEFORE the model is constructed, `module.` prefixes
     left by DataParallel training are stripped, the state dict is loaded strictly
-    (reference :660-689).
+    (reference :660-689).  `MODEL_HOOK` (above) or `model_hook=` runs between construction and loading.
     """
     with open(path, "rb") as f:
         state = torch.load(f, map_location="cpu")
@@ -29,5 +35,8 @@ def load_diffusion_model(path: str, device, infer_para=None, dataparallel=True, 
     net_param["device"] = device
     model = diffusion_models(task_model=net_param["task_model"], net_param=net_param,
                              train_model_select=kwargs["train_model_select"]).to(device)
+    hook = kwargs.get("model_hook") or MODEL_HOOK
+    if hook is not None:
+        hook(model)
     model.load_state_dict(state_dict, strict=True)
     return model.to(device), net_param
