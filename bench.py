@@ -69,31 +69,70 @@ def build_model(device, series):
     return synthetic.seeded_nsdiff_state(model, series, seed=123)
 
 
+def launch_workers(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh worker processes (one per GPU) BEFORE anything in this
+    process touches the GPU, relay rank 0's JSON line, fail if any worker fails.  Nothing is exec'd."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MPV_BENCH_WORKER="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print("bench workers failed: " + ", ".join("rank %d rc %d" % rc for rc in bad), file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=("c2", "c3"), default="c2",
+                    help="c2 (default, the headline): NsDiff 100-node biomass, N=32, T=50; c3: DiffusionTS 100-node SIS, N=32, T=100")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-windows", type=int, default=1, help="windows of the workload timed on the CPU oracle")
+    ap.add_argument("--cpu-windows", type=int, default=4, help="windows of the workload timed on the CPU oracle (each ~25 s on 16 threads)")
     ap.add_argument("--gemm", choices=("f16x3", "f32", "f16x2", "f16"), default="f16x3",
                     help="evaluation of the two 128x128 layers for the HEADLINE number: split-f16 matrix cores, fp32-equivalent "
                          "(default), exact fp32 MFMA, or the reduced-precision operand modes f16x2 / f16 (fp32 accumulate)")
     ap.add_argument("--host-data", action="store_true",
                     help="generate the synthetic trajectory with the numpy Euler-Maruyama on the host instead of the HIP kernel")
     ap.add_argument("--no-other-modes", action="store_true",
-                    help="skip the extra, separately reported runs of the reduced-precision operand modes (N=1 only)")
+                    help="skip the extra, separately reported runs (other GEMM modes, sample-writing path, trained checkpoints; N=1 only)")
+    ap.add_argument("--store-samples", action="store_true",
+                    help="headline step writes the [W,V,O,F,S] sample tensor and reduces it in a second kernel (the round-1 path)")
     ap.add_argument("--max-windows", type=int, default=None, help="profiling aid: cut the trajectory to this many windows "
                     "(the reported metric is then NOT the BASELINE workload and says so)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: rehearse the N>1 launch path on a 1-GPU box")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_workers(args))
+    if args.config == "c3":
+        from mpv_amd.bench_dts import main_c3
+        return main_c3(args, log)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus {} but WORLD_SIZE={}: launch with torch.distributed.run".format(args.gpus, world))
+        raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device: the path has no CPU implementation")
+    if args.backend == "gloo":                                     # rehearsal: every rank on the one visible device
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("MPV_BENCH_FORCE_DIST") == "1"     # force: smoke the RCCL path on one GPU
@@ -102,7 +141,10 @@ def main():
             del os.environ["NCCL_DEBUG"]                             # exactly one line there, the JSON record
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from mpv_amd import synthetic
     from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
@@ -133,15 +175,23 @@ def main():
     mean_dev, std_dev = model.scaler_mean.float().contiguous(), model.scaler_std.float().contiguous()
     S, P = CFG["n_z"], CFG["parallel_sample"]
 
-    def step(seed, gemm=args.gemm):
+    def step(seed, gemm=args.gemm, store=args.store_samples):
         gx = ctx.sigma_head(series_dev, n_windows, 0, CFG["window_step"], mean_dev, std_dev, add_eps=model.EPS)
-        samples = ctx.sample(gx, None, S, P, seed=seed, gemm=gemm)
-        mpv, pm, _ = ctx.reduce(samples, std_dev, mean_dev)
+        if store:      # sample tensor to HBM (232 MB), then the stand-alone reduction re-reads it
+            samples = ctx.sample(gx, None, S, P, seed=seed, gemm=gemm)
+            mpv, pm, _ = ctx.reduce(samples, std_dev, mean_dev)
+        else:          # summary fused into the sampler's epilogue: no sample tensor at all
+            _, mpv, pm, _ = ctx.sample(gx, None, S, P, seed=seed, gemm=gemm, summary=True, want_samples=False, std=std_dev, mean=mean_dev)
         curve = torch.stack([mpv, pm])                                                      # [2, W]
         if use_dist:
-            out = torch.empty(world, 2, n_windows, device=device)
-            dist.all_gather_into_tensor(out, curve)
-            curve = out
+            if args.backend == "nccl":
+                out = torch.empty(world, 2, n_windows, device=device)
+                dist.all_gather_into_tensor(out, curve)
+                curve = out
+            else:
+                parts = [torch.empty(2, n_windows) for _ in range(world)]
+                dist.all_gather(parts, curve.cpu())
+                curve = torch.stack(parts)
         return curve.cpu()                                                                   # host copy = sync
 
     def fence():
@@ -149,23 +199,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    def timed(n_steps, seed0, **kw):
+        ctx.timing_enable(True)
+        ctx.timing()                                                                         # drop earlier records
+        fence()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            curve = step(seed0 + i, **kw)
+        fence()
+        dt = time.perf_counter() - t0
+        kms, n = ctx.timing()
+        ctx.timing_enable(False)
+        return dt, kms, n, curve
+
     log("%d windows resident; warmup" % n_windows)
     for i in range(args.warmup):
         step(i)
         log("warmup step %d done" % i)
-    ctx.timing_enable(True)
-    ctx.timing()                                                                             # drop warmup records
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        curve = step(100 + i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, launches = ctx.timing()
-    ctx.timing_enable(False)
+    elapsed, kernel_ms, launches, curve = timed(args.steps, 100)
     log("timed %d steps in %.3f s; chain kernel avg %.2f ms" % (args.steps, elapsed, kernel_ms))
     if use_dist:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert bool(torch.isfinite(curve).all()), "non-finite MPV curve"
@@ -185,34 +239,36 @@ def main():
                                "windows=100, pred_len=100, rolling=50, N=32 samples, T=50 steps, {} windows per "
                                "trajectory, one trajectory per GPU per step".format(n_windows),
                    "windows_per_step_per_gpu": n_windows, "truncated_for_profiling": args.max_windows is not None, "noise": "on-device Philox4x32-10",
-                   "weights": "seeded default init (shipped checkpoints pin T=20)"},
-        "roofline": roofline(args.gemm, achieved, kernel_ms, launches, flop_per_launch, n_windows),
+                   "weights": "seeded default init (shipped checkpoints pin T=20)",
+                   "summary": "sample tensor written + stand-alone reduction" if args.store_samples else
+                              "MPV reduction fused into the sampler epilogue, no sample tensor",
+                   "parallelism": "windows sharded over %d rank(s), one all-gather of the curve" % world},
+        "roofline": roofline(args.gemm, achieved, kernel_ms, launches, flop_per_launch, n_windows, args.store_samples),
     }
 
-    # ---- reduced-precision operand modes, reported separately; never the headline unless --gemm asks
-    others = [] if (world > 1 or args.no_other_modes) else [g for g in ("f16x2", "f16") if g != args.gemm]
+    # ---- separately reported runs: the other GEMM modes, the sample-writing path; never the headline
+    extras = world == 1 and not args.no_other_modes
+    others = [g for g in ("f32", "f16x2", "f16") if g != args.gemm] if extras else []
     other_modes = {}
     for g in others:
-        n_steps = max(1, min(args.steps, 3))
-        step(7, g)
-        ctx.timing_enable(True)
-        ctx.timing()
-        fence()
-        t0 = time.perf_counter()
-        for i in range(n_steps):
-            step(200 + i, g)
-        fence()
-        dt = time.perf_counter() - t0
-        kms, _ = ctx.timing()
-        ctx.timing_enable(False)
-        products = {"f16x2": 2, "f16": 1}[g]
+        n_steps = max(1, min(args.steps, 3 if g != "f32" else 2))
+        step(7, gemm=g)
+        dt, kms, _, _ = timed(n_steps, 200, gemm=g)
+        products = {"f16x2": 2, "f16": 1, "f32": 0}[g]
+        peak = FP32_MATRIX_PEAK_TFLOPS if g == "f32" else F16_MATRIX_PEAK_TFLOPS / products
+        ach = flop_per_launch / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         other_modes[g] = {"value": n_windows * n_steps / dt, "unit": "windows/s", "steps": n_steps, "ms_per_step": dt / n_steps * 1e3,
-                          "dtype": DTYPES[g], "kernel_avg_ms": kms,
-                          "achieved_tflops": flop_per_launch / (kms * 1e-3) / 1e12 if kms > 0 else 0.0,
-                          "mfma_peak_tflops": F16_MATRIX_PEAK_TFLOPS / products}
+                          "dtype": DTYPES[g], "kernel_avg_ms": kms, "achieved_tflops": ach, "mfma_peak_tflops": peak, "frac": ach / peak}
         log("mode %s: %.1f windows/s" % (g, other_modes[g]["value"]))
     if other_modes:
         out["other_modes"] = other_modes
+    if extras:
+        step(8, store=not args.store_samples)
+        dt, kms, _, _ = timed(3, 300, store=not args.store_samples)
+        out["other_summary_path"] = {"summary": "sample tensor written + stand-alone reduction" if not args.store_samples else "fused",
+                                     "value": n_windows * 3 / dt, "unit": "windows/s", "kernel_avg_ms": kms}
+        log("other summary path: %.1f windows/s" % out["other_summary_path"]["value"])
+        out["trained_checkpoints"] = trained_checkpoint_records(device)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         parity = cpu_baseline_and_parity(model, sampled, args.cpu_windows, [args.gemm] + others)
@@ -226,6 +282,45 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def trained_checkpoint_records(device):
+    """Secondary records on TRAINED weights: both shipped sampler checkpoints (T = 20; committed as data under tests/golden/)
+    on a C2-like batch (100 nodes, N = 32), with the device counter of reverse steps that failed the split-f16 kernel's
+    end-of-step guard and were re-run through the exact routine."""
+    from mpv_amd.models.models import diffusion_models
+    recs = {}
+    for tag, nf, rolling in (("wofx", 2, 100), ("sim", 1, 50)):
+        path = ROOT / "tests" / "golden" / ("ckpt_%s.npz" % tag)
+        if not path.exists():
+            continue
+        z = np.load(path)
+        sd = {k: torch.from_numpy(z[k]) for k in z.files}
+        net = dict(device=device, scaler_type="StandardScaler", task_model="NsDiff_model_variants", rolling_length=rolling,
+                   diffusion_schedule="linear", diffusion_steps=20, beta_start=1e-4, beta_end=0.02, n_z_samples=32,
+                   parallel_sample=32, windows=200, pred_len=200, dataset_nf=nf)
+        m = diffusion_models("NsDiff_model_variants", net, train_model_select="cond_var").to(device)
+        m.load_state_dict({k: sd[k] for k in m.state_dict()}, strict=True)
+        m.eval()
+        g = torch.Generator().manual_seed(5)
+        W = 16
+        series = (torch.cumsum(torch.randn(100, 200 + 5 * (W - 1), nf, generator=g) * 0.1, dim=1)).to(device)
+        c = m.native_context()
+        m.sample_windows(series, W, 0, 5, seed=1, summary=True, want_samples=False)
+        c.chain_stats(reset=True)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(3):
+            _, _, mpv, _ = m.sample_windows(series, W, 0, 5, seed=2 + i, summary=True, want_samples=False)
+        mpv = mpv.cpu()
+        dt = time.perf_counter() - t0
+        steps, safe = c.chain_stats()
+        recs[tag] = {"checkpoint": "ews_results/%s" % ("NsDiff_machine/wo_fx" if tag == "wofx" else "real_data/model/simulation"),
+                     "shape": "100 nodes, F=%d, windows=pred_len=200, N=32, T=20, %d windows per launch" % (nf, W),
+                     "value": 3 * W / dt, "unit": "windows/s", "tile_steps": steps, "safe_steps": safe,
+                     "finite": bool(torch.isfinite(mpv).all())}
+        log("trained checkpoint %s: %.1f windows/s, %d of %d tile-steps through the exact routine" % (tag, recs[tag]["value"], safe, steps))
+    return recs
 
 
 DTYPES = {"f32": "f32",
@@ -250,7 +345,7 @@ def measured_traffic(kernel, n_windows):
     return None
 
 
-def roofline(gemm, achieved, kernel_ms, launches, flop_per_launch, n_windows):
+def roofline(gemm, achieved, kernel_ms, launches, flop_per_launch, n_windows, store_samples=False):
     """`achieved` = algorithmic TFLOP/s of the chain kernel (256*(256+5F) flop per chain-step)."""
     if gemm == "f32":
         return {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -268,7 +363,7 @@ def roofline(gemm, achieved, kernel_ms, launches, flop_per_launch, n_windows):
                 "peak_source": "dense f16 MFMA peak 2500 TFLOP/s / %d MFMA products per algorithmic product" % products,
                 "note": "reduced-precision operand mode; live bound is vector-instruction issue (DESIGN.md 3.1)"}
     peak = F16_MATRIX_PEAK_TFLOPS / 3.0
-    tr = measured_traffic("nsdiff_chain_f16_kernel<1,true>", n_windows)
+    tr = measured_traffic("nsdiff_chain_f16_kernel<1,true>" + ("" if store_samples else " fused"), n_windows)
     return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": (tr or {}).get("hbm_bytes_per_launch"), "traffic_detail": tr, "kernel": "nsdiff_chain_f16_kernel<1,true>",
             "kernel_avg_ms": kernel_ms, "launches": launches,
@@ -291,15 +386,18 @@ def cpu_baseline_and_parity(model, sampled, n_cpu_windows, modes):
     cfg = O.NsDiffConfig(CFG["windows"], CFG["pred_len"], CFG["nf"], CFG["rolling"], CFG["steps"],
                          n_z_samples=CFG["n_z"], parallel_sample=CFG["parallel_sample"])
     wins = [sampled[:, w * CFG["window_step"]: w * CFG["window_step"] + CFG["windows"], :] for w in range(n_cpu_windows)]
-    rec, cpu_mpv, cpu_out = [], [], []
+    rec, cpu_mpv, cpu_out, per_window_s = [], [], [], []
     torch.manual_seed(2024)
     t0 = time.perf_counter()
     with torch.no_grad():
         for w in wins:
+            t1 = time.perf_counter()
             x = O.scale(w, sd["scaler_mean"], sd["scaler_std"])
             outs = O.evaluation_step(sd, cfg, x, record=rec)
             cpu_out.append(outs)
             cpu_mpv.append(O.mpv_network(outs, sd["scaler_mean"], sd["scaler_std"])[1])
+            per_window_s.append(time.perf_counter() - t1)
+            log("cpu baseline window %d: %.1f s" % (len(per_window_s), per_window_s[-1]))
     cpu_s = time.perf_counter() - t0
     log("cpu baseline done in %.1f s" % cpu_s)
     # same windows on the GPU with the very noise the CPU run consumed (reference draw order)
@@ -315,8 +413,9 @@ def cpu_baseline_and_parity(model, sampled, n_cpu_windows, modes):
             x = O.scale(w, sd["scaler_mean"], sd["scaler_std"])
             outs, _ = model.evaluation_step(x, noise=noise)
             samp_err = max(samp_err, float((outs - cpu_out[i]).abs().max() / cpu_out[i].abs().max()))
-            mpv, _, _ = ctx.reduce(outs.to(ctx.device).unsqueeze(0).contiguous(), model.scaler_std.float().contiguous(),
-                                   model.scaler_mean.float().contiguous())
+            # the MPV as the bench step forms it: fused into the sampler's epilogue, same injected noise
+            z6 = noise.reshape(1, -1, CFG["steps"], x.shape[0] * CFG["parallel_sample"], CFG["pred_len"], CFG["nf"])
+            _, _, mpv, _ = model.sample_windows(x, 1, 0, 1, noise=z6, summary=True, want_samples=False)
             gpu_mpv.append(float(mpv[0]))
         gpu_mpv = np.array(gpu_mpv)
         per_mode[gemm] = {"mpv_max_abs_err": float(np.abs(gpu_mpv - cpu_mpv).max()),
@@ -325,8 +424,10 @@ def cpu_baseline_and_parity(model, sampled, n_cpu_windows, modes):
     model.gemm_mode = modes[0]
     return {
         "cpu_baseline": {"value": n_cpu_windows / cpu_s, "unit": "windows/s", "cores": cores, "kind": "port",
+                         "best_window_value": 1.0 / min(per_window_s), "per_window_s": [round(t, 2) for t in per_window_s],
                          "sample": "first {} of the 181 windows, full N=32 x T=50, oracle/nsdiff_oracle.py "
-                                   "(torch CPU fp32 port of the reference eager path), {:.1f} s".format(n_cpu_windows, cpu_s)},
+                                   "(torch CPU fp32 port of the reference eager path), {:.1f} s in all; value = windows / total, "
+                                   "best_window_value = 1 / fastest window".format(n_cpu_windows, cpu_s)},
         "per_mode": per_mode,
     }
 

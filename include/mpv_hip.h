@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MPV_ABI_VERSION 1
+#define MPV_ABI_VERSION 2
 
 #define MPV_OK 0
 #define MPV_EINVAL (-1)   /* bad argument / unsupported shape            */
@@ -115,7 +115,7 @@ typedef struct {
  *  15 sa   = sqrt(a)                                gamma_1 = sa*Sigma_2/D
  *  16 k1   = sa*(a-1)                               gamma_2 = (k1*Sigma_2 + k2*Sigma_1)/D
  *  17 k2   = 1-sp
- *  18,19 reserved: filled by mpv_nsdiff_load (bound coefficients of the layer-1 pre-activation)
+ *  18,19 unused (zero)
  */
 int mpv_nsdiff_load(mpv_ctx* ctx, const mpv_nsdiff_desc* desc, const mpv_nsdiff_weights* host_weights,
                     const float* host_coef);
@@ -131,6 +131,28 @@ typedef struct {
     uint64_t offset;      /* Philox stream offset (counter word 3) when noise == NULL              */
 } mpv_sample_shape;
 
+/* Outputs of a sampling call.  Every pointer is nullable; at least one of `samples` / `mpv` must be given.
+ *   samples  : dev [W][B][O][F][S] -- window w's slice is the reference's `outs` [B, pred_len, F, n_z_samples]
+ *              (NsDiff_model.py:262-266).  NULL = do not write the sample tensor at all (curve-only runs: the
+ *              reference keeps it only to feed summarize_pred_future_list).
+ *   mpv      : dev [W]    mean over (b,o,f) of the population variance over s of x = y*std + mean
+ *   pred_mean: dev [W]    mean of x over everything          (summarize_pred_future_list,
+ *   mpv_feat : dev [W][F] the variance mean per feature       diffusion_model_uncertainy.py:286-303, 529-538)
+ *   std/mean : dev [F] inverse scaling applied inside the summary only (_feature_inverse_transform :267-283), or both NULL.
+ * With the split-f16 sampler (gemm != MPV_GEMM_F32, nf <= 3) and S a power of two <= 32 or a multiple of 32 the summary
+ * is fused into the sampler's epilogue: a wave's 32 chains are whole (b,o,f) rows, sum x and sum x^2 are formed by
+ * wavefront shuffles in fp64, accumulated per workgroup in LDS and flushed once per workgroup; nothing but W*F*16 bytes
+ * per workgroup leaves the chip when samples == NULL.  Otherwise the library samples into a context-private workspace
+ * (or `samples`) and runs mpv_reduce on it. */
+typedef struct {
+    float* samples;
+    float* mpv;
+    float* pred_mean;
+    float* mpv_feat;
+    const float* std;
+    const float* mean;
+} mpv_sample_out;
+
 /* y0hat : dev [W][B][O][F] prior mean f(x) (= y_T_mean), or NULL for zeros (cond_var / Guassian).
  * gx    : dev [W][B][O][F] prior variance g(x) (already + EPS where the variant adds it).
  * noise : dev, or NULL.  When given it holds every normal draw of the reference in the
@@ -143,16 +165,15 @@ typedef struct {
  *         the four output words.  Draw k, feature f uses normal (k*F+f)&3 of block (k*F)>>2
  *         when F is 1 or 2 (all four normals of a block are consumed), normal f of block k
  *         when F is 3 or 4.
- * samples: dev [W][B][O][F][S] -- window w's slice is the reference's `outs`
- *         [B, pred_len, F, n_z_samples] (NsDiff_model.py:262-266).
+ * out   : see mpv_sample_out.
  */
 int mpv_nsdiff_sample(mpv_ctx* ctx, const mpv_sample_shape* shape, const float* y0hat, const float* gx,
-                      const float* noise, float* samples);
+                      const float* noise, const mpv_sample_out* out);
 
-/* Bound on |pre-activation| of layers 2 and 3 proved at load time from the weights
- * (max |gamma| (||W_row||_2 + |b|); the layer input has unit 2-norm).  Below 4 the f16x3 kernel
- * drops the exp-overflow / log1p small-argument guards of those layers (validation aid). */
-int mpv_nsdiff_preact_bound(mpv_ctx* ctx, float* bound);
+/* Counters of the split-f16 sampler since the last reset (synchronises the stream): tile_steps = reverse steps executed
+ * (one per 32-chain tile per t), safe_steps = how many of them failed the end-of-step range guard and were re-run
+ * through the exact out-of-line routine (nsdiff_chain_f16.hip::chain_step_safe). */
+int mpv_chain_stats(mpv_ctx* ctx, uint64_t* tile_steps, uint64_t* safe_steps, int reset);
 
 /* ------------------------------------------------------------------------------------
  * TMDM sampler (CARD-style reverse process around a supplied prior mean)
@@ -166,11 +187,11 @@ int mpv_nsdiff_preact_bound(mpv_ctx* ctx, float* bound);
  *       3..5 gamma_0..2, 6 sqrt(beta_hat_t)  (tmdm_diffusion_utils.py:69-88), rest 0.
  * mpv_tmdm_sample: shape->pred_len is the SEQUENCE length the sampler runs on (label_len + pred_len);
  * y0hat dev [W][B][L][F]; noise as in mpv_nsdiff_sample (draw 0 = z_T, then one per step t = T-1..1);
- * samples dev [W][B][L][F][S]; shape->gemm is MPV_GEMM_F16X3 (nf <= 3; the same tile-pipelined kernel as NsDiff with
+ * out as in mpv_nsdiff_sample (samples dev [W][B][L][F][S]); shape->gemm is MPV_GEMM_F16X3 (nf <= 3; the same tile-pipelined kernel as NsDiff with
  * the normalisation switched off) or MPV_GEMM_F32.
  * ---------------------------------------------------------------------------------- */
 int mpv_tmdm_load(mpv_ctx* ctx, const mpv_nsdiff_desc* desc, const mpv_nsdiff_weights* host_weights, const float* host_coef);
-int mpv_tmdm_sample(mpv_ctx* ctx, const mpv_sample_shape* shape, const float* y0hat, const float* noise, float* samples);
+int mpv_tmdm_sample(mpv_ctx* ctx, const mpv_sample_shape* shape, const float* y0hat, const float* noise, const mpv_sample_out* out);
 
 /* ------------------------------------------------------------------------------------
  * Synthetic input generation on device (the step before the path)

@@ -57,3 +57,105 @@ def test_block_bounds_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
     assert not D.active() and D.rank() == 0 and D.world_size() == 1 and D.shard_bounds(5) == (0, 5)
+
+
+# ---- the harness itself under sharding: run_evaluation_cache / run_slbp_sensitivity_cache with the CPU oracle injected ----
+def _tiny_model(noise_source):
+    from mpv_amd.models.models import diffusion_models
+    from oracle import nsdiff_oracle as O
+    sd = O.random_state_dict(1, 6, 24, 12, 8, seed=4)
+    sd["scaler_mean"], sd["scaler_std"] = torch.tensor([0.3]), torch.tensor([1.7])
+    net = dict(device="cpu", scaler_type="StandardScaler", task_model="NsDiff_model_variants", rolling_length=8,
+               diffusion_schedule="linear", diffusion_steps=6, beta_start=1e-4, beta_end=0.02, n_z_samples=4, parallel_sample=2,
+               windows=24, pred_len=12, dataset_nf=1, noise_source=noise_source)
+    model = diffusion_models("NsDiff_model_variants", net, train_model_select="cond_var")
+    model.load_state_dict(sd, strict=True)
+    return model.eval(), sd, O.NsDiffConfig(24, 12, 1, 8, 6, n_z_samples=4, parallel_sample=2)
+
+
+def _oracle_shard(sd, cfg):
+    """The CPU oracle as the per-shard computation (same contract as the harness's device shard)."""
+    from oracle import nsdiff_oracle as O
+
+    def compute(model, windows, pred_len, scale):
+        V = int(windows[0].shape[0])
+        outs, mpv, pm = [], [], []
+        for w in windows:
+            x = torch.as_tensor(w).float()
+            if scale:
+                x = O.scale(x, sd["scaler_mean"], sd["scaler_std"])
+            if model.noise_source == "torch_cpu":                # the reference's draw order from the shared CPU stream
+                z = model.host_noise(1, V)[0]                    # [C, T, V*P, O, F]
+                noise = O.replay_noise([z[c, k] for c in range(z.shape[0]) for k in range(z.shape[1])])
+            else:                                                # any per-window deterministic stream
+                g = torch.Generator().manual_seed(int(torch.as_tensor(w).double().abs().sum().item() * 1e6) % (2 ** 31))
+                noise = lambda shape, g=g: torch.randn(shape, generator=g)
+            o = O.evaluation_step(sd, cfg, x, noise=noise)[:, -pred_len:]
+            m, v = O.mpv_network(o, sd["scaler_mean"], sd["scaler_std"])
+            outs.append(o)
+            mpv.append(v)
+            pm.append(m)
+        return torch.stack(outs), torch.tensor(mpv, dtype=torch.float32), torch.tensor(pm, dtype=torch.float32)
+    return compute
+
+
+def _series(n_windows):
+    g = torch.Generator().manual_seed(77)
+    s = torch.cumsum(torch.randn(3, 24 + 5 * (n_windows - 1), 1, generator=g) * 0.1, dim=1) + 1.0
+    return s, np.arange(s.shape[1], dtype=np.float32) * 0.1
+
+
+def _harness_worker(rank, world, port, n_windows, noise_source, out_dir):
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+        model, sd, cfg = _tiny_model(noise_source)
+        H.SHARD_COMPUTE = _oracle_shard(sd, cfg)
+        series, time = _series(n_windows)
+        views, tp = H.build_sliding_windows(series, time, 24, 5)
+        assert len(views) == n_windows
+        cache = os.path.join(out_dir, "w%d_cache.pt" % world)
+        torch.manual_seed(5)
+        preds = H.run_evaluation_cache(model, views, 12, cache, "cpu", force_recompute=True)
+        assert len(preds) == n_windows                                         # one entry per window on EVERY rank
+        pm, ews = H.summarize_pred_future_list(preds, model=model)
+        assert len(ews) == n_windows
+        torch.save({"preds": list(preds), "ews": np.array(ews, dtype=np.float64), "pm": np.array(pm, dtype=np.float64)},
+                   os.path.join(out_dir, "w%d_r%d.pt" % (world, rank)))
+        # single-series (SLBP) variant through the same sharded path
+        slbp = [v[0] for v in views]
+        torch.manual_seed(6)
+        sl = H.run_slbp_sensitivity_cache(model, slbp, os.path.join(out_dir, "w%d_slbp.pt" % world), "cpu", force_recompute=True)
+        assert len(sl) == n_windows and tuple(sl[0].shape) == (12, 1, 4)
+        if world > 1:
+            dist.barrier()
+    finally:
+        H.SHARD_COMPUTE = None
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("noise_source", ["philox", "torch_cpu"])
+@pytest.mark.parametrize("world,n_windows", [(2, 5), (3, 2)])
+def test_sharded_harness_cache_equals_unsharded(tmp_path, world, n_windows, noise_source):
+    """run_evaluation_cache under world>1 (gloo): the cache file and pred_future_list hold ALL windows, equal the
+    single-process cache, and the curve is the same; noise_source='torch_cpu' replays ONE reference stream across ranks."""
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+    _harness_worker(0, 1, 0, n_windows, noise_source, str(tmp_path))
+    mp.spawn(_harness_worker, args=(world, _free_port(), n_windows, noise_source, str(tmp_path)), nprocs=world, join=True)
+    one = torch.load(tmp_path / "w1_r0.pt", weights_only=False)
+    cache_one = H._load_tensor_list(tmp_path / "w1_cache.pt")
+    cache_n = H._load_tensor_list(tmp_path / ("w%d_cache.pt" % world))
+    assert len(cache_one) == len(cache_n) == n_windows
+    assert all(torch.equal(a, b) for a, b in zip(cache_one, cache_n))
+    assert H.infer_sample_window_step_from_cache(24 + 5 * (n_windows - 1), 24, len(cache_n), 5) == 5
+    for r in range(world):
+        got = torch.load(tmp_path / ("w%d_r%d.pt" % (world, r)), weights_only=False)
+        assert all(torch.equal(a, b) for a, b in zip(one["preds"], got["preds"]))
+        np.testing.assert_array_equal(one["ews"], got["ews"])
+        np.testing.assert_array_equal(one["pm"], got["pm"])
+    slbp_one = H._load_tensor_list(tmp_path / "w1_slbp.pt")
+    slbp_n = H._load_tensor_list(tmp_path / ("w%d_slbp.pt" % world))
+    assert len(slbp_n) == n_windows and all(torch.equal(a, b) for a, b in zip(slbp_one, slbp_n))

@@ -19,9 +19,15 @@ def dev():
 
 
 def rel_err(got, want):
+    """ELEMENTWISE relative error with a floor of a tenth of the tensor's RMS: `rel_err < 1e-4` means
+    |got - want| <= 1e-4 |want| + 1e-5 rms(want) for every element (small-magnitude samples are constrained to 1e-5 of the
+    typical magnitude, not just to 1e-4 of the largest one)."""
     got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, dtype=np.float64)
     want = want.detach().cpu().double().numpy() if isinstance(want, torch.Tensor) else np.asarray(want, dtype=np.float64)
-    return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+    if want.size == 0:
+        return 0.0
+    floor = 0.1 * float(np.sqrt(np.mean(np.square(want)))) + 1e-30
+    return float((np.abs(got - want) / (np.abs(want) + floor)).max())
 
 
 def make_ctx(sd, nf, steps, sigma=None):
@@ -260,13 +266,11 @@ def test_fast_and_guarded_activation_paths_are_both_exercised(ckpt_wofx):
     including pre-activations beyond torch's softplus threshold (x > 20)."""
     sd = O.random_state_dict(1, 10, 100, 100, 50, seed=5)
     ctx = make_ctx(sd, 1, 10)
-    assert ctx.preact_bound() < 4.0
     big, huge = dict(sd), dict(sd)
     for i in (2, 3):
         big[O.EPS_NET + "lin%d.lin.weight" % i] = sd[O.EPS_NET + "lin%d.lin.weight" % i] * 60.0
         huge[O.EPS_NET + "lin%d.lin.weight" % i] = sd[O.EPS_NET + "lin%d.lin.weight" % i] * 400.0     # 2^x' overflows fp32
     ctx_big, ctx_huge = make_ctx(big, 1, 10), make_ctx(huge, 1, 10)
-    assert ctx_big.preact_bound() > 20.0 and ctx_huge.preact_bound() > 128.0
     g = torch.Generator().manual_seed(9)
     gx = (torch.rand(1, 4, 6, 1, generator=g) + 0.1)
     noise = torch.randn(10, 4, 6, 1, generator=g)
@@ -280,6 +284,12 @@ def test_fast_and_guarded_activation_paths_are_both_exercised(ckpt_wofx):
                 assert rel_err(got, want) < RTOL, gemm
             else:
                 assert bool(torch.isfinite(got).all())
+    # the device counter says which routine ran: default-init weights stay on the fast path, the 2^x'-overflowing ones
+    # fall through to the exact routine on (nearly) every step
+    steps, safe = ctx.chain_stats()
+    assert steps > 0 and safe == 0, (steps, safe)
+    steps_h, safe_h = ctx_huge.chain_stats()
+    assert safe_h > 0 and safe_h <= steps_h, (steps_h, safe_h)
 
 
 def test_ragged_and_empty_batches():
@@ -487,22 +497,152 @@ def test_c_abi_error_paths():
     assert lib.mpv_ctx_create(9999, None, C.byref(h)) < 0 and not h.value                     # bad device ordinal
     assert lib.mpv_ctx_create(0, None, C.byref(h)) == 0 and h.value
     shape = _native.SampleShape(1, 1, 4, 4, 4, 0, 1, 0)
-    assert lib.mpv_nsdiff_sample(h, C.byref(shape), None, None, None, None) < 0               # nothing loaded
+    none_out = _native.SampleOut()
+    assert lib.mpv_nsdiff_sample(h, C.byref(shape), None, None, None, C.byref(none_out)) < 0  # nothing loaded
     assert b"mpv_nsdiff_load first" in lib.mpv_last_error(h)
     sd = O.random_state_dict(1, 10, 100, 100, 50, seed=5)
     ctx = make_ctx(sd, 1, 10)
     gx = torch.ones(1, 1, 4, 1, device=dev())
     out = torch.empty(1, 1, 4, 1, 4, device=dev())
+    so = _native.SampleOut(samples=out.data_ptr())
     for bad, msg in ((_native.SampleShape(1, 1, 4, 4, 4, 7, 1, 0), b"gemm must be"),
                      (_native.SampleShape(1, 1, 4, 6, 4, 0, 1, 0), b"multiple of chunk"),
                      (_native.SampleShape(-1, 1, 4, 4, 4, 0, 1, 0), b"negative extent")):
-        rc = lib.mpv_nsdiff_sample(ctx._h, C.byref(bad), None, C.c_void_p(gx.data_ptr()), None, C.c_void_p(out.data_ptr()))
+        rc = lib.mpv_nsdiff_sample(ctx._h, C.byref(bad), None, C.c_void_p(gx.data_ptr()), None, C.byref(so))
         assert rc < 0 and msg in lib.mpv_last_error(ctx._h), (rc, lib.mpv_last_error(ctx._h))
     ok = _native.SampleShape(1, 1, 4, 4, 4, 0, 1, 0)
-    assert lib.mpv_nsdiff_sample(ctx._h, C.byref(ok), None, None, None, C.c_void_p(out.data_ptr())) < 0   # gx NULL, non-empty
-    assert lib.mpv_nsdiff_sample(ctx._h, C.byref(ok), None, C.c_void_p(gx.data_ptr()), None, C.c_void_p(out.data_ptr())) == 0
+    assert lib.mpv_nsdiff_sample(ctx._h, C.byref(ok), None, None, None, C.byref(so)) < 0   # gx NULL, non-empty
+    assert lib.mpv_nsdiff_sample(ctx._h, C.byref(ok), None, C.c_void_p(gx.data_ptr()), None, None) < 0            # out NULL
+    assert lib.mpv_nsdiff_sample(ctx._h, C.byref(ok), None, C.c_void_p(gx.data_ptr()), None, C.byref(none_out)) < 0   # neither samples nor mpv
+    assert b"out->samples and/or out->mpv" in lib.mpv_last_error(ctx._h)
+    assert lib.mpv_nsdiff_sample(ctx._h, C.byref(ok), None, C.c_void_p(gx.data_ptr()), None, C.byref(so)) == 0
     torch.cuda.synchronize()
     assert bool(torch.isfinite(out).all())
     d = _native.NsdiffDesc(0, 1)
     assert lib.mpv_nsdiff_load(ctx._h, C.byref(d), None, None) < 0
     lib.mpv_ctx_destroy(h)
+
+
+# ---- fused MPV epilogue (ABI v2): summary from the sampler itself, samples optional ---------------------------------------
+@pytest.mark.parametrize("nf,S", [(1, 32), (1, 64), (1, 4), (1, 1), (2, 8), (3, 32), (1, 33), (2, 100), (1, 96)])
+@pytest.mark.parametrize("gemm", ["f16x3", "f32"])
+def test_fused_summary_equals_reduce_of_the_same_samples(nf, S, gemm):
+    """mpv_nsdiff_sample with out->mpv: the summary (fused into the split-f16 kernel's epilogue where S allows, sample +
+    mpv_reduce otherwise) equals mpv_reduce and a float64 torch reduction of the samples of the SAME call; with
+    out->samples == NULL the same Philox seed gives the same curve."""
+    steps = 8
+    sd = O.random_state_dict(nf, steps, 40, 24, 16, seed=70 + nf)
+    ctx = make_ctx(sd, nf, steps)
+    g = torch.Generator().manual_seed(S)
+    W, B, Ol = 5, 3, 7
+    gx = (torch.rand(W, B, Ol, nf, generator=g) + 0.1).to(dev())
+    y0 = (torch.randn(W, B, Ol, nf, generator=g) * 0.2).to(dev())
+    std = (torch.rand(nf, generator=g) + 0.5).to(dev())
+    mean = torch.randn(nf, generator=g).to(dev())
+    samples, mpv, pm, feat = ctx.sample(gx, y0, S, S, seed=11, gemm=gemm, summary=True, per_feature=True, std=std, mean=mean)
+    mpv_r, pm_r, feat_r = ctx.reduce(samples, std, mean, per_feature=True)
+    x = samples.double() * std.double().view(1, 1, 1, -1, 1) + mean.double().view(1, 1, 1, -1, 1)
+    var = x.var(dim=-1, unbiased=False)
+    assert rel_err(mpv, var.mean(dim=(1, 2, 3))) < 2e-6 and rel_err(feat, var.mean(dim=(1, 2))) < 2e-6
+    assert rel_err(pm, x.mean(dim=(1, 2, 3, 4))) < 2e-6
+    assert rel_err(mpv, mpv_r) < 2e-6 and rel_err(pm, pm_r) < 2e-6 and rel_err(feat, feat_r) < 2e-6
+    none, mpv2, pm2, _ = ctx.sample(gx, y0, S, S, seed=11, gemm=gemm, summary=True, want_samples=False, std=std, mean=mean)
+    assert none is None and rel_err(mpv2, mpv) < 1e-6 and rel_err(pm2, pm) < 1e-6
+    _, mpv3, _, _ = ctx.sample(gx, y0, S, S, seed=12, gemm=gemm, summary=True, want_samples=False)      # other seed, no scaling
+    assert not torch.equal(mpv3, mpv2)
+
+
+def test_fused_summary_over_window_groups_and_tmdm(golden_tmdm):
+    """More windows than the workgroup's LDS accumulator table holds (F = 3: 20 per launch) -> several launches whose
+    Philox chains continue where the previous group stopped: identical to the one-launch sample tensor."""
+    nf, steps, S = 3, 6, 32
+    sd = O.random_state_dict(nf, steps, 40, 24, 16, seed=9)
+    ctx = make_ctx(sd, nf, steps)
+    g = torch.Generator().manual_seed(1)
+    W, B, Ol = 47, 2, 3
+    gx = (torch.rand(W, B, Ol, nf, generator=g) + 0.1).to(dev())
+    whole = ctx.sample(gx, None, S, S, seed=5)                                    # one launch, no summary
+    samples, mpv, pm, _ = ctx.sample(gx, None, S, S, seed=5, summary=True)        # grouped launches
+    assert torch.equal(samples, whole)
+    want = whole.double().var(dim=-1, unbiased=False).mean(dim=(1, 2, 3))
+    assert rel_err(mpv, want) < 2e-6 and rel_err(pm, whole.double().mean(dim=(1, 2, 3, 4))) < 2e-6
+
+
+def test_one_full_size_c2_window_against_the_oracle():
+    """BASELINE configs[1] at FULL size for one window (100 nodes x 100 horizon x 32 samples, T = 50): the default
+    split-f16 kernel against the CPU oracle on injected noise, elementwise, and the fused MPV against the oracle's."""
+    from mpv_amd import synthetic
+    sd0 = O.random_state_dict(1, 50, 100, 100, 50, seed=123)
+    model = _variant_model(sd0, "cond_var", 1, 50, 100, 100, 50, 32, 32)
+    g = torch.Generator().manual_seed(21)
+    series = torch.cumsum(torch.randn(100, 100, 1, generator=g) * 0.05, dim=1) + 3.0
+    synthetic.seeded_nsdiff_state(model, series, seed=123)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = O.NsDiffConfig(100, 100, 1, 50, 50, n_z_samples=32, parallel_sample=32)
+    x = O.scale(series, sd["scaler_mean"], sd["scaler_std"])
+    rec = []
+    torch.manual_seed(3)
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    want = O.evaluation_step(sd, cfg, x, record=rec)
+    outs, _ = model.evaluation_step(x, noise=torch.cat([z.reshape(-1) for z in rec]))
+    err = rel_err(outs, want)
+    m_w, v_w = O.mpv_network(want, sd["scaler_mean"], sd["scaler_std"])
+    ctx = model.native_context()
+    mpv, pm, _ = ctx.reduce(outs.to(dev()).unsqueeze(0).contiguous(), model.scaler_std.float().contiguous(), model.scaler_mean.float().contiguous())
+    print("full-size C2 window vs oracle: samples elementwise rel err %.3e, MPV rel err %.3e" % (err, abs(mpv.item() - v_w) / abs(v_w)))
+    assert err < RTOL
+    assert abs(mpv.item() - v_w) <= 1e-5 * abs(v_w) and abs(pm.item() - m_w) <= 1e-5 * abs(m_w) + 1e-6
+
+
+@pytest.mark.parametrize("tag", ["wofx", "sim"])
+def test_trained_checkpoints_stay_on_the_fast_path(ckpt_wofx, ckpt_sim, tag):
+    """Both shipped sampler checkpoints (trained weights, T = 20) on a C2-like batch: how many reverse steps fail the
+    end-of-step guard of the split-f16 kernel and are re-run through the exact routine (device counter)."""
+    sd, nf, rolling = (ckpt_wofx, 2, 100) if tag == "wofx" else (ckpt_sim, 1, 50)
+    model = _variant_model(sd, "cond_var", nf, 20, 200, 200, rolling, 32, 32)
+    g = torch.Generator().manual_seed(2)
+    series = torch.cumsum(torch.randn(16, 260, nf, generator=g) * 0.1, dim=1)
+    ctx = model.native_context()
+    ctx.chain_stats(reset=True)
+    samples, _ = model.sample_windows(series, 4, first=0, step=20, scale_input=False, seed=3)
+    steps, safe = ctx.chain_stats()
+    print("trained checkpoint %s: %d of %d tile-steps re-run through the exact routine" % (tag, safe, steps))
+    assert bool(torch.isfinite(samples).all()) and steps == (4 * 16 * 200 * 32 // 32) * 20
+    assert safe <= steps // 100
+
+
+@pytest.mark.parametrize("nf,windows,rolling,pred_len", [(2, 1000, 50, 200), (2, 200, 100, 1000), (1, 3000, 100, 100), (4, 1200, 64, 64)])
+def test_sigma_head_long_windows_fit_the_lds_budget(nf, windows, rolling, pred_len):
+    """Shipped sweep configs (ews_results/NsDiff_windows/models/dataset__w1000p200st100.yaml: F = 2, windows 1000,
+    rolling 50; NsDiff_pred ... w200p1000) and longer: rows per workgroup are chosen from the LDS budget (reference
+    g_backbone.py:49-72 has no such limit)."""
+    sd = O.random_state_dict(nf, 5, windows, pred_len, rolling, seed=windows)
+    ctx = make_ctx(sd, nf, 5, sigma=(windows, rolling, pred_len))
+    g = torch.Generator().manual_seed(windows)
+    x = torch.cumsum(torch.randn(5, windows, nf, generator=g) * 0.1, dim=1)
+    got = ctx.sigma_head(x.to(dev()), 1, 0, 1)[0]
+    want = O.sigma_head(sd, x, rolling, pred_len)
+    err = rel_err(got, want)
+    print("sigma head F=%d windows=%d rolling=%d O=%d: rel err %.3e" % (nf, windows, rolling, pred_len, err))
+    assert err < 1e-5
+
+
+def test_uncertainty_ews_curve_only_mode(tmp_path, golden_cases, monkeypatch):
+    """store_samples=False: same curve as the reference run, nothing cached, no sample list (fused summary epilogue)."""
+    from helpers import WOFX_NET, write_model_dir
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+    sd = O.random_state_dict(1, 50, 100, 100, 50, seed=123)
+    sd["scaler_mean"] = T(golden_cases["eval_seed_scaler_mean"])
+    sd["scaler_std"] = T(golden_cases["eval_seed_scaler_std"])
+    net = dict(WOFX_NET, diffusion_steps=50, rolling_length=50, windows=100, pred_len=100, dataset_nf=1)
+    mdir = tmp_path / "model"
+    write_model_dir(mdir, sd, net)
+    series = T(np.ascontiguousarray(golden_cases["net_series"]))[:, :, 0].t().contiguous()
+    _reseed_after(monkeypatch, H, "load_model_from_dir", 22)
+    res = H.uncertainty_ews(model_save_file=mdir, torch_time_series=series, time_data=torch.arange(series.shape[0]) * 0.1,
+                            dynamic_type="biomass", sampling_t=0.1, sample_window_step=80, device=dev(), save_nsdiff_g=False,
+                            infer_params={"n_z_samples": 8, "parallel_sample": 4, "noise_source": "torch_cpu"}, store_samples=False)
+    assert res["pred_future_list"] is None and not (mdir / "data.pt").exists()
+    np.testing.assert_allclose(np.array(res["ews"], dtype=np.float64), golden_cases["net_ews"], rtol=RTOL)
+    np.testing.assert_allclose(np.array(res["pred_mean"], dtype=np.float64), golden_cases["net_pred_mean"], rtol=RTOL)
+    np.testing.assert_allclose(res["time_points"], golden_cases["net_tp"])

@@ -15,7 +15,7 @@ import torch
 PKG = Path(__file__).resolve().parent
 import os
 LIB_PATH = Path(os.environ.get("MPV_LIB", PKG / "libmpv_hip.so"))   # MPV_LIB: kernel-variant experiments only
-ABI_VERSION = 1
+ABI_VERSION = 2
 HIDDEN = 128
 MAX_NF = 4
 COEF_COLS = 20
@@ -23,7 +23,7 @@ GEMM_MODES = {"f16x3": 0, "f32": 1, "f16x2": 2, "f16": 3}
 
 EXPORTS = (
     "mpv_abi_version", "mpv_ctx_create", "mpv_ctx_destroy", "mpv_ctx_set_stream", "mpv_last_error",
-    "mpv_nsdiff_load", "mpv_nsdiff_sample", "mpv_nsdiff_preact_bound", "mpv_nsdiff_philox_normals", "mpv_sigma_load", "mpv_sigma_head",
+    "mpv_nsdiff_load", "mpv_nsdiff_sample", "mpv_chain_stats", "mpv_nsdiff_philox_normals", "mpv_sigma_load", "mpv_sigma_head",
     "mpv_reduce", "mpv_chain_timing", "mpv_chain_timing_enable", "mpv_tmdm_load", "mpv_tmdm_sample",
     "mpv_biomass_simulate",
 )
@@ -48,6 +48,10 @@ class NsdiffWeights(C.Structure):
 class SampleShape(C.Structure):
     _fields_ = [("n_windows", C.c_int32), ("nodes", C.c_int32), ("pred_len", C.c_int32), ("n_samples", C.c_int32),
                 ("chunk", C.c_int32), ("gemm", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64)]
+
+
+class SampleOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("samples", "mpv", "pred_mean", "mpv_feat", "std", "mean")]
 
 
 class SigmaDesc(C.Structure):
@@ -88,12 +92,12 @@ def load_library():
         "mpv_ctx_set_stream": (C.c_int, [vp, vp]),
         "mpv_last_error": (C.c_char_p, [vp]),
         "mpv_nsdiff_load": (C.c_int, [vp, C.POINTER(NsdiffDesc), C.POINTER(NsdiffWeights), _F]),
-        "mpv_nsdiff_sample": (C.c_int, [vp, C.POINTER(SampleShape), vp, vp, vp, vp]),
+        "mpv_nsdiff_sample": (C.c_int, [vp, C.POINTER(SampleShape), vp, vp, vp, C.POINTER(SampleOut)]),
         "mpv_tmdm_load": (C.c_int, [vp, C.POINTER(NsdiffDesc), C.POINTER(NsdiffWeights), _F]),
-        "mpv_tmdm_sample": (C.c_int, [vp, C.POINTER(SampleShape), vp, vp, vp]),
+        "mpv_tmdm_sample": (C.c_int, [vp, C.POINTER(SampleShape), vp, vp, C.POINTER(SampleOut)]),
         "mpv_biomass_simulate": (C.c_int, [vp, C.POINTER(BiomassDesc), vp, vp, vp, vp]),
         "mpv_nsdiff_philox_normals": (C.c_int, [vp, u64, u64, i64, vp]),
-        "mpv_nsdiff_preact_bound": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "mpv_chain_stats": (C.c_int, [vp, C.POINTER(u64), C.POINTER(u64), C.c_int]),
         "mpv_sigma_load": (C.c_int, [vp, C.POINTER(SigmaDesc), C.POINTER(SigmaWeights)]),
         "mpv_sigma_head": (C.c_int, [vp, vp, i32, i64, i32, i64, i64, vp, vp, f32, vp]),
         "mpv_reduce": (C.c_int, [vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
@@ -217,9 +221,24 @@ class Context:
                                             float(add_eps), _dev_ptr(gx, self.device, "gx")), "mpv_sigma_head")
         return gx
 
+    def _sample_out(self, shape5, want_samples: bool, summary: bool, per_feature: bool, std, mean):
+        """Allocate the outputs of a sampling call and fill the mpv_sample_out struct (tensors kept alive by the caller)."""
+        W, F = shape5[0], shape5[3]
+        samples = torch.empty(shape5, device=self.device, dtype=torch.float32) if want_samples else None
+        mpv = torch.empty(W, device=self.device, dtype=torch.float32) if summary else None
+        pm = torch.empty(W, device=self.device, dtype=torch.float32) if summary else None
+        feat = torch.empty((W, F), device=self.device, dtype=torch.float32) if (summary and per_feature) else None
+        out = SampleOut(_dev_ptr(samples, self.device, "samples"), _dev_ptr(mpv, self.device, "mpv"),
+                        _dev_ptr(pm, self.device, "pred_mean"), _dev_ptr(feat, self.device, "mpv_feat"),
+                        _dev_ptr(std, self.device, "std"), _dev_ptr(mean, self.device, "mean"))
+        return out, samples, mpv, pm, feat
+
     def sample(self, gx: torch.Tensor, y0hat: Optional[torch.Tensor], n_samples: int, chunk: int,
-               noise: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0, gemm: str = "f16x3") -> torch.Tensor:
-        """gx / y0hat [W, B, O, F] on device -> samples [W, B, O, F, S]."""
+               noise: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0, gemm: str = "f16x3",
+               want_samples: bool = True, summary: bool = False, per_feature: bool = False, std=None, mean=None):
+        """gx / y0hat [W, B, O, F] on device -> samples [W, B, O, F, S]  (summary=False, the default), or
+        (samples | None, mpv [W], pred_mean [W], mpv_feat [W, F] | None) with summary=True: the MPV reduction fused into
+        the sampler's epilogue; want_samples=False then skips the sample tensor altogether."""
         if self.nsdiff is None:
             raise MpvError("NsDiff weights not loaded")
         W, B, O, F = gx.shape
@@ -231,15 +250,17 @@ class Context:
             need = W * self.nsdiff[0] * B * n_samples * O * F
             if noise.numel() != need:
                 raise MpvError("noise has {} elements, the draw order needs {}".format(noise.numel(), need))
-        out = torch.empty((W, B, O, F, n_samples), device=self.device, dtype=torch.float32)
         if gemm not in GEMM_MODES:
             raise MpvError("gemm must be one of {}".format(sorted(GEMM_MODES)))
+        if not want_samples and not summary:
+            raise MpvError("nothing to compute: want_samples=False and summary=False")
+        out, samples, mpv, pm, feat = self._sample_out((W, B, O, F, n_samples), want_samples, summary, per_feature, std, mean)
         shape = SampleShape(W, B, O, n_samples, chunk, GEMM_MODES[gemm], seed & (2 ** 64 - 1), offset & (2 ** 64 - 1))
         self._bind_stream()
         self._check(self.lib.mpv_nsdiff_sample(self._h, C.byref(shape), _dev_ptr(y0hat, self.device, "y0hat"),
                                                _dev_ptr(gx, self.device, "gx"), _dev_ptr(noise, self.device, "noise"),
-                                               _dev_ptr(out, self.device, "samples")), "mpv_nsdiff_sample")
-        return out
+                                               C.byref(out)), "mpv_nsdiff_sample")
+        return (samples, mpv, pm, feat) if summary else samples
 
     # ---- TMDM sampler ----------------------------------------------------------------
     def load_tmdm(self, steps: int, nf: int, lin_w: Sequence[torch.Tensor], lin_b: Sequence[torch.Tensor],
@@ -262,8 +283,9 @@ class Context:
         self.tmdm = (steps, nf)
 
     def sample_tmdm(self, y0hat: torch.Tensor, n_samples: int, chunk: int, noise: Optional[torch.Tensor] = None,
-                    seed: int = 0, offset: int = 0, gemm: str = "f16x3") -> torch.Tensor:
-        """y0hat [W, B, L, F] on device -> samples [W, B, L, F, S]."""
+                    seed: int = 0, offset: int = 0, gemm: str = "f16x3", want_samples: bool = True, summary: bool = False,
+                    per_feature: bool = False, std=None, mean=None):
+        """y0hat [W, B, L, F] on device -> samples [W, B, L, F, S]; summary / want_samples as in `sample`."""
         if self.tmdm is None:
             raise MpvError("TMDM weights not loaded")
         W, B, L, F = y0hat.shape
@@ -273,17 +295,18 @@ class Context:
             need = W * self.tmdm[0] * B * n_samples * L * F
             if noise.numel() != need:
                 raise MpvError("noise has {} elements, the draw order needs {}".format(noise.numel(), need))
-        out = torch.empty((W, B, L, F, n_samples), device=self.device, dtype=torch.float32)
         if gemm not in ("f16x3", "f32"):
             raise MpvError("the TMDM sampler supports gemm 'f16x3' and 'f32'")
         if gemm == "f16x3" and F > 3:
             gemm = "f32"                                       # the split-f16 kernel is built for nf <= 3
+        if not want_samples and not summary:
+            raise MpvError("nothing to compute: want_samples=False and summary=False")
+        out, samples, mpv, pm, feat = self._sample_out((W, B, L, F, n_samples), want_samples, summary, per_feature, std, mean)
         shape = SampleShape(W, B, L, n_samples, chunk, GEMM_MODES[gemm], seed & (2 ** 64 - 1), offset & (2 ** 64 - 1))
         self._bind_stream()
         self._check(self.lib.mpv_tmdm_sample(self._h, C.byref(shape), _dev_ptr(y0hat, self.device, "y0hat"),
-                                             _dev_ptr(noise, self.device, "noise"),
-                                             _dev_ptr(out, self.device, "samples")), "mpv_tmdm_sample")
-        return out
+                                             _dev_ptr(noise, self.device, "noise"), C.byref(out)), "mpv_tmdm_sample")
+        return (samples, mpv, pm, feat) if summary else samples
 
     # ---- synthetic input generation ---------------------------------------------------
     def biomass_simulate(self, row_ptr: torch.Tensor, col_idx: torch.Tensor, x0: torch.Tensor, ticks: int, burn_ticks: int,
@@ -305,10 +328,12 @@ class Context:
                                                   _dev_ptr(out, self.device, "series_out")), "mpv_biomass_simulate")
         return out
 
-    def preact_bound(self) -> float:
-        b = C.c_float()
-        self._check(self.lib.mpv_nsdiff_preact_bound(self._h, C.byref(b)), "mpv_nsdiff_preact_bound")
-        return b.value
+    def chain_stats(self, reset: bool = False):
+        """(tile_steps, safe_steps) of the split-f16 sampler since the last reset: reverse steps executed per 32-chain tile
+        and how many of them fell through to the exact out-of-line routine."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.mpv_chain_stats(self._h, C.byref(a), C.byref(b), int(reset)), "mpv_chain_stats")
+        return a.value, b.value
 
     def philox_normals(self, seed: int, offset: int, n_chains: int) -> torch.Tensor:
         if self.nsdiff is None:

@@ -1,20 +1,34 @@
 """Build libmpv_hip.so (the gfx950 HIP kernels + C ABI) in-tree with hipcc.
 
-    python -m mpv_amd.build            # or: python <package>/build.py
+    python -m mpv_amd.build            # or: python <package>/build.py [--force]
 
-hipcc cross-compiles for gfx950 without a GPU.  The .so is git-ignored but travels with
-the working tree to the GPU box.
+hipcc cross-compiles for gfx950 without a GPU.  Every csrc/*.hip is compiled to an object under build/ (in parallel,
+only when it or a header changed) and the objects are linked into the .so, which is git-ignored but travels with the
+working tree to the GPU box.
 """
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
-SOURCES = ["mpv_api.hip", "nsdiff_chain.hip", "nsdiff_chain_f16.hip", "sigma_head.hip", "mpv_reduce.hip", "biomass_sim.hip"]
+CSRC = PKG / "csrc"
+OBJ = PKG / "build"
 LIB = PKG / "libmpv_hip.so"
+# -fno-slp-vectorize: packed-f32 VALU (v_pk_fma_f32 ...) issues at half rate beside MFMAs on gfx950
+# (tools/ubench/pipe_overlap4: 4 v_pk_fma per MFMA gap = 68 cycles vs 8 v_fma = 48)
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fPIC"]
+
+
+def sources():
+    return sorted(CSRC.glob("*.hip"))
+
+
+def headers():
+    return sorted(CSRC.glob("*.h")) + [ROOT / "include" / "mpv_hip.h"]
 
 
 def hipcc_path() -> str:
@@ -24,26 +38,41 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or put /opt/rocm/bin on PATH)")
 
 
+def _newer(path: Path, than: Path) -> bool:
+    return (not than.exists()) or path.stat().st_mtime > than.stat().st_mtime
+
+
 def stale() -> bool:
-    if not LIB.exists():
-        return True
-    deps = [PKG / "csrc" / s for s in SOURCES] + [PKG / "csrc" / "mpv_common.h", PKG / "csrc" / "chain_common.h", ROOT / "include" / "mpv_hip.h"]
-    return any(d.stat().st_mtime > LIB.stat().st_mtime for d in deps)
+    return any(_newer(d, LIB) for d in sources() + headers())
+
+
+def _compile(src: Path, obj: Path, verbose: bool):
+    cmd = [hipcc_path(), *FLAGS, "-I", str(ROOT / "include"), "-I", str(CSRC), "-c", str(src), "-o", str(obj)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed on {}:\n{}{}".format(src.name, proc.stdout, proc.stderr))
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not stale():
         return LIB
-    # -fno-slp-vectorize: packed-f32 VALU (v_pk_fma_f32 ...) issues at half rate beside MFMAs on gfx950
-    # (tools/ubench/pipe_overlap4: 4 v_pk_fma per MFMA gap = 68 cycles vs 8 v_fma = 48)
-    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared",
-           "-I", str(ROOT / "include"), "-I", str(PKG / "csrc"), "-o", str(LIB)]
-    cmd += [str(PKG / "csrc" / s) for s in SOURCES]
+    OBJ.mkdir(exist_ok=True)
+    hdr_time = max(h.stat().st_mtime for h in headers())
+    jobs = []
+    for src in sources():
+        obj = OBJ / (src.stem + ".o")
+        if force or _newer(src, obj) or obj.stat().st_mtime < hdr_time:
+            jobs.append((src, obj))
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as pool:
+        list(pool.map(lambda j: _compile(j[0], j[1], verbose), jobs))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(OBJ / (s.stem + ".o")) for s in sources()]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+        raise RuntimeError("link failed:\n" + proc.stdout + proc.stderr)
     return LIB
 
 

@@ -50,6 +50,14 @@ struct ChainArgs {
     int T, B, O, S, P, C;
     unsigned seed_lo, seed_hi, off_lo;
     unsigned long long* tile_counter;   // f16 kernel: next unclaimed tile (waves pull tiles, so both waves of a SIMD stay busy to the end)
+    // ---- fused summary epilogue of the f16 kernel (all zero / NULL = off) ----
+    double* acc;                 // global [W][F][2] fp64: sum over rows of var_row, sum over rows of mean_row (zeroed by the launcher)
+    const float *inv_std, *inv_mean;   // [F] inverse scaling inside the summary, or NULL
+    int seg;                     // lanes of a tile that share a (b,o,f) row: min(S, 32), a power of two
+    int sub;                     // consecutive tiles that make up one row: max(1, S / 32); a claim covers `sub` tiles
+    int acc_windows;             // windows of this launch (rows of the LDS accumulator table)
+    long long chain_base;        // added to the chain index in the Philox key (launches over window groups)
+    unsigned long long* stats;   // [0] += steps re-run through chain_step_safe
 };
 
 // ---- softplus(x) = x > 20 ? x : log1p(exp(x))  (torch.nn.functional.softplus defaults) ----

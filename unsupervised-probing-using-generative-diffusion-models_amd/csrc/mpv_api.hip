@@ -114,7 +114,7 @@ static int load_chain_model(mpv_ctx* ctx, NsdiffModel& m, int T, int F, const mp
     m.e1 = dev[6]; m.e2 = dev[7]; m.e3 = dev[8]; m.w4 = dev[9]; m.ws = dev[10]; m.b4 = dev[11]; m.bs = dev[12];
     m.coef = dev[13];
     // ---- split-f16 variant (nsdiff_chain_f16.hip): scaled/split weights, biases as MFMA k-slots, folded
-    // per-step scale rows, layer-1 pre-activation bound coefficients
+    // per-step scale rows
     const float LOG2E = 1.44269504088896341f, LN2 = 0.693147180559945309f;
     const int INS = 4;                                    // layer-1 inputs scaled 2^4
     auto f16bits = [](float x) { const _Float16 h = (_Float16)x; unsigned short u; std::memcpy(&u, &h, 2); return u; };
@@ -180,30 +180,8 @@ static int load_chain_model(mpv_ctx* ctx, NsdiffModel& m, int T, int F, const mp
         g3[i] = std::ldexp(w->embed[2][i] * LOG2E, -sW[2]);
     }
     for (size_t i = 0; i < (size_t)F * H; ++i) wsl[i] = w->sig_w[i] * LN2;
-    // |x_j| = |gamma_tj (W_j . h + b_j)| <= |gamma_tj| (||W_j||_2 + |b_j|) because the layer input has unit 2-norm
-    float bound = 0.0f;
-    for (int L = 1; L <= 2; ++L)
-        for (int j = 0; j < H; ++j) {
-            double n2 = 0.0;
-            for (int k = 0; k < H; ++k) n2 += (double)wl[L][(size_t)j * H + k] * wl[L][(size_t)j * H + k];
-            const float reach = (float)std::sqrt(n2) + std::fabs(w->lin_b[L][j]);
-            for (int t = 0; t < T; ++t) bound = std::fmax(bound, std::fabs(w->embed[L][(size_t)t * H + j]) * reach);
-        }
-    m.preact_bound23 = std::isfinite(bound) ? bound : 1e30f;
-    // layer 1 (inputs unbounded): |x'_j| <= K1_t + K2_t * sum_c |in_c| in log2 units -> coefficient columns 18, 19
     std::vector<float> coef2(coef, coef + (size_t)T * MPV_COEF_COLS);
-    for (int t = 0; t < T; ++t) {
-        float k1 = 0.0f, k2 = 0.0f;
-        for (int j = 0; j < H; ++j) {
-            const float gl = std::fabs(w->embed[0][(size_t)t * H + j]) * LOG2E;
-            float wm = 0.0f;
-            for (int c = 0; c < 3 * F; ++c) wm = std::fmax(wm, std::fabs(w->lin_w[0][(size_t)j * 3 * F + c]));
-            k1 = std::fmax(k1, gl * std::fabs(w->lin_b[0][j]));
-            k2 = std::fmax(k2, gl * wm);
-        }
-        coef2[(size_t)t * MPV_COEF_COLS + 18] = std::isfinite(k1) ? k1 * 1.0001f : 1e30f;
-        coef2[(size_t)t * MPV_COEF_COLS + 19] = std::isfinite(k2) ? k2 * 1.0001f : 1e30f;
-    }
+    for (int t = 0; t < T; ++t) coef2[(size_t)t * MPV_COEF_COLS + 18] = coef2[(size_t)t * MPV_COEF_COLS + 19] = 0.0f;
     auto as_f32 = [](const void* v) { return reinterpret_cast<const float*>(v); };
     std::vector<const float*> d16;
     rc = upload_blob(ctx,
@@ -219,7 +197,7 @@ static int load_chain_model(mpv_ctx* ctx, NsdiffModel& m, int T, int F, const mp
     m.w1img = reinterpret_cast<const unsigned short*>(d16[4]);
     m.b2p = reinterpret_cast<const unsigned*>(d16[5]); m.b3p = reinterpret_cast<const unsigned*>(d16[6]);
     m.g1 = d16[7]; m.g2 = d16[8]; m.g3 = d16[9]; m.wsl = d16[10];
-    m.coef = d16[11];                                     // same rows as given + columns 18, 19
+    m.coef = d16[11];
     m.w4h = d16[12];                                      // eps head as the split-f16 kernel reads it (x act_scale)
     m.steps = T; m.nf = F; m.loaded = true;
     return MPV_OK;
@@ -272,6 +250,9 @@ void mpv_ctx_destroy(mpv_ctx* ctx) {
     if (ctx->sg.blob) (void)hipFree(ctx->sg.blob);
     if (ctx->reduce_ws) (void)hipFree(ctx->reduce_ws);
     if (ctx->tile_counter) (void)hipFree(ctx->tile_counter);
+    if (ctx->chain_stats) (void)hipFree(ctx->chain_stats);
+    if (ctx->summary_acc) (void)hipFree(ctx->summary_acc);
+    if (ctx->sample_ws) (void)hipFree(ctx->sample_ws);
     delete ctx;
 }
 
@@ -298,21 +279,34 @@ int mpv_nsdiff_load(mpv_ctx* ctx, const mpv_nsdiff_desc* d, const mpv_nsdiff_wei
     return load_chain_model(ctx, ctx->ns, d->steps, d->nf, w, coef, 1.0f);
 }
 
+static int check_sample_call(mpv_ctx* ctx, const char* fn, const mpv_sample_shape* s, const mpv_sample_out* out, bool* empty) {
+    const std::string f(fn);
+    if (!s) return mpv_fail(ctx, MPV_EINVAL, f + ": NULL shape");
+    if (s->n_windows < 0 || s->nodes < 0 || s->pred_len < 0 || s->n_samples < 0)
+        return mpv_fail(ctx, MPV_EINVAL, f + ": negative extent");
+    *empty = s->n_windows == 0 || s->nodes == 0 || s->pred_len == 0 || s->n_samples == 0;
+    if (!out) return mpv_fail(ctx, MPV_EINVAL, f + ": NULL argument (out)");
+    if (!*empty && !out->samples && !out->mpv) return mpv_fail(ctx, MPV_EINVAL, f + ": NULL argument (give out->samples and/or out->mpv)");
+    if ((out->mean == nullptr) != (out->std == nullptr)) return mpv_fail(ctx, MPV_EINVAL, f + ": give both std and mean or neither");
+    if ((out->pred_mean || out->mpv_feat) && !out->mpv) return mpv_fail(ctx, MPV_EINVAL, f + ": pred_mean / mpv_feat need mpv as well");
+    if (s->n_samples > 0 && (s->chunk < 1 || s->n_samples % s->chunk != 0))
+        return mpv_fail(ctx, MPV_EINVAL, f + ": n_samples must be a positive multiple of chunk");
+    return MPV_OK;
+}
+
 int mpv_nsdiff_sample(mpv_ctx* ctx, const mpv_sample_shape* s, const float* y0hat, const float* gx, const float* noise,
-                      float* samples) {
+                      const mpv_sample_out* out) {
     if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nsdiff_sample: ctx is NULL");
     if (!ctx->ns.loaded) return mpv_fail(ctx, MPV_ESTATE, "mpv_nsdiff_sample: call mpv_nsdiff_load first");
-    if (!s) return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: NULL shape");
-    if (s->n_windows < 0 || s->nodes < 0 || s->pred_len < 0 || s->n_samples < 0)
-        return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: negative extent");
-    const bool empty = s->n_windows == 0 || s->nodes == 0 || s->pred_len == 0 || s->n_samples == 0;
-    if (!empty && (!gx || !samples)) return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: NULL argument");
+    bool empty = false;
+    if (int rc = check_sample_call(ctx, "mpv_nsdiff_sample", s, out, &empty)) return rc;
+    if (!empty && !gx) return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: NULL argument");
     if (s->gemm < MPV_GEMM_F16X3 || s->gemm > MPV_GEMM_F16)
         return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: gemm must be MPV_GEMM_F16X3, MPV_GEMM_F32, MPV_GEMM_F16X2 or MPV_GEMM_F16");
-    if (s->n_samples > 0 && (s->chunk < 1 || s->n_samples % s->chunk != 0))
-        return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: n_samples must be a positive multiple of chunk");
+    if (s->gemm != MPV_GEMM_F32 && ctx->ns.nf > 3)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_sample: the split-f16 sampler supports nf 1..3 (use MPV_GEMM_F32 for nf = 4)");
     DeviceGuard g(ctx->device);
-    return launch_nsdiff_chain(ctx, *s, y0hat, gx, noise, samples);
+    return launch_nsdiff_chain(ctx, *s, y0hat, gx, noise, *out);
 }
 
 int mpv_tmdm_load(mpv_ctx* ctx, const mpv_nsdiff_desc* d, const mpv_nsdiff_weights* w, const float* coef) {
@@ -334,22 +328,18 @@ int mpv_tmdm_load(mpv_ctx* ctx, const mpv_nsdiff_desc* d, const mpv_nsdiff_weigh
     return load_chain_model(ctx, ctx->tm, d->steps, F, &x, coef, 0.693147180559945309f);
 }
 
-int mpv_tmdm_sample(mpv_ctx* ctx, const mpv_sample_shape* s, const float* y0hat, const float* noise, float* samples) {
+int mpv_tmdm_sample(mpv_ctx* ctx, const mpv_sample_shape* s, const float* y0hat, const float* noise, const mpv_sample_out* out) {
     if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_tmdm_sample: ctx is NULL");
     if (!ctx->tm.loaded) return mpv_fail(ctx, MPV_ESTATE, "mpv_tmdm_sample: call mpv_tmdm_load first");
-    if (!s) return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: NULL shape");
-    if (s->n_windows < 0 || s->nodes < 0 || s->pred_len < 0 || s->n_samples < 0)
-        return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: negative extent");
-    const bool empty = s->n_windows == 0 || s->nodes == 0 || s->pred_len == 0 || s->n_samples == 0;
-    if (!empty && (!y0hat || !samples)) return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: NULL argument");
+    bool empty = false;
+    if (int rc = check_sample_call(ctx, "mpv_tmdm_sample", s, out, &empty)) return rc;
+    if (!empty && !y0hat) return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: NULL argument");
     if (s->gemm != MPV_GEMM_F32 && s->gemm != MPV_GEMM_F16X3)
         return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: gemm must be MPV_GEMM_F16X3 or MPV_GEMM_F32");
     if (s->gemm == MPV_GEMM_F16X3 && ctx->tm.nf > 3)
         return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: the split-f16 sampler supports nf 1..3 (use MPV_GEMM_F32 for nf = 4)");
-    if (s->n_samples > 0 && (s->chunk < 1 || s->n_samples % s->chunk != 0))
-        return mpv_fail(ctx, MPV_EINVAL, "mpv_tmdm_sample: n_samples must be a positive multiple of chunk");
     DeviceGuard g(ctx->device);
-    return launch_tmdm_chain(ctx, *s, y0hat, noise, samples);
+    return launch_tmdm_chain(ctx, *s, y0hat, noise, *out);
 }
 
 int mpv_biomass_simulate(mpv_ctx* ctx, const mpv_biomass_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const float* x0,
@@ -363,11 +353,18 @@ int mpv_biomass_simulate(mpv_ctx* ctx, const mpv_biomass_desc* d, const int32_t*
     return launch_biomass_sim(ctx, *d, row_ptr, col_idx, x0, series_out);
 }
 
-int mpv_nsdiff_preact_bound(mpv_ctx* ctx, float* bound) {
-    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nsdiff_preact_bound: ctx is NULL");
-    if (!ctx->ns.loaded) return mpv_fail(ctx, MPV_ESTATE, "mpv_nsdiff_preact_bound: call mpv_nsdiff_load first");
-    if (!bound) return mpv_fail(ctx, MPV_EINVAL, "mpv_nsdiff_preact_bound: NULL argument");
-    *bound = ctx->ns.preact_bound23;
+int mpv_chain_stats(mpv_ctx* ctx, uint64_t* tile_steps, uint64_t* safe_steps, int reset) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_chain_stats: ctx is NULL");
+    DeviceGuard g(ctx->device);
+    MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long safe = 0;
+    if (ctx->chain_stats) MPV_HIP_TRY(ctx, hipMemcpy(&safe, ctx->chain_stats, sizeof(safe), hipMemcpyDeviceToHost));
+    if (tile_steps) *tile_steps = ctx->tile_steps;
+    if (safe_steps) *safe_steps = safe;
+    if (reset) {
+        ctx->tile_steps = 0;
+        if (ctx->chain_stats) MPV_HIP_TRY(ctx, hipMemset(ctx->chain_stats, 0, sizeof(safe)));
+    }
     return MPV_OK;
 }
 

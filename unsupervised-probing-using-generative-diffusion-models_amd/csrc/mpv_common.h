@@ -18,7 +18,6 @@ struct NsdiffModel {
     const unsigned *b2p, *b3p;
     const float *g1, *g2, *g3, *wsl, *w4h;
     float bone2 = 1.0f, bone3 = 1.0f, l1_scale = 1.0f;
-    float preact_bound23 = 1e30f;   // max over t, unit of |gamma| (||W_row||_2 + |b|) for layers 2 and 3
 };
 
 struct SigmaModel {
@@ -38,6 +37,12 @@ struct mpv_ctx {
     SigmaModel sg;
     double* reduce_ws = nullptr;   // partial sums of mpv_reduce
     unsigned long long* tile_counter = nullptr;   // work queue head of the split-f16 chain kernel (zeroed per launch)
+    unsigned long long* chain_stats = nullptr;    // [0] steps re-run through the exact routine (device counter)
+    unsigned long long tile_steps = 0;            // reverse steps launched on the split-f16 kernel (host count)
+    double* summary_acc = nullptr;                // fused summary accumulators [W][F][2]
+    size_t summary_acc_bytes = 0;
+    float* sample_ws = nullptr;                   // samples of a summary-only call that cannot use the fused epilogue
+    size_t sample_ws_bytes = 0;
     size_t reduce_ws_bytes = 0;
     // chain-kernel timing (HIP events on the launch stream)
     bool timing = false;
@@ -58,10 +63,11 @@ int mpv_reset_tile_counter(mpv_ctx* ctx);   // allocate on first use, zero it on
 
 // launchers implemented next to their kernels
 int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* gx,
-                        const float* noise, float* samples);
+                        const float* noise, const mpv_sample_out& out);
 namespace chain { struct ChainArgs; }
 int launch_chain_f16(mpv_ctx* ctx, const chain::ChainArgs& a, bool philox, int grid, int nf, int products, bool tmdm);
-int launch_tmdm_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* noise, float* samples);
+int launch_tmdm_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* noise, const mpv_sample_out& out);
+int chain_f16_summary_capacity(const mpv_ctx* ctx, int nf);
 int launch_biomass_sim(mpv_ctx* ctx, const mpv_biomass_desc& d, const int32_t* row_ptr, const int32_t* col_idx, const float* x0,
                        float* series_out);
 int launch_philox_dump(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out);

@@ -255,24 +255,66 @@ static void fill_model_args(ChainArgs& a, const NsdiffModel& m) {
     a.bone2 = m.bone2; a.bone3 = m.bone3; a.l1_scale = m.l1_scale; a.hi_mask = 0xFFFFE000u;
 }
 
-int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* gx,
-                        const float* noise, float* samples) {
-    const NsdiffModel& m = ctx->ns;
-    ChainArgs a{};
-    fill_model_args(a, m);
-    a.y0hat = y0hat; a.gx = gx; a.noise = noise; a.samples = samples;
-    a.T = m.steps; a.B = s.nodes; a.O = s.pred_len; a.S = s.n_samples; a.P = s.chunk; a.C = s.n_samples / s.chunk;
-    a.n_chains = (long long)s.n_windows * s.nodes * s.pred_len * s.n_samples;
-    a.n_tiles = (a.n_chains + TILE - 1) / TILE;
-    a.noise_kstride = (long long)s.nodes * s.chunk * s.pred_len * m.nf;
-    a.seed_lo = (unsigned)s.seed;
-    a.seed_hi = (unsigned)(s.seed >> 32) + (unsigned)(s.offset >> 32);
-    a.off_lo = (unsigned)s.offset;
-    if (a.n_chains == 0) return MPV_OK;
-    const long long wg_needed = (a.n_tiles + WAVES - 1) / WAVES;
-    const int grid = (int)(wg_needed < ctx->cu_count ? wg_needed : ctx->cu_count);   // 1 workgroup per CU (LDS-bound)
+// grow-only context workspace
+template <class T>
+static int ensure_ws(mpv_ctx* ctx, T** ptr, size_t* have, size_t need, const char* what) {
+    if (need <= *have) return MPV_OK;
+    if (*ptr) {
+        MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(*ptr);
+    }
+    *ptr = nullptr;
+    *have = 0;
+    if (hipMalloc(ptr, need) != hipSuccess) return mpv_fail(ctx, MPV_ENOMEM, what);
+    *have = need;
+    return MPV_OK;
+}
+
+__global__ void summary_finalize_kernel(const double* acc, int W, int F, long long R, float* mpv, float* pred_mean, float* mpv_feat) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    double vt = 0.0, mt = 0.0;
+    for (int f = 0; f < F; ++f) {
+        const double v = acc[(w * F + f) * 2], m = acc[(w * F + f) * 2 + 1];
+        if (mpv_feat) mpv_feat[w * F + f] = (float)(v / (double)R);
+        vt += v;
+        mt += m;
+    }
+    if (mpv) mpv[w] = (float)(vt / ((double)R * F));
+    if (pred_mean) pred_mean[w] = (float)(mt / ((double)R * F));
+}
+
+// Both samplers: geometry, the choice between the fused summary epilogue and sample + mpv_reduce, launches over
+// window groups when the LDS accumulator table cannot hold every window.
+static int run_chain(mpv_ctx* ctx, const NsdiffModel& m, bool tmdm, const mpv_sample_shape& s, const float* y0hat, const float* gx,
+                     const float* noise, const mpv_sample_out& out) {
+    const int F = m.nf;
+    const long long per_window = (long long)s.nodes * s.pred_len * s.n_samples;        // chains
+    if ((long long)s.n_windows * per_window == 0) return MPV_OK;
+    const bool want_summary = out.mpv || out.pred_mean || out.mpv_feat;
+    const bool f16 = s.gemm != MPV_GEMM_F32;
+    const int S = s.n_samples;
+    const bool s_ok = (S <= 32 && (S & (S - 1)) == 0) || (S % 32 == 0);
+    const int cap = (want_summary && f16 && s_ok) ? chain_f16_summary_capacity(ctx, F) : 0;
+    const bool fused = cap > 0;
+    float* samples = out.samples;
+    if (want_summary && !fused && !samples) {
+        if (int rc = ensure_ws(ctx, &ctx->sample_ws, &ctx->sample_ws_bytes, sizeof(float) * (size_t)s.n_windows * per_window * F,
+                               "sample workspace")) return rc;
+        samples = ctx->sample_ws;
+    }
+    if (fused) {
+        const size_t need = sizeof(double) * (size_t)s.n_windows * F * 2;
+        if (int rc = ensure_ws(ctx, &ctx->summary_acc, &ctx->summary_acc_bytes, need, "summary accumulators")) return rc;
+        MPV_HIP_TRY(ctx, hipMemsetAsync(ctx->summary_acc, 0, need, ctx->stream));
+    }
+    if (!ctx->chain_stats) {
+        MPV_HIP_TRY(ctx, hipMalloc(&ctx->chain_stats, sizeof(unsigned long long)));
+        MPV_HIP_TRY(ctx, hipMemsetAsync(ctx->chain_stats, 0, sizeof(unsigned long long), ctx->stream));
+    }
     if ((size_t)L_FLOATS * sizeof(float) > ctx->max_lds)
         return mpv_fail(ctx, MPV_EINVAL, "device LDS too small for the resident-weight chain kernel");
+    const bool philox = (noise == nullptr);
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {
@@ -280,53 +322,85 @@ int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0
         MPV_HIP_TRY(ctx, hipEventCreate(&e1));
         MPV_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
     }
-    int rc;
-    const bool philox = (noise == nullptr);
-    if (s.gemm == MPV_GEMM_F16X3 || s.gemm == MPV_GEMM_F16X2 || s.gemm == MPV_GEMM_F16) {
-        rc = launch_chain_f16(ctx, a, philox, grid, m.nf, s.gemm == MPV_GEMM_F16X3 ? 3 : (s.gemm == MPV_GEMM_F16X2 ? 2 : 1), false);
-    } else
-    switch (m.nf) {
-        case 1: rc = launch_f<1>(ctx, a, philox, grid); break;
-        case 2: rc = launch_f<2>(ctx, a, philox, grid); break;
-        case 3: rc = launch_f<3>(ctx, a, philox, grid); break;
-        case 4: rc = launch_f<4>(ctx, a, philox, grid); break;
-        default: return mpv_fail(ctx, MPV_EINVAL, "nf must be 1..4");
+    const int group = fused ? cap : s.n_windows;
+    for (int w0 = 0; w0 < s.n_windows; w0 += group) {
+        const int wn = (s.n_windows - w0 < group) ? s.n_windows - w0 : group;
+        const long long rows0 = (long long)w0 * s.nodes * s.pred_len;               // (w,b,o) rows before this group
+        ChainArgs a{};
+        fill_model_args(a, m);
+        a.y0hat = y0hat ? y0hat + rows0 * F : nullptr;
+        a.gx = gx ? gx + rows0 * F : nullptr;
+        a.noise = noise ? noise + (long long)w0 * per_window * m.steps * F : nullptr;
+        a.samples = samples ? samples + rows0 * F * S : nullptr;
+        a.T = m.steps; a.B = s.nodes; a.O = s.pred_len; a.S = S; a.P = s.chunk; a.C = S / s.chunk;
+        a.n_chains = (long long)wn * per_window;
+        a.n_tiles = (a.n_chains + TILE - 1) / TILE;
+        a.noise_kstride = (long long)s.nodes * s.chunk * s.pred_len * F;
+        a.seed_lo = (unsigned)s.seed;
+        a.seed_hi = (unsigned)(s.seed >> 32) + (unsigned)(s.offset >> 32);
+        a.off_lo = (unsigned)s.offset;
+        a.chain_base = rows0 * S;
+        a.sub = 1;
+        a.seg = 1;
+        a.stats = ctx->chain_stats;
+        if (fused) {
+            a.acc = ctx->summary_acc + (size_t)w0 * F * 2;
+            a.inv_std = out.std; a.inv_mean = out.mean;
+            a.seg = S < 32 ? S : 32;
+            a.sub = S <= 32 ? 1 : S / 32;
+            a.acc_windows = wn;
+        }
+        const long long wg_needed = (a.n_tiles / a.sub + WAVES - 1) / WAVES;
+        const int grid = (int)(wg_needed < ctx->cu_count ? wg_needed : ctx->cu_count);   // 1 workgroup per CU (LDS-bound)
+        int rc;
+        if (f16) {
+            rc = launch_chain_f16(ctx, a, philox, grid, F, s.gemm == MPV_GEMM_F16X3 ? 3 : (s.gemm == MPV_GEMM_F16X2 ? 2 : 1), tmdm);
+            ctx->tile_steps += (unsigned long long)a.n_tiles * m.steps;
+        } else if (tmdm) {
+            switch (F) {
+                case 1: rc = launch_f<1, true>(ctx, a, philox, grid); break;
+                case 2: rc = launch_f<2, true>(ctx, a, philox, grid); break;
+                case 3: rc = launch_f<3, true>(ctx, a, philox, grid); break;
+                case 4: rc = launch_f<4, true>(ctx, a, philox, grid); break;
+                default: return mpv_fail(ctx, MPV_EINVAL, "nf must be 1..4");
+            }
+        } else {
+            switch (F) {
+                case 1: rc = launch_f<1>(ctx, a, philox, grid); break;
+                case 2: rc = launch_f<2>(ctx, a, philox, grid); break;
+                case 3: rc = launch_f<3>(ctx, a, philox, grid); break;
+                case 4: rc = launch_f<4>(ctx, a, philox, grid); break;
+                default: return mpv_fail(ctx, MPV_EINVAL, "nf must be 1..4");
+            }
+        }
+        if (rc != MPV_OK) return rc;
     }
-    if (rc != MPV_OK) return rc;
     if (ctx->timing) {
         MPV_HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
         ctx->events.emplace_back(e0, e1);
     }
-    return MPV_OK;
+    if (!want_summary) return MPV_OK;
+    const long long R = (long long)s.nodes * s.pred_len;
+    if (fused) {
+        hipLaunchKernelGGL(summary_finalize_kernel, dim3((s.n_windows + 63) / 64), dim3(64), 0, ctx->stream, ctx->summary_acc,
+                           s.n_windows, F, R, out.mpv, out.pred_mean, out.mpv_feat);
+        MPV_HIP_TRY(ctx, hipGetLastError());
+        return MPV_OK;
+    }
+    // unfused: the stand-alone reduction over the sample tensor (it needs both scalar outputs; route missing ones to scratch)
+    if (int rc = ensure_ws(ctx, &ctx->summary_acc, &ctx->summary_acc_bytes, sizeof(double) * (size_t)s.n_windows * 2, "summary scratch")) return rc;
+    float* scratch = reinterpret_cast<float*>(ctx->summary_acc);
+    return launch_mpv_reduce(ctx, samples, s.n_windows, R, F, S, out.std, out.mean, out.mpv ? out.mpv : scratch,
+                             out.pred_mean ? out.pred_mean : scratch + s.n_windows, out.mpv_feat);
 }
 
-// TMDM sampler: same launch geometry, the exact-fp32 kernel with TMDM = true
-int launch_tmdm_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* noise, float* samples) {
-    const NsdiffModel& m = ctx->tm;
-    ChainArgs a{};
-    fill_model_args(a, m);
-    a.y0hat = y0hat; a.gx = nullptr; a.noise = noise; a.samples = samples;
-    a.T = m.steps; a.B = s.nodes; a.O = s.pred_len; a.S = s.n_samples; a.P = s.chunk; a.C = s.n_samples / s.chunk;
-    a.n_chains = (long long)s.n_windows * s.nodes * s.pred_len * s.n_samples;
-    a.n_tiles = (a.n_chains + TILE - 1) / TILE;
-    a.noise_kstride = (long long)s.nodes * s.chunk * s.pred_len * m.nf;
-    a.seed_lo = (unsigned)s.seed;
-    a.seed_hi = (unsigned)(s.seed >> 32) + (unsigned)(s.offset >> 32);
-    a.off_lo = (unsigned)s.offset;
-    if (a.n_chains == 0) return MPV_OK;
-    const long long wg_needed = (a.n_tiles + WAVES - 1) / WAVES;
-    const int grid = (int)(wg_needed < ctx->cu_count ? wg_needed : ctx->cu_count);
-    if ((size_t)L_FLOATS * sizeof(float) > ctx->max_lds)
-        return mpv_fail(ctx, MPV_EINVAL, "device LDS too small for the resident-weight chain kernel");
-    const bool philox = (noise == nullptr);
-    if (s.gemm == MPV_GEMM_F16X3) return launch_chain_f16(ctx, a, philox, grid, m.nf, 3, true);
-    switch (m.nf) {
-        case 1: return launch_f<1, true>(ctx, a, philox, grid);
-        case 2: return launch_f<2, true>(ctx, a, philox, grid);
-        case 3: return launch_f<3, true>(ctx, a, philox, grid);
-        case 4: return launch_f<4, true>(ctx, a, philox, grid);
-        default: return mpv_fail(ctx, MPV_EINVAL, "nf must be 1..4");
-    }
+int launch_nsdiff_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* gx,
+                        const float* noise, const mpv_sample_out& out) {
+    return run_chain(ctx, ctx->ns, false, s, y0hat, gx, noise, out);
+}
+
+int launch_tmdm_chain(mpv_ctx* ctx, const mpv_sample_shape& s, const float* y0hat, const float* noise, const mpv_sample_out& out) {
+    return run_chain(ctx, ctx->tm, true, s, y0hat, nullptr, noise, out);
 }
 
 int launch_philox_dump(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out) {

@@ -62,6 +62,10 @@ template <int F> struct Lds {                   // byte offsets
     static constexpr int GAM = HB + 32;                                  // per wave [3][128] scale rows
     static constexpr int BYTES = GAM + WAVES * 3 * HID * 4;
     static_assert(BYTES <= 160 * 1024, "LDS budget");
+    // fused summary (dynamic, only when ChainArgs::acc): per-wave row slots [WAVES][F][2] fp64, then the
+    // workgroup's accumulator table [acc_windows][F][2] fp64
+    static constexpr int SLOT = (BYTES + 7) & ~7;
+    static constexpr int TAB = SLOT + WAVES * F * 16;
 };
 
 // All LDS reads go through `smem + 32-bit offset`: the opaque per-step copies of the base OFFSETS keep the
@@ -742,6 +746,55 @@ __device__ __noinline__ Vec<F> chain_step_safe(StepCtx k, int t, Vec<F> y, Vec<F
     return heads_posterior<F, NORM>(k, t, a, ea, inv, y, mu, g, z);
 }
 
+// ---- fused summary (reference summarize_pred_future_list, diffusion_model_uncertainy.py:286-303) ---------------------
+// After the last step lanes 0..31 hold y_0 of 32 consecutive chains = `32/seg` whole (w,b,o) rows (seg = S <= 32) or
+// one 32-sample piece of a row (S a multiple of 32; the claim covers all S/32 pieces).  Per feature: inverse-scale in
+// fp32 as the reference does, sum x and sum x^2 inside the row segment by wavefront shuffles in fp64 (x^2 is exact in
+// fp64, so var = E[x^2] - E[x]^2 carries no cancellation worth speaking of), then add (var_row, mean_row) to the
+// workgroup's LDS table.  Out of line and after the step loop: nothing of it is live during the steps.
+__device__ __forceinline__ double shfl_xor_d(double v, int m) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __shfl_xor((unsigned)u, m), hi = __shfl_xor((unsigned)(u >> 32), m);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+template <int F>
+__device__ __noinline__ void summary_epilogue(const ChainArgs& p, const Vec<F>& y, bool valid, long long n, int lane, bool row_done,
+                                              double* row_slot, double* acc_tab) {
+    const long long row = n / p.S;
+    const int w = (int)(row / ((long long)p.O * p.B));
+    const double inv_s = 1.0 / (double)p.S;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        float x = y.v[f];
+        if (p.inv_std) x = x * p.inv_std[f] + p.inv_mean[f];
+        double d1 = valid ? (double)x : 0.0;
+        double d2 = d1 * d1;
+        for (int m = 1; m < p.seg; m <<= 1) {                 // wave-uniform trip count
+            d1 += shfl_xor_d(d1, m);
+            d2 += shfl_xor_d(d2, m);
+        }
+        if (p.sub == 1) {
+            if (valid && lane < 32 && (lane & (p.seg - 1)) == 0) {
+                const double mean = d1 * inv_s;
+                atomicAdd(&acc_tab[(w * F + f) * 2], d2 * inv_s - mean * mean);
+                atomicAdd(&acc_tab[(w * F + f) * 2 + 1], mean);
+            }
+        } else if (lane == 0) {                               // S = 32 * sub: this wave owns the whole row, piece by piece
+            d1 += row_slot[f * 2];
+            d2 += row_slot[f * 2 + 1];
+            if (row_done) {
+                const double mean = d1 * inv_s;
+                atomicAdd(&acc_tab[(w * F + f) * 2], d2 * inv_s - mean * mean);
+                atomicAdd(&acc_tab[(w * F + f) * 2 + 1], mean);
+                d1 = d2 = 0.0;
+            }
+            row_slot[f * 2] = d1;
+            row_slot[f * 2 + 1] = d2;
+        }
+    }
+}
+
 template <int F, bool PHILOX, int NP, bool NORM>
 __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -768,6 +821,10 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
             f[LD::HB / 4 + threadIdx.x] = p.b4[threadIdx.x];
             f[LD::HB / 4 + 4 + threadIdx.x] = p.bs[threadIdx.x];
         }
+    }
+    if (p.acc) {
+        double* z = reinterpret_cast<double*>(smem + LD::SLOT);
+        for (int i = threadIdx.x; i < WAVES * F * 2 + p.acc_windows * F * 2; i += THREADS) z[i] = 0.0;
     }
     __syncthreads();
 
@@ -799,9 +856,14 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
     unsigned char* const gam_w = smem + LD::GAM + wave * (3 * HID * 4);
     const int gl = (lane & 31) * 16;                                              // scale-row staging: 16 B per lane
 
+    double* const acc_tab = reinterpret_cast<double*>(smem + LD::TAB);
+    double* const row_slot = reinterpret_cast<double*>(smem + LD::SLOT) + wave * (F * 2);
+    const int n_sub = p.sub;                                  // 1 unless the fused summary needs S/32 tiles per row
     for (;;) {
-        const long long tile = claim_tile(p.tile_counter, lane);
-        if (tile >= p.n_tiles) break;
+        const long long claim = claim_tile(p.tile_counter, lane);
+        if (claim * n_sub >= p.n_tiles) break;
+      for (int sub = 0; sub < n_sub; ++sub) {
+        const long long tile = claim * n_sub + sub;
         const long long n_raw = tile * TILE + r_lane;
         const bool valid = n_raw < p.n_chains;
         const long long n = valid ? n_raw : p.n_chains - 1;
@@ -826,7 +888,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
                     (long long)o * F;
         }
         if (PHILOX) {
-            next_normals<F>((unsigned long long)n, 0u, p, zc, z);
+            next_normals<F>((unsigned long long)(n + p.chain_base), 0u, p, zc, z);
         } else {
 #pragma unroll
             for (int f = 0; f < F; ++f) z[f] = p.noise[nbase + f];
@@ -864,7 +926,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
             }
             if (t > 0) {
                 if (PHILOX) {
-                    next_normals<F>((unsigned long long)n, (unsigned)(p.T - t), p, zc, z);
+                    next_normals<F>((unsigned long long)(n + p.chain_base), (unsigned)(p.T - t), p, zc, z);
                 } else {
 #pragma unroll
                     for (int f = 0; f < F; ++f) z[f] = p.noise[nbase + (long long)(p.T - t) * p.noise_kstride + f];
@@ -875,7 +937,10 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
             bool ok = true;
             TR(9);
             Vec<F> yn = chain_step_fast<F, NP, NORM>(k, t, y, mu, g, zv, ok TR_ARGS);
-            if (__builtin_expect(!__all(ok), 0)) yn = chain_step_safe<F, NORM>(k, t, y, mu, g, zv);
+            if (__builtin_expect(!__all(ok), 0)) {
+                yn = chain_step_safe<F, NORM>(k, t, y, mu, g, zv);
+                if (lane == 0 && p.stats) atomicAdd(p.stats, 1ull);
+            }
             y = yn;
             if (t > 0 && lane < 32) {                       // all reads of this step's rows are done (same wave, in order)
                 *reinterpret_cast<f32x4*>(gam_w + gl) = nx1;
@@ -891,9 +956,19 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
             atomicAdd(&mpv_trace[14], (unsigned long long)p.T);
         }
 #endif
-        if (valid && h_lane == 0) {
+        if (p.samples && valid && h_lane == 0) {
 #pragma unroll
             for (int f = 0; f < F; ++f) p.samples[(row * F + f) * p.S + s] = y.v[f];
+        }
+        if (p.acc) summary_epilogue<F>(p, y, valid, n, lane, sub == n_sub - 1, row_slot, acc_tab);
+      }
+    }
+    if (p.acc) {                                              // one flush per workgroup: W*F*2 fp64 atomics
+        __syncthreads();
+        const int cells = p.acc_windows * F * 2;
+        for (int i = threadIdx.x; i < cells; i += THREADS) {
+            const double v = acc_tab[i];
+            if (v != 0.0) atomicAdd(p.acc + i, v);
         }
     }
 #ifdef MPV_TRACE
@@ -910,7 +985,7 @@ template <int F, int NP, bool NORM = true>
 int launch_f16_f(mpv_ctx* ctx, const ChainArgs& a, bool philox, int grid) {
     auto kp = nsdiff_chain_f16_kernel<F, true, NP, NORM>;
     auto kn = nsdiff_chain_f16_kernel<F, false, NP, NORM>;
-    constexpr int lds = Lds<F>::BYTES;
+    const int lds = a.acc ? Lds<F>::TAB + a.acc_windows * F * 16 : Lds<F>::BYTES;
     if ((size_t)lds > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "device LDS too small for the resident-weight chain kernel");
     MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(philox ? kp : kn),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -938,6 +1013,13 @@ extern "C" int mpv_debug_trace(unsigned long long* out16, int reset) {
     return 0;
 }
 #endif
+
+// windows whose [F][2] fp64 accumulators fit in the LDS left beside the resident weights (0 = none: nf out of range)
+int chain_f16_summary_capacity(const mpv_ctx* ctx, int nf) {
+    const long long tab = nf == 1 ? Lds<1>::TAB : (nf == 2 ? Lds<2>::TAB : (nf == 3 ? Lds<3>::TAB : -1));
+    if (tab < 0 || (long long)ctx->max_lds <= tab) return 0;
+    return (int)(((long long)ctx->max_lds - tab) / (nf * 16));
+}
 
 int launch_chain_f16(mpv_ctx* ctx, const chain::ChainArgs& a, bool philox, int grid, int nf, int products, bool tmdm) {
     if (nf < 1 || nf > 3) return mpv_fail(ctx, MPV_EINVAL, "the split-f16 sampler supports nf 1..3 (use MPV_GEMM_F32 for nf = 4)");

@@ -116,11 +116,11 @@ __global__ __launch_bounds__(SG_THREADS) void sigma_head_kernel(const SigmaArgs 
     constexpr int R = GROUPS * F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* red = reinterpret_cast<double*>(smem);                 // 8 doubles
-    float* xw = reinterpret_cast<float*>(smem + 64);              // [GROUPS][F][Tw]
     const int K0p = (p.K0 + 3) & ~3;                               // row stride of v: 16-byte aligned rows
     const int Twp = (p.Tw + 3) & ~3;
-    float* v = xw + GROUPS * F * Twp;                              // [GROUPS][F][K0p]
-    float* h1 = v + GROUPS * F * K0p;                              // [GROUPS][F][H]
+    float* v = reinterpret_cast<float*>(smem + 64);               // [GROUPS][F][K0p]
+    float* xw = v + GROUPS * F * K0p;                              // [GROUPS][F][Twp]: dead once v is formed, so the
+    float* h1 = xw;                                                // hidden layers reuse its space: [GROUPS][F][H]
     float* h2 = h1 + GROUPS * F * p.H;                             // [GROUPS][F][H]
 
     const long long g0 = (long long)blockIdx.x * GROUPS;
@@ -128,7 +128,6 @@ __global__ __launch_bounds__(SG_THREADS) void sigma_head_kernel(const SigmaArgs 
     const int ng = (int)(left < GROUPS ? left : GROUPS);
     if (ng < GROUPS) {                                             // rows of a ragged last workgroup: zeros, never stored
         for (int i = threadIdx.x; i < R * K0p; i += SG_THREADS) v[i] = 0.0f;
-        for (int i = threadIdx.x; i < R * p.H; i += SG_THREADS) h1[i] = h2[i] = 0.0f;
     }
 
     // ---- gather + scale the windows: xw[g][f][t] --------------------------------------
@@ -159,6 +158,10 @@ __global__ __launch_bounds__(SG_THREADS) void sigma_head_kernel(const SigmaArgs 
         v[(i / p.K0) * K0p + pos] = (float)(q / p.k) + 10e-8f;
     }
     __syncthreads();
+    if (ng < GROUPS) {                                             // (xw is dead now: its space becomes h1 / h2)
+        for (int i = threadIdx.x; i < R * p.H; i += SG_THREADS) h1[i] = h2[i] = 0.0f;
+        __syncthreads();
+    }
     // ---- MLP --------------------------------------------------------------------------
     dense<true, R>(p.w0t, p.b0, v, K0p, h1, p.H, p.K0, p.H, ng * F);
     __syncthreads();
@@ -178,10 +181,20 @@ __global__ __launch_bounds__(SG_THREADS) void sigma_head_kernel(const SigmaArgs 
     }
 }
 
+// LDS of one workgroup: v rows + max(window rows, two hidden layers)
+static size_t sigma_lds_bytes(const SigmaArgs& a, int groups) {
+    const size_t twp = (a.Tw + 3) & ~3, k0p = (a.K0 + 3) & ~3, hid = 2 * (size_t)a.H;
+    return 64 + sizeof(float) * (size_t)groups * a.F * (k0p + (twp > hid ? twp : hid));
+}
+
+// G rows per workgroup: as many as the accumulator registers allow (G*F = 16), halved until the staging fits the LDS
 template <int F, int GROUPS>
 int launch_sigma_fg(mpv_ctx* ctx, const SigmaArgs& a) {
-    const size_t lds = 64 + sizeof(float) * (size_t)GROUPS * F * (((a.Tw + 3) & ~3) + ((a.K0 + 3) & ~3) + 2 * a.H);
-    if (lds > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "sigma head: window too long for LDS staging");
+    const size_t lds = sigma_lds_bytes(a, GROUPS);
+    if (lds > ctx->max_lds) {
+        if constexpr (GROUPS > 1) return launch_sigma_fg<F, GROUPS / 2>(ctx, a);
+        else return mpv_fail(ctx, MPV_EINVAL, "sigma head: window too long for LDS staging even with one row per workgroup");
+    }
     MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sigma_head_kernel<F, GROUPS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long blocks = (a.n_groups + GROUPS - 1) / GROUPS;

@@ -188,6 +188,13 @@ def _load_tensor_list(cache_path):
     return data_list
 
 
+def _save_on_primary(data_list, cache_path):
+    """One writer per cache file: rank 0 saves, the others wait until the file is complete."""
+    if dist_utils.is_primary():
+        _save_tensor_list(data_list, cache_path)
+    dist_utils.barrier()
+
+
 def read_sensitivity_pred_future_cache(cache_path):
     try:
         return _load_tensor_list(cache_path)
@@ -297,22 +304,34 @@ def _stack_windows(window_list: Sequence[torch.Tensor]) -> torch.Tensor:
     return torch.stack([torch.as_tensor(w).float() for w in window_list], dim=0).flatten(0, 1)
 
 
-def _sample_stacked(model, window_list, pred_len, scale: bool):
-    """All windows in as few launches as memory allows.  Returns per-window CPU tensors
-    [V, pred_len, F, S] plus the device-side MPV / pred_mean (inverse-scaled as summarize does)."""
-    if not window_list:
-        return [], np.zeros(0, np.float32), np.zeros(0, np.float32)
-    V = int(window_list[0].shape[0])
+# Test hook: callable(model, windows, pred_len, scale) -> (samples [w, V, pred_len, F, S], mpv [w], pred_mean [w]) that
+# replaces the device computation of ONE shard (tests/test_distributed_gloo.py injects the CPU oracle here so that the
+# sharding, gathering and cache logic around it run under gloo without a GPU).  Never set by the product.
+SHARD_COMPUTE = None
+
+
+def _skip_host_noise(model, n_windows: int, nodes: int):
+    """torch_cpu noise under sharding: the reference draws window after window from ONE stream, so a rank whose block
+    starts at window `n_windows` first consumes the draws of the windows before it (drawn and dropped one window at a
+    time: the CPU generator has no skip-ahead)."""
+    if getattr(model, "noise_source", "philox") != "torch_cpu":
+        return
+    for _ in range(n_windows):
+        model.host_noise(1, nodes)
+
+
+def _native_shard(model, windows, pred_len, scale, keep_samples=True):
+    """This rank's windows on the device: as few launches as memory allows.  keep_samples=False (curve-only runs of a
+    stacked model whose horizon is not cut) never materialises the sample tensor: the summary comes out of the sampler."""
+    V = int(windows[0].shape[0])
     ctx = model.native_context()
-    lo, hi = dist_utils.shard_bounds(len(window_list))
-    preds: List[torch.Tensor] = []
-    mpv_parts, mean_parts = [], []
+    inv_std = model.scaler_std.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
+    inv_mean = model.scaler_mean.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
+    preds, mpv_parts, mean_parts = [], [], []
     if not hasattr(model, "_prior_variance"):
         # a model family without the stacked NsDiff entry (TMDM: its prior is the caller's torch module): the reference's
         # own window loop, one evaluation_step per window (still the native sampler), then the device reduction
-        inv_std = model.scaler_std.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
-        inv_mean = model.scaler_mean.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
-        for w in window_list[lo:hi]:
+        for w in windows:
             x = torch.as_tensor(w).float()
             if scale:
                 x = model.scaler_transform(x.to(model.scaler_mean.device))
@@ -321,29 +340,89 @@ def _sample_stacked(model, window_list, pred_len, scale: bool):
             mpv, pm, _ = ctx.reduce(outs.to(ctx.device).unsqueeze(0).contiguous(), inv_std, inv_mean)
             mpv_parts.append(mpv)
             mean_parts.append(pm)
-            preds.append(outs.cpu())
-        mpv_local = torch.cat(mpv_parts) if mpv_parts else torch.zeros(0, device=ctx.device)
-        mean_local = torch.cat(mean_parts) if mean_parts else torch.zeros(0, device=ctx.device)
-        mpv_all, mean_all = dist_utils.gather_curve(len(window_list), lo, hi, mpv_local, mean_local)
-        return preds, mpv_all, mean_all
-    chunk = _windows_per_launch(model, V)
-    inv_std = model.scaler_std.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
-    inv_mean = model.scaler_mean.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
-    for start in range(lo, hi, chunk):
-        part = window_list[start: min(start + chunk, hi)]
-        rows = _stack_windows(part).to(ctx.device)                        # [w*V, windows, F]
-        # one pseudo-window over w*V rows; the scaler is fused into the sigma-head load
-        samples, _ = model.sample_windows(rows, 1, 0, 1, scale_input=scale, noise=_host_noise_for(model, len(part), V))
-        samples = samples.reshape(len(part), V, model.pred_len, model.dataset_nf, -1)[:, :, -pred_len:]
-        samples = samples.contiguous()
-        mpv, pm, _ = ctx.reduce(samples, inv_std, inv_mean)
-        mpv_parts.append(mpv)
-        mean_parts.append(pm)
-        preds.extend(samples.cpu().unbind(0))
-    mpv_local = torch.cat(mpv_parts) if mpv_parts else torch.zeros(0, device=ctx.device)
-    mean_local = torch.cat(mean_parts) if mean_parts else torch.zeros(0, device=ctx.device)
-    mpv_all, mean_all = dist_utils.gather_curve(len(window_list), lo, hi, mpv_local, mean_local)
-    return preds, mpv_all, mean_all
+            preds.append(outs.unsqueeze(0))
+    else:
+        chunk = _windows_per_launch(model, V)
+        for start in range(0, len(windows), chunk):
+            part = windows[start: start + chunk]
+            rows = _stack_windows(part).to(ctx.device)                        # [w*V, windows, F]
+            noise = _host_noise_for(model, len(part), V)
+            if not keep_samples and pred_len == model.pred_len:
+                # windows as the launch's window axis so that the fused summary is per window
+                rows4 = rows.reshape(len(part), V, rows.shape[1], rows.shape[2])
+                _, mpv, pm = _summary_only(model, rows4, scale, noise)
+                mpv_parts.append(mpv)
+                mean_parts.append(pm)
+                preds.append(torch.zeros((len(part), 0), device=ctx.device))
+                continue
+            # one pseudo-window over w*V rows; the scaler is fused into the sigma-head load
+            samples, _ = model.sample_windows(rows, 1, 0, 1, scale_input=scale, noise=noise)
+            samples = samples.reshape(len(part), V, model.pred_len, model.dataset_nf, -1)[:, :, -pred_len:]
+            samples = samples.contiguous()
+            mpv, pm, _ = ctx.reduce(samples, inv_std, inv_mean)
+            mpv_parts.append(mpv)
+            mean_parts.append(pm)
+            preds.append(samples if dist_utils.active() else samples.cpu())     # sharded: gathered from device memory
+    return torch.cat(preds, dim=0), torch.cat(mpv_parts), torch.cat(mean_parts)
+
+
+def _summary_only(model, rows4, scale, noise):
+    """[w, V, windows, F] stacked windows -> (None, mpv [w], pred_mean [w]) without a sample tensor: sigma head over
+    w*V rows, then ONE sampler launch with w windows of V nodes whose epilogue reduces every (node, horizon, feature) row."""
+    w, V = rows4.shape[0], rows4.shape[1]
+    ctx = model.native_context()
+    flat = rows4.reshape(w * V, rows4.shape[2], rows4.shape[3]).contiguous()
+    gx = model._prior_variance(ctx, flat, 1, 0, 1, scale).reshape(w, V, model.pred_len, model.dataset_nf)
+    y0hat = None
+    if getattr(model, "needs_backbone", False):
+        wins = (flat - model.scaler_mean.to(flat.device)) / model.scaler_std.to(flat.device) if scale else flat
+        y0hat = model._backbone_mean(wins).to(ctx.device).float().reshape(gx.shape).contiguous()
+    S, P = model._check_sampling_config()
+    std = mean = None
+    if _uses_scaler(model):
+        std, mean = model.scaler_std.to(ctx.device).float().contiguous(), model.scaler_mean.to(ctx.device).float().contiguous()
+    if noise is not None:                                    # [1, C, T, (w*V)*P, O, F] of the stacked launch -> [w, C, T, V*P, O, F]
+        _, C_, T_, _, O_, F_ = noise.shape
+        noise = noise.reshape(C_, T_, w, V * P, O_, F_).permute(2, 0, 1, 3, 4, 5).contiguous().to(ctx.device)
+        seed = 0
+    else:
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    _, mpv, pm, _ = ctx.sample(gx.contiguous(), y0hat, S, P, noise=noise, seed=seed, gemm=model.gemm_mode, summary=True,
+                               want_samples=False, std=std, mean=mean)
+    return None, mpv, pm
+
+
+def _sample_stacked(model, window_list, pred_len, scale: bool, keep_samples: bool = True):
+    """All windows of a trajectory -> (list of W CPU tensors [V, pred_len, F, S], MPV [W], pred_mean [W]).
+
+    With torch.distributed active every rank computes a contiguous block of windows (`distributed.shard_bounds`), then
+    the per-window scalars AND the sample tensors are all-gathered, so every rank returns the complete, identical
+    result: the reference's list holds one entry per window (reference :323-339) and the cache written from it must too."""
+    n = len(window_list)
+    if n == 0:
+        return [], np.zeros(0, np.float32), np.zeros(0, np.float32)
+    lo, hi = dist_utils.shard_bounds(n)
+    V = int(window_list[0].shape[0])
+    compute = SHARD_COMPUTE or _native_shard
+    if hi > lo:
+        if lo > 0:
+            _skip_host_noise(model, lo, V)
+        if keep_samples:
+            samples, mpv_local, mean_local = compute(model, list(window_list[lo:hi]), pred_len, scale)
+        else:
+            samples, mpv_local, mean_local = compute(model, list(window_list[lo:hi]), pred_len, scale, keep_samples=False)
+    else:                                   # more ranks than windows: an empty block still joins the collectives
+        cfg = getattr(model, "configs", model)
+        S = int(getattr(cfg, "n_z_samples", getattr(model, "n_z_samples", 1)))
+        nccl = dist_utils.active() and torch.distributed.get_backend() == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+        samples = torch.zeros((0, V, pred_len, int(window_list[0].shape[-1]), S), device=dev)
+        mpv_local = mean_local = torch.zeros(0, device=dev)
+    mpv_all, mean_all = dist_utils.gather_curve(n, lo, hi, mpv_local, mean_local)
+    if not keep_samples:
+        return None, mpv_all, mean_all
+    full = dist_utils.gather_windows(n, lo, hi, samples)
+    return list(full.unbind(0)), mpv_all, mean_all
 
 
 def _host_noise_for(model, n_windows: int, nodes: int):
@@ -365,21 +444,28 @@ class _DeviceCurve(list):
     pred_mean: Optional[np.ndarray] = None
 
 
-def run_evaluation_cache(model, timeseries_datas, pred_len, cache_path, device, force_recompute=False, max_windows=None):
+def run_evaluation_cache(model, timeseries_datas, pred_len, cache_path, device, force_recompute=False, max_windows=None,
+                         store_samples=True):
     """Windows -> list of CPU tensors [V, pred_len, F, n_z_samples], cached (reference :323-339).
 
     The reference leaves `time_series_trans` unbound when `model.scaler is None`; here an
-    unscaled model simply samples the raw window."""
+    unscaled model simply samples the raw window.  store_samples=False (extension): curve only -- nothing is cached, the
+    returned list is empty and carries the device-reduced `ews` / `pred_mean`; no sample tensor is ever written."""
     cache_path = Path(cache_path)
     if cache_path.exists() and not force_recompute:
         return _load_tensor_list(cache_path)
     windows = list(timeseries_datas[:max_windows] if max_windows is not None else timeseries_datas)
+    if not store_samples:
+        with torch.no_grad():
+            _, mpv, pm = _sample_stacked(model, windows, pred_len, scale=_uses_scaler(model), keep_samples=False)
+        out = _DeviceCurve()
+        out.ews, out.pred_mean = mpv, pm
+        return out
     with torch.no_grad():
         preds, mpv, pm = _sample_stacked(model, windows, pred_len, scale=_uses_scaler(model))
     out = _DeviceCurve(preds)
     out.ews, out.pred_mean = mpv, pm
-    if dist_utils.is_primary() or not dist_utils.active():
-        _save_tensor_list(list(out), cache_path)
+    _save_on_primary(list(out), cache_path)
     return out
 
 
@@ -395,8 +481,7 @@ def run_slbp_sensitivity_cache(model, input_datas, cache_path, device, force_rec
     with torch.no_grad():
         preds, _, _ = _sample_stacked(model, windows, model.pred_len, scale=_uses_scaler(model))
     preds = [p.squeeze(0) for p in preds]
-    if dist_utils.is_primary() or not dist_utils.active():
-        _save_tensor_list(preds, cache_path)
+    _save_on_primary(preds, cache_path)
     return preds
 
 
@@ -420,7 +505,7 @@ def run_nsdiff_g_cache(model, timeseries_datas, cache_path, device, pred_dim=0, 
         if pred_dim >= gx.shape[-1]:
             raise IndexError("pred_dim {} out of bounds for F={}.".format(pred_dim, gx.shape[-1]))
         g_list = list(gx.unbind(0))
-    _save_tensor_list(g_list, cache_path)
+    _save_on_primary(g_list, cache_path)
     return g_list
 
 
@@ -661,7 +746,7 @@ def run_slbp_gx_cache_for_fig6(model, input_datas, cache_path, device, pred_dim=
         if pred_dim >= gx.shape[-1]:
             raise IndexError("pred_dim {} out of bounds for F={}.".format(pred_dim, gx.shape[-1]))
         gx_list = list(gx.unbind(0))
-    _save_tensor_list(gx_list, cache_path)
+    _save_on_primary(gx_list, cache_path)
     return gx_list
 
 
@@ -862,11 +947,13 @@ _METHOD_ALIASES = {"variance": "sampling", "sampling_variance": "sampling", "pre
 def uncertainty_ews(model_save_file=None, data_file=None, torch_time_series=None, time_data=None, dynamic_type=None,
                     task_model=None, graph_file=None, cache_path=None, sample_window_step=None, sampling_t=None,
                     infer_params=None, pred_dim=0, force_recompute=False, save_nsdiff_g=True, nsdiff_g_path=None,
-                    uncertainty_method="sampling", max_windows=None, device=None, load_model_when_cached=False):
+                    uncertainty_method="sampling", max_windows=None, device=None, load_model_when_cached=False,
+                    store_samples=True):
     """Trajectory + trained model -> MPV early-warning curve (reference :1253-1541).
 
     Same arguments and result keys as the reference.  `uncertainty_method`: "sampling" (variance
-    of N sampled futures), "gx" (sigma head only) or "both".
+    of N sampled futures), "gx" (sigma head only) or "both".  Extension: store_samples=False computes the curve only (the
+    MPV reduction runs in the sampler's epilogue, no sample tensor, no cache file, `pred_future_list` is None).
     """
     dynamic_type = _dynamic_name(dynamic_type)
     method = _METHOD_ALIASES.get(str(uncertainty_method).lower(), str(uncertainty_method).lower())
@@ -938,11 +1025,11 @@ def uncertainty_ews(model_save_file=None, data_file=None, torch_time_series=None
                 need_model()
         else:
             preds = run_evaluation_cache(need_model(), window_views, pred_len, cache_path, device,
-                                         force_recompute=force_recompute, max_windows=max_windows)
+                                         force_recompute=force_recompute, max_windows=max_windows, store_samples=store_samples)
         pred_mean_list, ews_list = summarize_pred_future_list(preds, model=model)
 
     result = {
-        "pred_future_list": list(preds) if preds is not None else None,
+        "pred_future_list": list(preds) if (preds is not None and (store_samples or len(preds))) else None,
         "pred_mean": pred_mean_list, "ews": ews_list, "time_points": time_points[: len(ews_list)],
         "cache_path": str(cache_path), "figure_path": str(resolve_figure_path(cache_path)),
         "torch_time_series": torch_time_series, "time_data": torch.as_tensor(time_data).cpu().detach().numpy(),

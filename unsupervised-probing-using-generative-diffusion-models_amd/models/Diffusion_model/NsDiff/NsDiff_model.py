@@ -161,13 +161,19 @@ class _NsDiffBase(nn.Module):
 
     def sample_windows(self, series: torch.Tensor, n_windows: int, first: int = 0, step: int = 1, *,
                        scale_input: bool = False, y0hat: Optional[torch.Tensor] = None,
-                       noise: Optional[torch.Tensor] = None, seed: Optional[int] = None, offset: int = 0):
+                       noise: Optional[torch.Tensor] = None, seed: Optional[int] = None, offset: int = 0,
+                       summary: bool = False, want_samples: bool = True, inverse_scale: bool = True):
         """Batched device path: series [V, L, F] (resident, sub-sampled) -> samples
         [n_windows, V, pred_len, F, n_z_samples] on device, plus the gx it used.
 
         Window w covers series[:, first + w*step : first + w*step + windows].  With
         scale_input the scaler is fused into the load (raw series in); otherwise the series
         must already be scaled.  One sigma-head launch and one chain launch in total.
+
+        summary=True also returns the per-window MPV and prediction mean (the reduction fused into the sampler's
+        epilogue; inverse-scaled with the model's scaler when `inverse_scale` and the model has one, as
+        summarize_pred_future_list does): (samples | None, gx, mpv [W], pred_mean [W]).  want_samples=False skips the
+        sample tensor (curve-only runs).
         """
         if getattr(self, "model", None) is None:
             raise RuntimeError("this model has no diffusion network (train_model_select={!r})".format(
@@ -190,8 +196,16 @@ class _NsDiffBase(nn.Module):
             noise = noise.to(device=ctx.device, dtype=torch.float32).contiguous()
         elif seed is None:
             seed = _draw_seed()
-        samples = ctx.sample(gx, y0hat, S, P, noise=noise, seed=seed or 0, offset=offset, gemm=self.gemm_mode)
-        return samples, gx
+        if not summary:
+            samples = ctx.sample(gx, y0hat, S, P, noise=noise, seed=seed or 0, offset=offset, gemm=self.gemm_mode)
+            return samples, gx
+        std = mean = None
+        if inverse_scale and self.scaler is not None:
+            std = self.scaler_std.to(ctx.device).float().contiguous()
+            mean = self.scaler_mean.to(ctx.device).float().contiguous()
+        samples, mpv, pm, _ = ctx.sample(gx, y0hat, S, P, noise=noise, seed=seed or 0, offset=offset, gemm=self.gemm_mode,
+                                         summary=True, want_samples=want_samples, std=std, mean=mean)
+        return samples, gx, mpv, pm
 
     def _evaluation_step(self, batch, y0hat, noise):
         if batch.dim() != 3 or batch.shape[1] < self.windows:
