@@ -85,9 +85,11 @@ def launch_workers(args) -> int:
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     out, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if out:
-        sys.stdout.write(out)
-        sys.stdout.flush()
+    for line in (out or "").splitlines():               # rank 0 prints exactly one JSON record; drop library banners (gloo)
+        if line.startswith("{"):
+            print(line, flush=True)
+        elif line.strip():
+            print(line, file=sys.stderr)
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
         print("bench workers failed: " + ", ".join("rank %d rc %d" % rc for rc in bad), file=sys.stderr)

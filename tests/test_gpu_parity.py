@@ -269,7 +269,7 @@ def test_fast_and_guarded_activation_paths_are_both_exercised(ckpt_wofx):
     big, huge = dict(sd), dict(sd)
     for i in (2, 3):
         big[O.EPS_NET + "lin%d.lin.weight" % i] = sd[O.EPS_NET + "lin%d.lin.weight" % i] * 60.0
-        huge[O.EPS_NET + "lin%d.lin.weight" % i] = sd[O.EPS_NET + "lin%d.lin.weight" % i] * 400.0     # 2^x' overflows fp32
+        huge[O.EPS_NET + "lin%d.lin.weight" % i] = sd[O.EPS_NET + "lin%d.lin.weight" % i] * 4000.0    # 2^x' overflows fp32
     ctx_big, ctx_huge = make_ctx(big, 1, 10), make_ctx(huge, 1, 10)
     g = torch.Generator().manual_seed(9)
     gx = (torch.rand(1, 4, 6, 1, generator=g) + 0.1)
@@ -549,7 +549,7 @@ def test_fused_summary_equals_reduce_of_the_same_samples(nf, S, gemm):
     none, mpv2, pm2, _ = ctx.sample(gx, y0, S, S, seed=11, gemm=gemm, summary=True, want_samples=False, std=std, mean=mean)
     assert none is None and rel_err(mpv2, mpv) < 1e-6 and rel_err(pm2, pm) < 1e-6
     _, mpv3, _, _ = ctx.sample(gx, y0, S, S, seed=12, gemm=gemm, summary=True, want_samples=False)      # other seed, no scaling
-    assert not torch.equal(mpv3, mpv2)
+    assert S == 1 or not torch.equal(mpv3, mpv2)
 
 
 def test_fused_summary_over_window_groups_and_tmdm(golden_tmdm):

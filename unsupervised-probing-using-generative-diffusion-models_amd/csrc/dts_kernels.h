@@ -1,0 +1,492 @@
+// DiffusionTS transformer for gfx950: device kernels (forward and input-gradient).
+//
+// Follows reference models/Diffusion_model/DiffusionTS/diffusionts_transformer.py:12-438 and
+// diffusionts_model_utils.py:158-202 (Conv_MLP, AdaLayerNorm).  Activations are fp32 [B][L][D] ("token major", D fastest).
+// Every dense contraction runs on the exact-fp32 matrix pipe, v_mfma_f32_16x16x4_f32 (the Langevin infill update is
+// g / (|g| + 1e-10), i.e. sign descent: reduced-precision products would flip signs and leave the reference's trajectory):
+//   * dts_lin_kernel      token-wise Linear  Y^T[n][tok] = W[n][k] X^T[k][tok]  with LayerNorm / AdaLayerNorm / GELU / GELU'
+//                         prologues and bias / residual / accumulate epilogues  (QKV, proj, MLP, and their transposes)
+//   * dts_seqmix_kernel   per-sequence  Y_b = W X_b  (Conv1d(L -> 2L, k=1) over the TOKEN axis, its transpose, the real DFT)
+//   * dts_attn_*          softmax attention per (sequence, head): forward (online softmax), dQ pass, dK/dV pass.  A 16x16
+//                         score tile in accumulator layout (column = lane&15, rows = 4*(lane>>4)+reg) is directly the B
+//                         operand of the next product, so P never leaves registers and nothing is transposed.
+// Operand convention of the builtin: lane l supplies A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; D[i = 4*(l>>4)+r][j = l&15].
+// A lane reads 4 consecutive k (one ds_read_b128) and issues 4 MFMAs; MFMA e then contracts k = {16s + 4g + e : g = 0..3}.
+#pragma once
+#include "mpv_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace dts {
+
+#define DTS_MMA(acc, a, b) (acc) = __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (acc), 0, 0, 0)
+
+constexpr float LOG2E = 1.44269504088896341f;
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// token-wise Linear
+// ---------------------------------------------------------------------------------------------------------------------
+enum { PRO_NONE = 0, PRO_LN = 1, PRO_ADALN = 2, PRO_GELUGRAD = 3, PRO_GELU = 4 };
+
+struct LinArgs {
+    const float* X; int ldx;        // [rows][ldx], first K columns
+    const float* W;                 // [N][K]
+    const float* bias;              // [N] | null
+    const float* R; int ldr;        // residual [rows][ldr] | null
+    float* Y; int ldy;              // [rows][ldy]
+    const float* P1; const float* P2;   // LN: weight, bias [K]; ADALN: scale, shift [K]; GELUGRAD: P1 = u [rows][ldp]
+    int ldp;
+    long long rows;
+    int K, N;
+    int pro;
+    int accumulate;                 // Y += result
+};
+
+constexpr int LIN_TM = 64;          // tokens per workgroup pass
+constexpr int LIN_THREADS = 256;
+
+__global__ __launch_bounds__(LIN_THREADS) void dts_lin_kernel(const LinArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int KS = p.K + 4;                         // padded row stride
+    float* Wl = lds;                                // [N][KS]
+    float* Xl = lds + (size_t)p.N * KS;             // [64][KS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int K4 = p.K >> 2;
+    for (int i = tid; i < p.N * K4; i += LIN_THREADS) {
+        const int n = i / K4, c = i - n * K4;
+        *reinterpret_cast<f32x4*>(Wl + n * KS + 4 * c) = *reinterpret_cast<const f32x4*>(p.W + (size_t)n * p.K + 4 * c);
+    }
+    const long long n_tiles = (p.rows + LIN_TM - 1) / LIN_TM;
+    const int srow = tid >> 2, spart = tid & 3;     // staging: 4 threads per token row
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();                            // previous pass done with Xl (and Wl staged)
+        // ---- stage 64 token rows with the prologue applied ----
+        {
+            const long long tok = tile * LIN_TM + srow;
+            const bool live = tok < p.rows;
+            const float* xr = p.X + (live ? tok : 0) * (long long)p.ldx;
+            float* dst = Xl + srow * KS;
+            if (p.pro == PRO_LN || p.pro == PRO_ADALN) {
+                float s = 0.0f;
+                for (int c = spart; c < K4; c += 4) {
+                    const f32x4 v = live ? *reinterpret_cast<const f32x4*>(xr + 4 * c) : f32x4{0, 0, 0, 0};
+                    *reinterpret_cast<f32x4*>(dst + 4 * c) = v;
+                    s += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                const float mean = s / (float)p.K;
+                float q = 0.0f;
+                for (int c = spart; c < K4; c += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(dst + 4 * c);
+                    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                    q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+                q += __shfl_xor(q, 1);
+                q += __shfl_xor(q, 2);
+                const float rstd = 1.0f / sqrtf(q / (float)p.K + 1e-5f);
+                for (int c = spart; c < K4; c += 4) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(dst + 4 * c);
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(p.P1 + 4 * c), b = *reinterpret_cast<const f32x4*>(p.P2 + 4 * c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (v[e] - mean) * rstd;
+                        v[e] = (p.pro == PRO_ADALN) ? xh * (1.0f + a[e]) + b[e] : xh * a[e] + b[e];
+                    }
+                    *reinterpret_cast<f32x4*>(dst + 4 * c) = v;
+                }
+            } else {
+                const float* ur = p.P1 ? p.P1 + (live ? tok : 0) * (long long)p.ldp : nullptr;
+                for (int c = spart; c < K4; c += 4) {
+                    f32x4 v = live ? *reinterpret_cast<const f32x4*>(xr + 4 * c) : f32x4{0, 0, 0, 0};
+                    if (p.pro == PRO_GELUGRAD) {
+                        const f32x4 u = live ? *reinterpret_cast<const f32x4*>(ur + 4 * c) : f32x4{0, 0, 0, 0};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(u[e]);
+                    } else if (p.pro == PRO_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+                    }
+                    *reinterpret_cast<f32x4*>(dst + 4 * c) = v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- wave `wave` multiplies its 16 tokens with every 16-row block of W ----
+        const long long tok = tile * LIN_TM + 16 * wave + r16;
+        const float* xb = Xl + (16 * wave + r16) * KS + 4 * g;
+        for (int nt = 0; nt < (p.N >> 4); ++nt) {
+            f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            const float* wa = Wl + (16 * nt + r16) * KS + 4 * g;
+            int s = 0;
+            for (; s + 2 <= (p.K >> 4); s += 2) {                 // two independent accumulator chains
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(wa + 16 * s), b0 = *reinterpret_cast<const f32x4*>(xb + 16 * s);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(wa + 16 * s + 16), b1 = *reinterpret_cast<const f32x4*>(xb + 16 * s + 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    DTS_MMA(acc0, a0[e], b0[e]);
+                    DTS_MMA(acc1, a1[e], b1[e]);
+                }
+            }
+            for (; s < (p.K >> 4); ++s) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(wa + 16 * s), b0 = *reinterpret_cast<const f32x4*>(xb + 16 * s);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) DTS_MMA(acc0, a0[e], b0[e]);
+            }
+            if (tok < p.rows) {
+                const int n0 = 16 * nt + 4 * g;
+                f32x4 v = acc0 + acc1;
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n0);
+                if (p.R) v += *reinterpret_cast<const f32x4*>(p.R + tok * (long long)p.ldr + n0);
+                float* y = p.Y + tok * (long long)p.ldy + n0;
+                if (p.accumulate) v += *reinterpret_cast<const f32x4*>(y);
+                *reinterpret_cast<f32x4*>(y) = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm / AdaLayerNorm backward w.r.t. the input:  dx (+)= rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))
+// 16 lanes per token, NPL = D/16 channels per lane
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NPL>
+__global__ __launch_bounds__(256) void dts_ln_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ gam,
+                                                         int ada, float* dx, int accumulate, long long rows) {
+    constexpr int D = 16 * NPL;
+    const long long tok = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int li = threadIdx.x & 15;
+    const bool live = tok < rows;
+    float xv[NPL], gv[NPL];
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < NPL; ++e) {
+        xv[e] = live ? x[tok * D + NPL * li + e] : 0.0f;
+        s += xv[e];
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m);
+    const float mean = s / (float)D;
+    float q = 0.0f;
+#pragma unroll
+    for (int e = 0; e < NPL; ++e) {
+        xv[e] -= mean;
+        q += xv[e] * xv[e];
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) q += __shfl_xor(q, m);
+    const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
+    float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+    for (int e = 0; e < NPL; ++e) {
+        const float gm = ada ? 1.0f + gam[NPL * li + e] : gam[NPL * li + e];
+        xv[e] *= rstd;                                             // xhat
+        gv[e] = live ? g[tok * D + NPL * li + e] * gm : 0.0f;
+        m1 += gv[e];
+        m2 += gv[e] * xv[e];
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+        m1 += __shfl_xor(m1, m);
+        m2 += __shfl_xor(m2, m);
+    }
+    m1 /= (float)D;
+    m2 /= (float)D;
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < NPL; ++e) {
+            const float v = rstd * (gv[e] - m1 - xv[e] * m2);
+            float* o = dx + tok * D + NPL * li + e;
+            *o = accumulate ? *o + v : v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// per-sequence mixing along the token axis:  Y[b][m][d] (+)= bias[m] + sum_k W[m][k] X[b][k][d]
+// W is stored padded [Mp][Kp] (multiples of 16, zero filled); one workgroup per sequence, X_b staged in LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SeqmixArgs {
+    const float* W; int Mp, Kp;
+    const float* bias;              // [M] | null
+    const float* X; long long xs; int ldx; int K;     // X_b = X + b*xs, rows k < K, row stride ldx
+    float* Y; long long ys; int ldy; int M;           // Y_b = Y + b*ys, rows m < M
+    int accumulate;
+};
+
+template <int DT>                   // D = 16*DT
+__global__ __launch_bounds__(256) void dts_seqmix_kernel(const SeqmixArgs p) {
+    constexpr int D = 16 * DT, DS = D + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [Kp][DS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    const float* xb = p.X + (long long)blockIdx.x * p.xs;
+    for (int i = tid; i < p.Kp * (D / 4); i += 256) {
+        const int k = i / (D / 4), c = i - k * (D / 4);
+        const f32x4 v = k < p.K ? *reinterpret_cast<const f32x4*>(xb + (long long)k * p.ldx + 4 * c) : f32x4{0, 0, 0, 0};
+        *reinterpret_cast<f32x4*>(lds + k * DS + 4 * c) = v;
+    }
+    __syncthreads();
+    float* yb = p.Y + (long long)blockIdx.x * p.ys;
+    for (int mt = wave; mt < (p.Mp >> 4); mt += 4) {
+        f32x4 acc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0, 0, 0, 0};
+        const float* wa = p.W + (long long)(16 * mt + r16) * p.Kp + 4 * g;
+        for (int s = 0; s < (p.Kp >> 4); ++s) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(wa + 16 * s);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float* xr = lds + (16 * s + 4 * g + e) * DS + r16;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) DTS_MMA(acc[dt], a[e], xr[16 * dt]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 16 * mt + 4 * g + r;
+            if (m < p.M) {
+                const float bm = p.bias ? p.bias[m] : 0.0f;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    float* o = yb + (long long)m * p.ldy + 16 * dt + r16;
+                    const float v = acc[dt][r] + bm;
+                    *o = p.accumulate ? *o + v : v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attention, one workgroup per (sequence, head); E = head_dim / 4
+// ---------------------------------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const float *Q, *K, *V; int ldq, ldk, ldv;      // token rows; column 0 of head 0
+    const float *dO, *O; int ldo;
+    float* out; int ldout;                          // fwd: O ; dq: dQ ; dkv: dK
+    float* out2; int ldout2;                        // dkv: dV
+    float* lse;                                     // [B][H][Lq], base-2 log-sum-exp of the scaled scores
+    const float* delta;                             // [B][H][Lq]
+    int H, Lq, Lk, hd;
+    float scale;
+};
+
+template <int E>
+__device__ __forceinline__ void load_frag(const float* p, float (&f)[E]) {
+    if constexpr (E == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) f[e] = p[e];
+    }
+}
+
+// rows [n][hd] of one head (token stride ld) -> LDS row-major [np][hd+4] (rows >= n zero) and/or transposed [16][np+4]
+template <int E>
+__device__ __forceinline__ void stage_head(const float* src, int ld, int n, int np, float* row_major, float* transposed) {
+    constexpr int HD = 4 * E;
+    for (int i = threadIdx.x; i < np * HD; i += 256) {
+        const int r = i / HD, d = i - r * HD;
+        const float v = r < n ? src[(long long)r * ld + d] : 0.0f;
+        if (row_major) row_major[r * (HD + 4) + d] = v;
+        if (transposed) transposed[d * (np + 4) + r] = v;
+    }
+    if (transposed && HD < 16)
+        for (int i = threadIdx.x; i < (16 - HD) * (np + 4); i += 256) transposed[HD * (np + 4) + i] = 0.0f;
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void dts_attn_fwd_kernel(const AttnArgs p) {
+    constexpr int HD = 4 * E, RS = HD + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+    const int Lkp = (p.Lk + 15) & ~15, TS = Lkp + 4;
+    float* Kl = lds;                       // [Lkp][RS]
+    float* VT = Kl + Lkp * RS;             // [16][TS]
+    stage_head<E>(p.K + (long long)b * p.Lk * p.ldk + h * HD, p.ldk, p.Lk, Lkp, Kl, nullptr);
+    stage_head<E>(p.V + (long long)b * p.Lk * p.ldv + h * HD, p.ldv, p.Lk, Lkp, nullptr, VT);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    const float c = p.scale * LOG2E;
+    for (int jt = wave; jt < ((p.Lq + 15) >> 4); jt += 4) {
+        const int j = 16 * jt + r16;
+        const bool jl = j < p.Lq;
+        float qf[E];
+        load_frag<E>(p.Q + ((long long)b * p.Lq + (jl ? j : 0)) * p.ldq + h * HD + E * g, qf);
+        float m = -INFINITY, l = 0.0f;
+        f32x4 o = {0, 0, 0, 0};
+        for (int it = 0; it < (Lkp >> 4); ++it) {
+            float kf[E];
+            load_frag<E>(Kl + (16 * it + r16) * RS + E * g, kf);
+            f32x4 s = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < E; ++e) DTS_MMA(s, kf[e], qf[e]);
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[r] = (16 * it + 4 * g + r < p.Lk) ? s[r] * c : -INFINITY;
+                tmax = fmaxf(tmax, s[r]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float mn = fmaxf(m, tmax);                       // finite from the first tile on (Lk >= 1)
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            float ps = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[r] = __builtin_amdgcn_exp2f(s[r] - mn);
+                ps += s[r];
+            }
+            l = l * alpha + ps;
+            o *= alpha;
+            m = mn;
+            const f32x4 vt = *reinterpret_cast<const f32x4*>(VT + r16 * TS + 16 * it + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) DTS_MMA(o, vt[r], s[r]);
+        }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        if (jl) {
+            if (4 * g < HD) {
+                const float inv = 1.0f / l;
+                float* dst = p.out + ((long long)b * p.Lq + j) * p.ldout + h * HD + 4 * g;
+                *reinterpret_cast<f32x4*>(dst) = o * inv;
+            }
+            if (g == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Lq + j] = m + __builtin_amdgcn_logf(l);
+        }
+    }
+}
+
+// delta[b][h][q] = sum_d dO[q][d] O[q][d]
+__global__ void dts_attn_delta_kernel(const float* dO, const float* O, int ld, int H, int L, int hd, long long n, float* delta) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // (b*H + h)*L + q
+    if (i >= n) return;
+    const int q = (int)(i % L);
+    const long long bh = i / L;
+    const int h = (int)(bh % H);
+    const long long b = bh / H;
+    const float* a = dO + (b * L + q) * ld + h * hd;
+    const float* o = O + (b * L + q) * ld + h * hd;
+    float s = 0.0f;
+    for (int d = 0; d < hd; ++d) s += a[d] * o[d];
+    delta[i] = s;
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void dts_attn_dq_kernel(const AttnArgs p) {
+    constexpr int HD = 4 * E, RS = HD + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+    const int Lkp = (p.Lk + 15) & ~15, TS = Lkp + 4;
+    float* Kl = lds;                       // [Lkp][RS]
+    float* Vl = Kl + Lkp * RS;             // [Lkp][RS]
+    float* KT = Vl + Lkp * RS;             // [16][TS]
+    stage_head<E>(p.K + (long long)b * p.Lk * p.ldk + h * HD, p.ldk, p.Lk, Lkp, Kl, KT);
+    stage_head<E>(p.V + (long long)b * p.Lk * p.ldv + h * HD, p.ldv, p.Lk, Lkp, Vl, nullptr);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    const float c = p.scale * LOG2E;
+    for (int jt = wave; jt < ((p.Lq + 15) >> 4); jt += 4) {
+        const int j = 16 * jt + r16;
+        const bool jl = j < p.Lq;
+        const long long tok = (long long)b * p.Lq + (jl ? j : 0);
+        float qf[E], df[E];
+        load_frag<E>(p.Q + tok * p.ldq + h * HD + E * g, qf);
+        load_frag<E>(p.dO + tok * p.ldo + h * HD + E * g, df);
+        const float lse = p.lse[((long long)b * p.H + h) * p.Lq + (jl ? j : 0)];
+        const float del = p.delta[((long long)b * p.H + h) * p.Lq + (jl ? j : 0)];
+        f32x4 dq = {0, 0, 0, 0};
+        for (int it = 0; it < (Lkp >> 4); ++it) {
+            float kf[E], vf[E];
+            load_frag<E>(Kl + (16 * it + r16) * RS + E * g, kf);
+            load_frag<E>(Vl + (16 * it + r16) * RS + E * g, vf);
+            f32x4 s = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                DTS_MMA(s, kf[e], qf[e]);
+                DTS_MMA(t2, vf[e], df[e]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = (16 * it + 4 * g + r < p.Lk) ? __builtin_amdgcn_exp2f(s[r] * c - lse) : 0.0f;
+                s[r] = pr * (t2[r] - del) * p.scale;
+            }
+            const f32x4 kt = *reinterpret_cast<const f32x4*>(KT + r16 * TS + 16 * it + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) DTS_MMA(dq, kt[r], s[r]);
+        }
+        if (jl && 4 * g < HD)
+            *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lq + j) * p.ldout + h * HD + 4 * g) = dq;
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void dts_attn_dkv_kernel(const AttnArgs p) {
+    constexpr int HD = 4 * E, RS = HD + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+    const int Lqp = (p.Lq + 15) & ~15, TS = Lqp + 4;
+    float* Ql = lds;                       // [Lqp][RS]
+    float* Dl = Ql + Lqp * RS;             // [Lqp][RS]   dO
+    float* QT = Dl + Lqp * RS;             // [16][TS]
+    float* DT_ = QT + 16 * TS;             // [16][TS]    dO^T
+    float* lsel = DT_ + 16 * TS;           // [Lqp]
+    float* dell = lsel + Lqp;              // [Lqp]
+    stage_head<E>(p.Q + (long long)b * p.Lq * p.ldq + h * HD, p.ldq, p.Lq, Lqp, Ql, QT);
+    stage_head<E>(p.dO + (long long)b * p.Lq * p.ldo + h * HD, p.ldo, p.Lq, Lqp, Dl, DT_);
+    for (int i = threadIdx.x; i < Lqp; i += 256) {
+        lsel[i] = i < p.Lq ? p.lse[((long long)b * p.H + h) * p.Lq + i] : INFINITY;     // padded queries: P = 0
+        dell[i] = i < p.Lq ? p.delta[((long long)b * p.H + h) * p.Lq + i] : 0.0f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    const float c = p.scale * LOG2E;
+    for (int jt = wave; jt < ((p.Lk + 15) >> 4); jt += 4) {
+        const int j = 16 * jt + r16;                                  // key
+        const bool jl = j < p.Lk;
+        const long long tok = (long long)b * p.Lk + (jl ? j : 0);
+        float kf[E], vf[E];
+        load_frag<E>(p.K + tok * p.ldk + h * HD + E * g, kf);
+        load_frag<E>(p.V + tok * p.ldv + h * HD + E * g, vf);
+        f32x4 dk = {0, 0, 0, 0}, dv = {0, 0, 0, 0};
+        for (int it = 0; it < (Lqp >> 4); ++it) {
+            float qa[E], da[E];
+            load_frag<E>(Ql + (16 * it + r16) * RS + E * g, qa);
+            load_frag<E>(Dl + (16 * it + r16) * RS + E * g, da);
+            f32x4 s = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                DTS_MMA(s, qa[e], kf[e]);
+                DTS_MMA(t2, da[e], vf[e]);
+            }
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsel + 16 * it + 4 * g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dell + 16 * it + 4 * g);
+            f32x4 pr, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pr[r] = __builtin_amdgcn_exp2f(s[r] * c - l4[r]);
+                ds[r] = pr[r] * (t2[r] - d4[r]) * p.scale;
+            }
+            const f32x4 dt = *reinterpret_cast<const f32x4*>(DT_ + r16 * TS + 16 * it + 4 * g);
+            const f32x4 qt = *reinterpret_cast<const f32x4*>(QT + r16 * TS + 16 * it + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                DTS_MMA(dv, dt[r], pr[r]);
+                DTS_MMA(dk, qt[r], ds[r]);
+            }
+        }
+        if (jl && 4 * g < HD) {
+            *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lk + j) * p.ldout + h * HD + 4 * g) = dk;
+            *reinterpret_cast<f32x4*>(p.out2 + ((long long)b * p.Lk + j) * p.ldout2 + h * HD + 4 * g) = dv;
+        }
+    }
+}
+
+}  // namespace dts
