@@ -194,6 +194,75 @@ int mpv_tmdm_load(mpv_ctx* ctx, const mpv_nsdiff_desc* desc, const mpv_nsdiff_we
 int mpv_tmdm_sample(mpv_ctx* ctx, const mpv_sample_shape* shape, const float* y0hat, const float* noise, const mpv_sample_out* out);
 
 /* ------------------------------------------------------------------------------------
+ * DiffusionTS: transformer x0-predictor + DDIM / Langevin-infill sampler
+ * replaces: Transformer.forward and its blocks (DiffusionTS/diffusionts_transformer.py:12-438, AdaLayerNorm / Conv_MLP of
+ *           diffusionts_model_utils.py:158-202), Diffusion_TS.output / model_predictions (DiffusionTS/DiffusionTS.py:147-160),
+ *           the input gradient that langevin_fn takes through the transformer by autograd (:359-407), fast_sample_infill
+ *           (:277-310), q_sample (:232-237) and the tile / un-tile of DiffusionTS_model.evaluation_step
+ *           (DiffusionTS/DiffusionTS_model.py:72-109, including its sample-major tiling but node-major un-tiling).
+ * Every dense contraction (QKV / proj / MLP Linear layers, softmax attention forward and backward, the Conv1d(L -> 2L, k=1)
+ * over the token axis, the real DFT of the Fourier season layer) runs on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t seq_len;       /* L = windows + pred_len = n_channel = max_len                         */
+    int32_t nf;            /* F = feature_size (1..8)                                              */
+    int32_t d_model;       /* n_embd: 16, 32 or 64                                                 */
+    int32_t n_heads;       /* d_model / n_heads in {4, 8, 16}                                      */
+    int32_t n_enc, n_dec;  /* n_layer_enc, n_layer_dec                                             */
+    int32_t mlp_times;     /* mlp_hidden_times                                                     */
+    int32_t timesteps;     /* rows of the AdaLayerNorm table                                       */
+    int32_t combine_taps;  /* kernel size of combine_s (1 or 5; circular 'same' convolution)       */
+} mpv_dts_desc;
+
+/* tensors: host pointers, PyTorch layouts, state_dict()["model.model.*"] in this order
+ *   0 emb.sequential.1.weight [D][F][3]   1 emb...bias [D]   2 inverse.sequential.1.weight [F][D][3]   3 inverse...bias [F]
+ *   4 combine_s.weight [F][D][taps]       5 combine_m.weight [n_dec]   6 pos_enc.pe [L][D]   7 pos_dec.pe [L][D]
+ *   then per encoder block (14): ln2.{weight,bias}, attn.{key,query,value,proj}.{weight,bias}, mlp.0.{weight,bias}, mlp.2.{weight,bias}
+ *   then per decoder block (30): ln2.{weight,bias}, attn1.{key,query,value,proj}.{weight,bias}, attn2.{key,query,value,proj}.{weight,bias},
+ *        trend.trend.0.{weight [3][L][3],bias}, trend.trend.3.{weight [F][D][3],bias}, mlp.0.{weight,bias}, mlp.2.{weight,bias},
+ *        proj.{weight [2L][L],bias}, linear.{weight [F][D],bias}
+ * ada_tables: host [timesteps][n_enc + 2 n_dec][2 D]: cat(scale, shift) = Linear(SiLU(SinusoidalPosEmb(t))) of every AdaLayerNorm
+ *   (order: encoder block i ln1; decoder block i ln1, ln1_1), evaluated by the host with the reference's fp32 ops
+ *   (diffusionts_model_utils.py:49-61, 187-202).
+ * rfftfreq: host [L/2 + 1] = torch.fft.rfftfreq(L).   poly: host [3][L] = TrendBlock.poly_space (transformer.py:26-27). */
+int mpv_dts_load(mpv_ctx* ctx, const mpv_dts_desc* desc, const float* const* tensors, int32_t n_tensors, const float* ada_tables,
+                 const float* rfftfreq, const float* poly);
+
+/* (trend, season_error) = Transformer.forward(x [B][L][F], t) for one timestep t shared by the batch; all dev, [B][L][F]. */
+int mpv_dts_forward(mpv_ctx* ctx, const float* x, int32_t B, int32_t t, float* trend, float* season_error);
+
+/* Vector-Jacobian product of model_output = trend + season_error w.r.t. x: g_x = (d model_output / d x)^T g_out, all dev [B][L][F]
+ * (what autograd gives langevin_fn).  The top-k bin SELECTION of the Fourier layer is piecewise constant, as under autograd. */
+int mpv_dts_vjp(mpv_ctx* ctx, const float* x, int32_t B, int32_t t, const float* g_out, float* g_x);
+
+/* Validation aid: copy an internal tensor of the last forward / vjp ("enc_x", "dec_x" with a block index; "trend_sum",
+ * "season_sum", "means", "g_dec", "g_enc") into out (dev). */
+int mpv_dts_debug_tensor(mpv_ctx* ctx, const char* name, int32_t index, float* out, int64_t n_floats);
+
+#define MPV_DTS_PLAN_COLS 10
+typedef struct {
+    int32_t n_windows;     /* W evaluation_step calls batched in this call                                   */
+    int32_t nodes;         /* V = batch rows of one evaluation_step                                           */
+    int32_t windows;       /* observed length; pred_len = seq_len - windows                                   */
+    int32_t n_samples;     /* S = n_z_samples                                                                 */
+    int32_t chunk;         /* par = min(parallel_sample, n_z_samples); S % par == 0                           */
+    int32_t n_pairs;       /* rows of `plan` = sampling_timesteps                                             */
+    float infill_coef;     /* model_kwargs["coef"] (:87)                                                      */
+    uint64_t seed;         /* Philox key when noise == NULL                                                   */
+} mpv_dts_sample_shape;
+
+/* history: dev [W][V][windows][F] scaled windows.  plan: HOST [n_pairs][MPV_DTS_PLAN_COLS], one row per DDIM pair
+ * (time, time_next) of fast_sample_infill, built by the host with the reference's fp32 ops: 0 time, 1 time_next,
+ * 2 sqrt_recip_alphas_cumprod[time], 3 sqrt_recipm1_alphas_cumprod[time], 4 sqrt(alpha_next), 5 sqrt(1 - alpha_next) (eta = 0),
+ * 6 K Langevin iterations, 7 their learning rate, 8 sqrt_alphas_cumprod[time], 9 sqrt_one_minus_alphas_cumprod[time].
+ * noise: dev or NULL.  When given: for chunk c < S/par, every normal draw of the reference in its order -- img,
+ * then per pair with time_next >= 0: the sigma = 0 `noise`, K Langevin epsilons (both drawn but unused), q_sample's noise --
+ * each draw a tensor [W][par*V][L][F] (the W windows' streams side by side).  NULL: Philox4x32-10 for the draws that are used.
+ * samples: dev [W][V][pred_len][F][S]; window w's slice is the reference's `outs`. */
+int mpv_dts_sample(mpv_ctx* ctx, const mpv_dts_sample_shape* shape, const float* history, const float* plan, const float* noise,
+                   float* samples);
+
+/* ------------------------------------------------------------------------------------
  * Synthetic input generation on device (the step before the path)
  * replaces: the harvested-biomass network simulator dataset/spdata_sde_biomass_dynamic_gene.py:53-68 (drift f, noise g;
  *           there integrated by torchsde) + normalize_time_series / sample_time_series of the harness

@@ -44,6 +44,37 @@ class Tap:
         return np.concatenate([d.reshape(-1).numpy() for d in self.draws])
 
 
+def record_blocks_and_grads(out, tag, m, x, t):
+    """Per-block forward outputs of Transformer.forward (forward hooks on the reference's own blocks) and the input gradient of
+    model_output for a seeded upstream gradient, with the gradients that reach the encoder output and the decoder input."""
+    tf = m.model.model
+    acts, hooks = {}, []
+    for i, blk in enumerate(tf.encoder.blocks):
+        hooks.append(blk.register_forward_hook(lambda mod, inp, o, i=i: acts.__setitem__("enc%d" % i, o[0])))
+    for i, blk in enumerate(tf.decoder.blocks):
+        hooks.append(blk.register_forward_hook(lambda mod, inp, o, i=i: acts.__setitem__("dec%d" % i, o)))
+    xin = x.clone().requires_grad_(True)
+    tt = torch.full((x.shape[0],), t, dtype=torch.long)
+    with torch.enable_grad():
+        y = m.model.output(xin, tt)
+        gen = torch.Generator().manual_seed(41)
+        g_out = torch.randn(y.shape, generator=gen)
+        enc_last = acts["enc%d" % (len(tf.encoder.blocks) - 1)]
+        enc_last.retain_grad()
+        (gx,) = torch.autograd.grad((y * g_out).sum(), xin, retain_graph=True)
+        (g_enc,) = torch.autograd.grad((y * g_out).sum(), enc_last)
+    for h in hooks:
+        h.remove()
+    out["blk_%s_t" % tag] = np.array(t, dtype=np.int64)
+    for i in range(len(tf.encoder.blocks)):
+        out["blk_%s_enc%d" % (tag, i)] = G.npy(acts["enc%d" % i])
+    for i in range(len(tf.decoder.blocks)):
+        xo, mean, trend, season = acts["dec%d" % i]
+        out["blk_%s_dec%d_x" % (tag, i)], out["blk_%s_dec%d_mean" % (tag, i)] = G.npy(xo), G.npy(mean)
+        out["blk_%s_dec%d_trend" % (tag, i)], out["blk_%s_dec%d_season" % (tag, i)] = G.npy(trend), G.npy(season)
+    out["vjp_%s_y" % tag], out["vjp_%s_gout" % tag], out["vjp_%s_gx" % tag], out["vjp_%s_genc" % tag] = G.npy(y), G.npy(g_out), G.npy(gx), G.npy(g_enc)
+
+
 def main():
     sys.meta_path.append(G._AbsentFinder())
     sys.path.insert(0, str(G.REF))
@@ -81,6 +112,32 @@ def main():
         assert by is None
         out["eval_%s_out" % tag], out["eval_%s_noise" % tag] = G.npy(outs), tap.flat()
         out["eval_%s_ndraws" % tag] = np.array([d.numel() for d in tap.draws], dtype=np.int64)
+        record_blocks_and_grads(out, tag, m, x, par["timesteps"] // 2)
+    # BASELINE configs[2] dimensions (d_model 64, 4 heads x 16, L = 200, 3 + 6 blocks): weights = seeded default init of the
+    # build's own parameter holders (same names and shapes; loaded strictly into the reference model), so no state dict is stored
+    sys.path.insert(0, str(HERE.parents[1]))
+    import mpv_amd  # noqa: F401
+    from mpv_amd.models.Diffusion_model.DiffusionTS.DiffusionTS_model import DiffusionTS_model as Mirror
+    par = dict(windows=100, pred_len=100, dataset_nf=1, d_model=64, n_layer_enc=3, n_layer_dec=6, n_heads=4, timesteps=100, diffusion_steps=5,
+               n_z_samples=2, parallel_sample=2)
+    torch.manual_seed(11)
+    mirror = Mirror(dict(par, device="cpu", scaler_type="StandardScaler"))
+    m = DiffusionTS_model(dict(par, device="cpu", scaler_type="StandardScaler")).eval()
+    m.load_state_dict(mirror.state_dict(), strict=True)
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(2, 200, 1, generator=g) * 0.7
+    out["x_c3"] = G.npy(x)
+    with torch.no_grad():
+        for t in (3, 50, 97):
+            trend, season = m.model.model(x, torch.full((2,), t, dtype=torch.long))
+            out["tf_c3_t%d_trend" % t], out["tf_c3_t%d_season" % t] = G.npy(trend), G.npy(season)
+    record_blocks_and_grads(out, "c3", m, x, 50)
+    batch = torch.randn(2, 100, 1, generator=g) * 0.5
+    out["batch_c3"] = G.npy(batch)
+    torch.manual_seed(78)
+    with Tap() as tap:
+        outs, _ = m.evaluation_step(batch.clone())
+    out["eval_c3_out"], out["eval_c3_noise"] = G.npy(outs), tap.flat()
     np.savez_compressed(HERE / "diffusionts_cases.npz", **out)
     f = HERE / "diffusionts_cases.npz"
     print("%-28s %8.1f KiB" % (f.name, f.stat().st_size / 1024))

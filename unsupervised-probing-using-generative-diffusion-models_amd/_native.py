@@ -25,7 +25,7 @@ EXPORTS = (
     "mpv_abi_version", "mpv_ctx_create", "mpv_ctx_destroy", "mpv_ctx_set_stream", "mpv_last_error",
     "mpv_nsdiff_load", "mpv_nsdiff_sample", "mpv_chain_stats", "mpv_nsdiff_philox_normals", "mpv_sigma_load", "mpv_sigma_head",
     "mpv_reduce", "mpv_chain_timing", "mpv_chain_timing_enable", "mpv_tmdm_load", "mpv_tmdm_sample",
-    "mpv_biomass_simulate",
+    "mpv_biomass_simulate", "mpv_dts_load", "mpv_dts_forward", "mpv_dts_vjp", "mpv_dts_debug_tensor", "mpv_dts_sample",
 )
 
 
@@ -52,6 +52,18 @@ class SampleShape(C.Structure):
 
 class SampleOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("samples", "mpv", "pred_mean", "mpv_feat", "std", "mean")]
+
+
+class DtsDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("seq_len", "nf", "d_model", "n_heads", "n_enc", "n_dec", "mlp_times", "timesteps", "combine_taps")]
+
+
+class DtsSampleShape(C.Structure):
+    _fields_ = [("n_windows", C.c_int32), ("nodes", C.c_int32), ("windows", C.c_int32), ("n_samples", C.c_int32), ("chunk", C.c_int32),
+                ("n_pairs", C.c_int32), ("infill_coef", C.c_float), ("seed", C.c_uint64)]
+
+
+DTS_PLAN_COLS = 10
 
 
 class SigmaDesc(C.Structure):
@@ -101,6 +113,11 @@ def load_library():
         "mpv_sigma_load": (C.c_int, [vp, C.POINTER(SigmaDesc), C.POINTER(SigmaWeights)]),
         "mpv_sigma_head": (C.c_int, [vp, vp, i32, i64, i32, i64, i64, vp, vp, f32, vp]),
         "mpv_reduce": (C.c_int, [vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
+        "mpv_dts_load": (C.c_int, [vp, C.POINTER(DtsDesc), C.POINTER(_F), i32, _F, _F, _F]),
+        "mpv_dts_forward": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+        "mpv_dts_vjp": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+        "mpv_dts_debug_tensor": (C.c_int, [vp, C.c_char_p, i32, vp, i64]),
+        "mpv_dts_sample": (C.c_int, [vp, C.POINTER(DtsSampleShape), vp, _F, vp, vp]),
         "mpv_chain_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i64)]),
         "mpv_chain_timing_enable": (C.c_int, [vp, C.c_int]),
     }
@@ -152,6 +169,7 @@ class Context:
         self.nsdiff = None     # (steps, nf)
         self.tmdm = None       # (steps, nf)
         self.sigma = None      # SigmaDesc fields
+        self.dts = None        # DtsDesc fields
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -307,6 +325,78 @@ class Context:
         self._check(self.lib.mpv_tmdm_sample(self._h, C.byref(shape), _dev_ptr(y0hat, self.device, "y0hat"),
                                              _dev_ptr(noise, self.device, "noise"), C.byref(out)), "mpv_tmdm_sample")
         return (samples, mpv, pm, feat) if summary else samples
+
+    # ---- DiffusionTS -------------------------------------------------------------------
+    def load_dts(self, seq_len: int, nf: int, d_model: int, n_heads: int, n_enc: int, n_dec: int, mlp_times: int, timesteps: int,
+                 combine_taps: int, tensors: Sequence[torch.Tensor], ada_tables: torch.Tensor, rfftfreq: torch.Tensor, poly: torch.Tensor):
+        keep = [_host_f32(t) for t in tensors]
+        ada, fr, po = _host_f32(ada_tables), _host_f32(rfftfreq), _host_f32(poly)
+        if tuple(ada.shape) != (timesteps, n_enc + 2 * n_dec, 2 * d_model):
+            raise MpvError("ada_tables has shape {}, expected {}".format(tuple(ada.shape), (timesteps, n_enc + 2 * n_dec, 2 * d_model)))
+        if fr.numel() != seq_len // 2 + 1 or tuple(po.shape) != (3, seq_len):
+            raise MpvError("rfftfreq / poly tables do not match seq_len {}".format(seq_len))
+        arr = (_F * len(keep))(*[_fptr(t) for t in keep])
+        desc = DtsDesc(seq_len, nf, d_model, n_heads, n_enc, n_dec, mlp_times, timesteps, combine_taps)
+        self._bind_stream()
+        self._check(self.lib.mpv_dts_load(self._h, C.byref(desc), arr, len(keep), _fptr(ada), _fptr(fr), _fptr(po)), "mpv_dts_load")
+        self.dts = (seq_len, nf, d_model, n_heads, n_enc, n_dec, timesteps)
+
+    def _dts_x(self, x):
+        if self.dts is None:
+            raise MpvError("DiffusionTS weights not loaded")
+        if x.dim() != 3 or x.shape[1] != self.dts[0] or x.shape[2] != self.dts[1]:
+            raise MpvError("x must be [B, {}, {}], got {}".format(self.dts[0], self.dts[1], tuple(x.shape)))
+
+    def dts_forward(self, x: torch.Tensor, t: int):
+        """(trend, season_error) = Transformer.forward(x [B, L, F] on device, t)."""
+        self._dts_x(x)
+        trend, season = torch.empty_like(x), torch.empty_like(x)
+        self._bind_stream()
+        self._check(self.lib.mpv_dts_forward(self._h, _dev_ptr(x, self.device, "x"), x.shape[0], int(t), _dev_ptr(trend, self.device, "trend"),
+                                             _dev_ptr(season, self.device, "season")), "mpv_dts_forward")
+        return trend, season
+
+    def dts_vjp(self, x: torch.Tensor, t: int, g_out: torch.Tensor) -> torch.Tensor:
+        """(d (trend + season_error) / d x)^T g_out, all [B, L, F] on device."""
+        self._dts_x(x)
+        if tuple(g_out.shape) != tuple(x.shape):
+            raise MpvError("g_out shape {} != x shape {}".format(tuple(g_out.shape), tuple(x.shape)))
+        gx = torch.empty_like(x)
+        self._bind_stream()
+        self._check(self.lib.mpv_dts_vjp(self._h, _dev_ptr(x, self.device, "x"), x.shape[0], int(t), _dev_ptr(g_out, self.device, "g_out"),
+                                         _dev_ptr(gx, self.device, "g_x")), "mpv_dts_vjp")
+        return gx
+
+    def dts_debug(self, name: str, index: int, shape) -> torch.Tensor:
+        out = torch.empty(shape, device=self.device, dtype=torch.float32)
+        self._bind_stream()
+        self._check(self.lib.mpv_dts_debug_tensor(self._h, name.encode(), int(index), _dev_ptr(out, self.device, "out"), out.numel()),
+                    "mpv_dts_debug_tensor")
+        return out
+
+    def dts_sample(self, history: torch.Tensor, plan: torch.Tensor, n_samples: int, chunk: int, infill_coef: float,
+                   noise: Optional[torch.Tensor] = None, seed: int = 0) -> torch.Tensor:
+        """history [W, V, windows, F] on device, plan [n_pairs, 10] (host) -> samples [W, V, pred_len, F, S] on device."""
+        if self.dts is None:
+            raise MpvError("DiffusionTS weights not loaded")
+        W, V, windows, F = history.shape
+        L = self.dts[0]
+        if F != self.dts[1] or not (0 < windows < L):
+            raise MpvError("history must be [W, V, windows < {}, {}], got {}".format(L, self.dts[1], tuple(history.shape)))
+        plan = _host_f32(plan)
+        if plan.dim() != 2 or plan.shape[1] != DTS_PLAN_COLS:
+            raise MpvError("plan must be [n_pairs, {}]".format(DTS_PLAN_COLS))
+        if noise is not None:
+            draws = 1 + sum(2 + int(r[6]) for r in plan.tolist() if r[1] >= 0)
+            need = (n_samples // chunk) * draws * W * chunk * V * L * F
+            if noise.numel() != need:
+                raise MpvError("noise has {} elements, the draw order needs {}".format(noise.numel(), need))
+        out = torch.empty((W, V, L - windows, F, n_samples), device=self.device, dtype=torch.float32)
+        shape = DtsSampleShape(W, V, windows, n_samples, chunk, plan.shape[0], float(infill_coef), seed & (2 ** 64 - 1))
+        self._bind_stream()
+        self._check(self.lib.mpv_dts_sample(self._h, C.byref(shape), _dev_ptr(history, self.device, "history"), _fptr(plan),
+                                            _dev_ptr(noise, self.device, "noise"), _dev_ptr(out, self.device, "samples")), "mpv_dts_sample")
+        return out
 
     # ---- synthetic input generation ---------------------------------------------------
     def biomass_simulate(self, row_ptr: torch.Tensor, col_idx: torch.Tensor, x0: torch.Tensor, ticks: int, burn_ticks: int,

@@ -1,0 +1,608 @@
+// DiffusionTS on gfx950: weights, workspace, the forward / input-gradient schedules of the 9-block transformer and the DDIM +
+// Langevin-infill sampler (reference DiffusionTS_model.py:72-109, DiffusionTS.py:152-160, 277-310, 359-407), behind the
+// mpv_dts_* entry points of include/mpv_hip.h.  The kernels are in dts_kernels.h (MFMA) and dts_small.h (VALU).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "dts_small.h"
+
+using namespace dts;
+
+namespace {
+
+struct EncW { const float *ln2w, *ln2b, *wqkv, *bqkv, *wp, *bp, *w0, *b0, *w2, *b2, *wqkv_t, *wp_t, *w0_t, *w2_t; };
+struct DecW {
+    const float *ln2w, *ln2b;
+    const float *wqkv1, *bqkv1, *wp1, *bp1, *wqkv1_t, *wp1_t;
+    const float *wq2, *bq2, *wkv2, *bkv2, *wp2, *bp2, *wq2_t, *wkv2_t, *wp2_t;
+    const float *tw0, *tb0, *tw3, *tb3;
+    const float *w0, *b0, *w2, *b2, *w0_t, *w2_t;
+    const float *wproj, *bproj, *wproj_t;          // padded [Mp][Kp]
+    const float *wlin, *blin;
+};
+
+}  // namespace
+
+struct DtsEngine {
+    mpv_dts_desc d{};
+    int L = 0, F = 0, D = 0, H = 0, hd = 0, NF = 0, NFp = 0, topk = 0, Lp = 0, L2p = 0, n_ada = 0, M = 0;
+    float* blob = nullptr;
+    std::vector<EncW> enc;
+    std::vector<DecW> dec;
+    const float *wemb = nullptr, *bemb = nullptr, *winv = nullptr, *binv = nullptr, *wcs = nullptr, *wcm = nullptr, *pe_enc = nullptr,
+                *pe_dec = nullptr, *ada = nullptr, *freq = nullptr, *poly = nullptr, *dft = nullptr, *cosT = nullptr, *sinT = nullptr;
+    // workspace (one allocation, grow-only)
+    float* ws = nullptr;
+    size_t ws_floats = 0;
+    int cap_B = 0;
+    // sub-buffers for batch cap_B (set by carve())
+    std::vector<float*> xe, xd;                      // block inputs: [n_enc+1], [n_dec+1]
+    struct EncS { float *qkv, *att, *lse, *x1, *u; };
+    struct DecS { float *qkv1, *att1, *lse1, *x1, *q2, *kv2, *att2, *lse2, *x2, *u, *t3; int* fidx; };
+    std::vector<EncS> es;
+    std::vector<DecS> dsv;
+    float *pr = nullptr, *spec = nullptr, *famp = nullptr, *fph = nullptr, *x3 = nullptr, *trend_sum = nullptr, *season_sum = nullptr,
+          *means = nullptr, *trend = nullptr, *season = nullptr;
+    float *gA = nullptr, *gB = nullptr, *gC = nullptr, *gwide = nullptr, *gqkv = nullptr, *gkv = nullptr, *genc = nullptr, *gpr = nullptr,
+          *delta = nullptr, *gseason = nullptr, *gmeans = nullptr, *gout = nullptr, *gx = nullptr;
+    // sampler state [B][L][F]
+    float *img = nullptr, *target = nullptr, *xstart = nullptr, *pmean = nullptr, *noise = nullptr;
+};
+
+namespace {
+
+// ---- launch helpers ------------------------------------------------------------------------------------------------
+template <class K>
+int set_lds(mpv_ctx* ctx, K kernel, size_t bytes) {
+    if (bytes > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "DiffusionTS: a kernel needs more LDS than the device has (sequence too long)");
+    MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return MPV_OK;
+}
+
+int lin(mpv_ctx* ctx, const float* X, int ldx, const float* W, const float* bias, int K, int N, long long rows, float* Y, int ldy, int pro = PRO_NONE,
+        const float* P1 = nullptr, const float* P2 = nullptr, int ldp = 0, const float* R = nullptr, int ldr = 0, int accumulate = 0) {
+    LinArgs a{X, ldx, W, bias, R, ldr, Y, ldy, P1, P2, ldp, rows, K, N, pro, accumulate};
+    const size_t lds = sizeof(float) * (size_t)(N + LIN_TM) * (K + 4);
+    if (int rc = set_lds(ctx, dts_lin_kernel, lds)) return rc;
+    const long long tiles = (rows + LIN_TM - 1) / LIN_TM;
+    const long long per_cu = std::max<long long>(1, std::min<long long>(4, (long long)ctx->max_lds / (long long)lds));
+    const int grid = (int)std::min<long long>(tiles, per_cu * ctx->cu_count);
+    hipLaunchKernelGGL(dts_lin_kernel, dim3(grid), dim3(LIN_THREADS), lds, ctx->stream, a);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+int seqmix(mpv_ctx* ctx, int D, const float* W, int Mp, int Kp, const float* bias, const float* X, long long xs, int ldx, int K, float* Y,
+           long long ys, int ldy, int M, int B, int accumulate = 0) {
+    SeqmixArgs a{W, Mp, Kp, bias, X, xs, ldx, K, Y, ys, ldy, M, accumulate};
+    const size_t lds = sizeof(float) * (size_t)Kp * (D + 4);
+    if (D == 64) {
+        if (int rc = set_lds(ctx, dts_seqmix_kernel<4>, lds)) return rc;
+        hipLaunchKernelGGL(dts_seqmix_kernel<4>, dim3(B), dim3(256), lds, ctx->stream, a);
+    } else if (D == 32) {
+        if (int rc = set_lds(ctx, dts_seqmix_kernel<2>, lds)) return rc;
+        hipLaunchKernelGGL(dts_seqmix_kernel<2>, dim3(B), dim3(256), lds, ctx->stream, a);
+    } else if (D == 16) {
+        if (int rc = set_lds(ctx, dts_seqmix_kernel<1>, lds)) return rc;
+        hipLaunchKernelGGL(dts_seqmix_kernel<1>, dim3(B), dim3(256), lds, ctx->stream, a);
+    } else {
+        return mpv_fail(ctx, MPV_EINVAL, "DiffusionTS: d_model must be 16, 32 or 64");
+    }
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+template <int E>
+int attn_launch(mpv_ctx* ctx, int mode, const AttnArgs& a, int B) {
+    const int Lkp = (a.Lk + 15) & ~15, Lqp = (a.Lq + 15) & ~15, RS = 4 * E + 4;
+    const dim3 grid(B * a.H), block(256);
+    if (mode == 0) {
+        const size_t lds = sizeof(float) * ((size_t)Lkp * RS + 16 * (Lkp + 4));
+        if (int rc = set_lds(ctx, dts_attn_fwd_kernel<E>, lds)) return rc;
+        hipLaunchKernelGGL(dts_attn_fwd_kernel<E>, grid, block, lds, ctx->stream, a);
+    } else if (mode == 1) {
+        const size_t lds = sizeof(float) * (2 * (size_t)Lkp * RS + 16 * (Lkp + 4));
+        if (int rc = set_lds(ctx, dts_attn_dq_kernel<E>, lds)) return rc;
+        hipLaunchKernelGGL(dts_attn_dq_kernel<E>, grid, block, lds, ctx->stream, a);
+    } else {
+        const size_t lds = sizeof(float) * (2 * (size_t)Lqp * RS + 32 * (Lqp + 4) + 2 * Lqp);
+        if (int rc = set_lds(ctx, dts_attn_dkv_kernel<E>, lds)) return rc;
+        hipLaunchKernelGGL(dts_attn_dkv_kernel<E>, grid, block, lds, ctx->stream, a);
+    }
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+int attn(mpv_ctx* ctx, int mode, const AttnArgs& a, int B) {
+    switch (a.hd) {
+        case 4: return attn_launch<1>(ctx, mode, a, B);
+        case 8: return attn_launch<2>(ctx, mode, a, B);
+        case 16: return attn_launch<4>(ctx, mode, a, B);
+        default: return mpv_fail(ctx, MPV_EINVAL, "DiffusionTS: head dimension must be 4, 8 or 16");
+    }
+}
+
+int ln_bwd(mpv_ctx* ctx, int D, const float* g, const float* x, const float* gam, int ada, float* dx, int accumulate, long long rows) {
+    const dim3 grid((unsigned)((rows + 15) / 16)), block(256);
+    if (D == 64) hipLaunchKernelGGL(dts_ln_bwd_kernel<4>, grid, block, 0, ctx->stream, g, x, gam, ada, dx, accumulate, rows);
+    else if (D == 32) hipLaunchKernelGGL(dts_ln_bwd_kernel<2>, grid, block, 0, ctx->stream, g, x, gam, ada, dx, accumulate, rows);
+    else hipLaunchKernelGGL(dts_ln_bwd_kernel<1>, grid, block, 0, ctx->stream, g, x, gam, ada, dx, accumulate, rows);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+inline dim3 g1d(long long n, int threads = 256) { return dim3((unsigned)((n + threads - 1) / threads)); }
+
+#define DTS_TRY(expr)            \
+    do {                         \
+        if (int rc_ = (expr)) return rc_; \
+    } while (0)
+
+// ---- workspace -------------------------------------------------------------------------------------------------------
+int carve(mpv_ctx* ctx, DtsEngine& e, int B) {
+    if (B <= e.cap_B) return MPV_OK;
+    const size_t T = (size_t)B * e.L, D = e.D, F = e.F, H = e.H;
+    const size_t BH = (size_t)B * H * e.L;
+    size_t total = 0;
+    auto take = [&](size_t n) { const size_t at = total; total += (n + 3) & ~size_t(3); return at; };
+    std::vector<size_t> o_xe(e.d.n_enc + 1), o_xd(e.d.n_dec + 1);
+    for (auto& o : o_xe) o = take(T * D);
+    for (auto& o : o_xd) o = take(T * D);
+    struct EO { size_t qkv, att, lse, x1, u; };
+    struct DO_ { size_t qkv1, att1, lse1, x1, q2, kv2, att2, lse2, x2, u, t3, fidx; };
+    std::vector<EO> eo(e.d.n_enc);
+    std::vector<DO_> dofs(e.d.n_dec);
+    for (auto& o : eo) o = EO{take(T * 3 * D), take(T * D), take(BH), take(T * D), take(T * e.M)};
+    for (auto& o : dofs)
+        o = DO_{take(T * 3 * D), take(T * D), take(BH), take(T * D), take(T * D), take(T * 2 * D), take(T * D), take(BH), take(T * D),
+                take(T * e.M), take((size_t)B * 3 * D), take((size_t)B * e.topk * D)};
+    const size_t o_pr = take(2 * T * D), o_spec = take((size_t)B * 2 * e.NFp * D), o_famp = take((size_t)B * e.topk * D),
+                 o_fph = take((size_t)B * e.topk * D), o_x3 = take(T * D), o_ts = take(T * F), o_ss = take(T * D),
+                 o_means = take((size_t)B * e.d.n_dec * F), o_trend = take(T * F), o_season = take(T * F);
+    const size_t o_gA = take(T * D), o_gB = take(T * D), o_gC = take(T * D), o_gw = take(T * e.M), o_gqkv = take(T * 3 * D), o_gkv = take(T * 2 * D),
+                 o_genc = take(T * D), o_gpr = take(2 * T * D), o_delta = take(BH), o_gs = take(T * D), o_gm = take((size_t)B * e.d.n_dec * F),
+                 o_gout = take(T * F), o_gx = take(T * F);
+    const size_t o_img = take(T * F), o_tgt = take(T * F), o_xs = take(T * F), o_pm = take(T * F), o_nz = take(T * F);
+    if (e.ws) {
+        MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(e.ws);
+        e.ws = nullptr;
+        e.cap_B = 0;
+    }
+    if (hipMalloc(&e.ws, total * sizeof(float)) != hipSuccess) return mpv_fail(ctx, MPV_ENOMEM, "DiffusionTS workspace");
+    e.ws_floats = total;
+    e.cap_B = B;
+    float* w = e.ws;
+    e.xe.resize(o_xe.size());
+    e.xd.resize(o_xd.size());
+    for (size_t i = 0; i < o_xe.size(); ++i) e.xe[i] = w + o_xe[i];
+    for (size_t i = 0; i < o_xd.size(); ++i) e.xd[i] = w + o_xd[i];
+    e.es.resize(eo.size());
+    e.dsv.resize(dofs.size());
+    for (size_t i = 0; i < eo.size(); ++i) e.es[i] = DtsEngine::EncS{w + eo[i].qkv, w + eo[i].att, w + eo[i].lse, w + eo[i].x1, w + eo[i].u};
+    for (size_t i = 0; i < dofs.size(); ++i) {
+        const DO_& o = dofs[i];
+        e.dsv[i] = DtsEngine::DecS{w + o.qkv1, w + o.att1, w + o.lse1, w + o.x1, w + o.q2, w + o.kv2, w + o.att2, w + o.lse2, w + o.x2, w + o.u, w + o.t3,
+                                   reinterpret_cast<int*>(w + o.fidx)};
+    }
+    e.pr = w + o_pr; e.spec = w + o_spec; e.famp = w + o_famp; e.fph = w + o_fph; e.x3 = w + o_x3; e.trend_sum = w + o_ts; e.season_sum = w + o_ss;
+    e.means = w + o_means; e.trend = w + o_trend; e.season = w + o_season;
+    e.gA = w + o_gA; e.gB = w + o_gB; e.gC = w + o_gC; e.gwide = w + o_gw; e.gqkv = w + o_gqkv; e.gkv = w + o_gkv; e.genc = w + o_genc; e.gpr = w + o_gpr;
+    e.delta = w + o_delta; e.gseason = w + o_gs; e.gmeans = w + o_gm; e.gout = w + o_gout; e.gx = w + o_gx;
+    e.img = w + o_img; e.target = w + o_tgt; e.xstart = w + o_xs; e.pmean = w + o_pm; e.noise = w + o_nz;
+    return MPV_OK;
+}
+
+// ---- forward: Transformer.forward (transformer.py:422-438) ----------------------------------------------------------
+int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t) {
+    const int L = e.L, F = e.F, D = e.D, H = e.H, M = e.M;
+    const long long T = (long long)B * L;
+    const float scale = 1.0f / std::sqrt((float)e.hd);
+    const float* ada_t = e.ada + (size_t)t * e.n_ada * 2 * D;
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(dts_embed_fwd_kernel, g1d(T * D), dim3(256), 0, st, x, e.wemb, e.bemb, e.pe_enc, e.pe_dec, L, F, D, T * D, e.xe[0], e.xd[0]);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    int ada_i = 0;
+    for (int i = 0; i < e.d.n_enc; ++i, ++ada_i) {                       // EncoderBlock.forward :235-239
+        const EncW& w = e.enc[i];
+        const DtsEngine::EncS& s = e.es[i];
+        const float* sc = ada_t + (size_t)ada_i * 2 * D;
+        DTS_TRY(lin(ctx, e.xe[i], D, w.wqkv, w.bqkv, D, 3 * D, T, s.qkv, 3 * D, PRO_ADALN, sc, sc + D));
+        AttnArgs a{s.qkv, s.qkv + D, s.qkv + 2 * D, 3 * D, 3 * D, 3 * D, nullptr, nullptr, D, s.att, D, nullptr, 0, s.lse, nullptr, H, L, L, e.hd, scale};
+        DTS_TRY(attn(ctx, 0, a, B));
+        DTS_TRY(lin(ctx, s.att, D, w.wp, w.bp, D, D, T, s.x1, D, PRO_NONE, nullptr, nullptr, 0, e.xe[i], D));
+        DTS_TRY(lin(ctx, s.x1, D, w.w0, w.b0, D, M, T, s.u, M, PRO_LN, w.ln2w, w.ln2b));
+        DTS_TRY(lin(ctx, s.u, M, w.w2, w.b2, M, D, T, e.xe[i + 1], D, PRO_GELU, nullptr, nullptr, 0, s.x1, D));
+    }
+    const float* encout = e.xe[e.d.n_enc];
+    MPV_HIP_TRY(ctx, hipMemsetAsync(e.trend_sum, 0, sizeof(float) * T * F, st));
+    MPV_HIP_TRY(ctx, hipMemsetAsync(e.season_sum, 0, sizeof(float) * T * D, st));
+    for (int i = 0; i < e.d.n_dec; ++i, ada_i += 2) {                    // DecoderBlock.forward :323-332
+        const DecW& w = e.dec[i];
+        const DtsEngine::DecS& s = e.dsv[i];
+        const float* sc1 = ada_t + (size_t)ada_i * 2 * D;
+        const float* sc2 = sc1 + 2 * D;
+        DTS_TRY(lin(ctx, e.xd[i], D, w.wqkv1, w.bqkv1, D, 3 * D, T, s.qkv1, 3 * D, PRO_ADALN, sc1, sc1 + D));
+        AttnArgs a1{s.qkv1, s.qkv1 + D, s.qkv1 + 2 * D, 3 * D, 3 * D, 3 * D, nullptr, nullptr, D, s.att1, D, nullptr, 0, s.lse1, nullptr, H, L, L, e.hd, scale};
+        DTS_TRY(attn(ctx, 0, a1, B));
+        DTS_TRY(lin(ctx, s.att1, D, w.wp1, w.bp1, D, D, T, s.x1, D, PRO_NONE, nullptr, nullptr, 0, e.xd[i], D));
+        DTS_TRY(lin(ctx, s.x1, D, w.wq2, w.bq2, D, D, T, s.q2, D, PRO_ADALN, sc2, sc2 + D));
+        DTS_TRY(lin(ctx, encout, D, w.wkv2, w.bkv2, D, 2 * D, T, s.kv2, 2 * D));
+        AttnArgs a2{s.q2, s.kv2, s.kv2 + D, D, 2 * D, 2 * D, nullptr, nullptr, D, s.att2, D, nullptr, 0, s.lse2, nullptr, H, L, L, e.hd, scale};
+        DTS_TRY(attn(ctx, 0, a2, B));
+        DTS_TRY(lin(ctx, s.att2, D, w.wp2, w.bp2, D, D, T, s.x2, D, PRO_NONE, nullptr, nullptr, 0, s.x1, D));
+        // proj: Conv1d(L -> 2L, k=1) over the token axis, then trend (first L rows) and season (last L rows)
+        DTS_TRY(seqmix(ctx, D, w.wproj, e.L2p, e.Lp, w.bproj, s.x2, (long long)L * D, D, L, e.pr, 2LL * L * D, D, 2 * L, B));
+        hipLaunchKernelGGL(dts_trend_fwd_kernel, dim3(B), dim3(256), sizeof(float) * (3 * D + 3 * F), st, e.pr, 2LL * L * D, w.tw0, w.tb0, w.tw3, w.tb3,
+                           e.poly, L, F, D, s.t3, e.trend_sum);
+        MPV_HIP_TRY(ctx, hipGetLastError());
+        DTS_TRY(seqmix(ctx, D, e.dft, 2 * e.NFp, e.Lp, nullptr, e.pr + (long long)L * D, 2LL * L * D, D, L, e.spec, 2LL * e.NFp * D, D, 2 * e.NFp, B));
+        hipLaunchKernelGGL(dts_fourier_select_kernel, g1d((long long)B * D), dim3(256), 0, st, e.spec, e.NF, e.NFp, D, e.topk, (long long)B * D, s.fidx,
+                           e.famp, e.fph);
+        hipLaunchKernelGGL(dts_fourier_synth_kernel, g1d(T * D), dim3(256), 0, st, s.fidx, e.famp, e.fph, e.freq + 1, L, D, e.topk, T * D, e.season_sum);
+        MPV_HIP_TRY(ctx, hipGetLastError());
+        DTS_TRY(lin(ctx, s.x2, D, w.w0, w.b0, D, M, T, s.u, M, PRO_LN, w.ln2w, w.ln2b));
+        DTS_TRY(lin(ctx, s.u, M, w.w2, w.b2, M, D, T, e.x3, D, PRO_GELU, nullptr, nullptr, 0, s.x2, D));
+        hipLaunchKernelGGL(dts_meansub_fwd_kernel, dim3(B), dim3(256), sizeof(float) * D, st, e.x3, w.wlin, w.blin, L, F, D, e.xd[i + 1],
+                           e.means + (size_t)i * F, e.d.n_dec * F);
+        MPV_HIP_TRY(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(dts_tail_fwd_kernel, dim3(B), dim3(256), sizeof(float) * (2 * L * F + 2 * F), st, e.xd[e.d.n_dec], e.season_sum, e.trend_sum, e.means,
+                       e.winv, e.binv, e.wcs, e.wcm, L, F, D, e.d.combine_taps, e.d.n_dec, e.trend, e.season);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+// attention backward of one layer: dQ into dq (ldq), dK/dV into dk/dv (ldkv)
+int attn_bwd(mpv_ctx* ctx, DtsEngine& e, int B, const float* Q, int ldq, const float* K, const float* V, int ldkv, const float* O, const float* dO,
+             float* lse, float* dq, int lddq, float* dk, float* dv, int lddkv) {
+    const long long n = (long long)B * e.H * e.L;
+    const float scale = 1.0f / std::sqrt((float)e.hd);
+    hipLaunchKernelGGL(dts_attn_delta_kernel, g1d(n), dim3(256), 0, ctx->stream, dO, O, e.D, e.H, e.L, e.hd, n, e.delta);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    AttnArgs a{Q, K, V, ldq, ldkv, ldkv, dO, O, e.D, dq, lddq, nullptr, 0, lse, e.delta, e.H, e.L, e.L, e.hd, scale};
+    DTS_TRY(attn(ctx, 1, a, B));
+    a.out = dk; a.ldout = lddkv; a.out2 = dv; a.ldout2 = lddkv;
+    DTS_TRY(attn(ctx, 2, a, B));
+    return MPV_OK;
+}
+
+// ---- input gradient: gout = dLoss/d(trend + season_error) [B][L][F] -> gx = dLoss/dx [B][L][F]; uses the saved forward --------
+int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, int t) {
+    const int L = e.L, F = e.F, D = e.D, M = e.M;
+    const long long T = (long long)B * L;
+    const float* ada_t = e.ada + (size_t)t * e.n_ada * 2 * D;
+    hipStream_t st = ctx->stream;
+    // tail: d_h (decoder output) -> gA, d_season, d_means
+    hipLaunchKernelGGL(dts_tail_bwd_kernel, dim3(B), dim3(256), 0, st, gout, e.winv, e.wcs, e.wcm, L, F, D, e.d.combine_taps, e.d.n_dec, e.gA, e.gseason,
+                       e.gmeans);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    MPV_HIP_TRY(ctx, hipMemsetAsync(e.genc, 0, sizeof(float) * T * D, st));
+    float* gcur = e.gA;                                                  // gradient w.r.t. the current block OUTPUT
+    float* gnext = e.gB;
+    for (int i = e.d.n_dec - 1; i >= 0; --i) {
+        const DecW& w = e.dec[i];
+        const DtsEngine::DecS& s = e.dsv[i];
+        const int ada_i = e.d.n_enc + 2 * i;
+        const float* sc1 = ada_t + (size_t)ada_i * 2 * D;
+        const float* sc2 = sc1 + 2 * D;
+        // out = x3 - mean(x3), mean_i = Linear(mean): d_x3 -> gnext
+        hipLaunchKernelGGL(dts_meansub_bwd_kernel, dim3(B), dim3(256), sizeof(float) * D, st, gcur, w.wlin, e.gmeans + (size_t)i * F, e.d.n_dec * F, L, F, D, gnext);
+        MPV_HIP_TRY(ctx, hipGetLastError());
+        std::swap(gcur, gnext);                                          // gcur = d_x3
+        // x3 = x2 + mlp(ln2(x2))
+        DTS_TRY(lin(ctx, gcur, D, w.w2_t, nullptr, D, M, T, e.gwide, M));
+        DTS_TRY(lin(ctx, e.gwide, M, w.w0_t, nullptr, M, D, T, e.gC, D, PRO_GELUGRAD, s.u, nullptr, M));
+        DTS_TRY(ln_bwd(ctx, D, e.gC, s.x2, w.ln2w, 0, gcur, 1, T));     // gcur = d_x2 (so far)
+        // trend / season branches through proj
+        hipLaunchKernelGGL(dts_trend_bwd_kernel, dim3(B), dim3(256), sizeof(float) * (3 * F + 3 * D), st, gout, s.t3, w.tw0, w.tw3, e.poly, L, F, D, e.gpr,
+                           2LL * L * D);
+        hipLaunchKernelGGL(dts_fourier_bwd_kernel, dim3(B), dim3(256), sizeof(float) * 2 * e.topk * D, st, e.gseason, s.fidx, e.cosT, e.sinT, L, D, e.topk,
+                           e.gpr, 2LL * L * D);
+        MPV_HIP_TRY(ctx, hipGetLastError());
+        DTS_TRY(seqmix(ctx, D, w.wproj_t, e.Lp, e.L2p, nullptr, e.gpr, 2LL * L * D, D, 2 * L, gcur, (long long)L * D, D, L, B, 1));
+        // x2 = x1 + proj2(attn2(q2(ln1_1(x1)), kv2(enc)))
+        DTS_TRY(lin(ctx, gcur, D, w.wp2_t, nullptr, D, D, T, e.gC, D));                      // d_att2
+        DTS_TRY(attn_bwd(ctx, e, B, s.q2, D, s.kv2, s.kv2 + D, 2 * D, s.att2, e.gC, s.lse2, e.gqkv, D, e.gkv, e.gkv + D, 2 * D));
+        DTS_TRY(lin(ctx, e.gkv, 2 * D, w.wkv2_t, nullptr, 2 * D, D, T, e.genc, D, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 1));
+        DTS_TRY(lin(ctx, e.gqkv, D, w.wq2_t, nullptr, D, D, T, e.gC, D));
+        DTS_TRY(ln_bwd(ctx, D, e.gC, s.x1, sc2, 1, gcur, 1, T));       // gcur = d_x1
+        // x1 = x0 + proj1(attn1(qkv1(ln1(x0))))
+        DTS_TRY(lin(ctx, gcur, D, w.wp1_t, nullptr, D, D, T, e.gC, D));
+        DTS_TRY(attn_bwd(ctx, e, B, s.qkv1, 3 * D, s.qkv1 + D, s.qkv1 + 2 * D, 3 * D, s.att1, e.gC, s.lse1, e.gqkv, 3 * D, e.gqkv + D, e.gqkv + 2 * D, 3 * D));
+        DTS_TRY(lin(ctx, e.gqkv, 3 * D, w.wqkv1_t, nullptr, 3 * D, D, T, e.gC, D));
+        DTS_TRY(ln_bwd(ctx, D, e.gC, e.xd[i], sc1, 1, gcur, 1, T));    // gcur = d_x0 = gradient w.r.t. the previous block's output
+    }
+    float* gdec0 = gcur;                                                 // d(h_dec0)
+    float* genc = e.genc;                                                // d(encoder output), accumulated over the decoder blocks
+    float* tmp = (gcur == e.gA) ? e.gB : e.gA;
+    for (int i = e.d.n_enc - 1; i >= 0; --i) {
+        const EncW& w = e.enc[i];
+        const DtsEngine::EncS& s = e.es[i];
+        const float* sc = ada_t + (size_t)i * 2 * D;
+        DTS_TRY(lin(ctx, genc, D, w.w2_t, nullptr, D, M, T, e.gwide, M));
+        DTS_TRY(lin(ctx, e.gwide, M, w.w0_t, nullptr, M, D, T, e.gC, D, PRO_GELUGRAD, s.u, nullptr, M));
+        DTS_TRY(ln_bwd(ctx, D, e.gC, s.x1, w.ln2w, 0, genc, 1, T));    // genc = d_x1
+        DTS_TRY(lin(ctx, genc, D, w.wp_t, nullptr, D, D, T, e.gC, D));
+        DTS_TRY(attn_bwd(ctx, e, B, s.qkv, 3 * D, s.qkv + D, s.qkv + 2 * D, 3 * D, s.att, e.gC, s.lse, e.gqkv, 3 * D, e.gqkv + D, e.gqkv + 2 * D, 3 * D));
+        DTS_TRY(lin(ctx, e.gqkv, 3 * D, w.wqkv_t, nullptr, 3 * D, D, T, e.gC, D));
+        DTS_TRY(ln_bwd(ctx, D, e.gC, e.xe[i], sc, 1, genc, 1, T));     // genc = d_x0
+    }
+    (void)tmp;
+    hipLaunchKernelGGL(dts_embed_bwd_kernel, g1d(T * F), dim3(256), 0, st, genc, gdec0, e.wemb, L, F, D, T * F, gx);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+std::vector<float> transposed2(const float* w, int rows, int cols) {
+    std::vector<float> t((size_t)rows * cols);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = w[(size_t)r * cols + c];
+    return t;
+}
+std::vector<float> padded(const float* w, int rows, int cols, int rp, int cp) {
+    std::vector<float> t((size_t)rp * cp, 0.0f);
+    for (int r = 0; r < rows; ++r) std::memcpy(&t[(size_t)r * cp], w + (size_t)r * cols, sizeof(float) * cols);
+    return t;
+}
+
+}  // namespace
+
+void dts_engine_destroy(DtsEngine* e) {
+    if (!e) return;
+    if (e->blob) (void)hipFree(e->blob);
+    if (e->ws) (void)hipFree(e->ws);
+    delete e;
+}
+
+extern "C" {
+
+int mpv_dts_load(mpv_ctx* ctx, const mpv_dts_desc* d, const float* const* tensors, int32_t n_tensors, const float* ada_tables,
+                 const float* rfftfreq, const float* poly) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_dts_load: ctx is NULL");
+    if (!d || !tensors || !ada_tables || !rfftfreq || !poly) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_load: NULL argument");
+    const int L = d->seq_len, F = d->nf, D = d->d_model, H = d->n_heads;
+    if (L < 4 || F < 1 || F > 8 || (D != 16 && D != 32 && D != 64) || H < 1 || D % H != 0 || d->n_enc < 1 || d->n_dec < 1 || d->timesteps < 1 ||
+        d->mlp_times < 1 || (d->combine_taps & 1) == 0 || d->combine_taps > L)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_load: need seq_len >= 4, 1 <= nf <= 8, d_model in {16,32,64}, n_heads | d_model, odd combine_taps");
+    const int hd = D / H;
+    if (hd != 4 && hd != 8 && hd != 16) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_load: head dimension must be 4, 8 or 16");
+    const int want = 8 + 14 * d->n_enc + 30 * d->n_dec;
+    if (n_tensors != want) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_load: wrong number of weight tensors");
+    for (int i = 0; i < n_tensors; ++i)
+        if (!tensors[i]) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_load: NULL weight tensor");
+    DeviceGuard dg_(ctx->device);
+    MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    dts_engine_destroy(ctx->dts);
+    ctx->dts = nullptr;
+    DtsEngine* e = new (std::nothrow) DtsEngine();
+    if (!e) return mpv_fail(ctx, MPV_ENOMEM, "mpv_dts_load: out of host memory");
+    e->d = *d;
+    e->L = L; e->F = F; e->D = D; e->H = H; e->hd = hd; e->M = d->mlp_times * D;
+    e->NF = (L % 2 == 0) ? L / 2 - 1 : (L - 1) / 2;                      // rfft bins 1 .. (L/2 - 1 | (L-1)/2), transformer.py:66-73
+    e->NFp = (e->NF + 15) & ~15;
+    e->topk = (int)std::log((double)e->NF);                              // int(factor * log(length)), :93
+    if (e->topk < 1 || e->topk > DTS_MAX_TOPK) { delete e; return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_load: sequence length gives an unsupported top-k"); }
+    e->Lp = (L + 15) & ~15;
+    e->L2p = (2 * L + 15) & ~15;
+    e->n_ada = d->n_enc + 2 * d->n_dec;
+    // ---- host staging of everything, one upload --------------------------------------------------------------------
+    std::vector<float> host;
+    auto put = [&](const float* p, size_t n) { const size_t at = host.size(); host.insert(host.end(), p, p + n); host.resize((host.size() + 3) & ~size_t(3)); return at; };
+    auto putv = [&](const std::vector<float>& v) { return put(v.data(), v.size()); };
+    auto cat = [&](std::initializer_list<std::pair<const float*, size_t>> parts) { std::vector<float> v; for (auto& p : parts) v.insert(v.end(), p.first, p.first + p.second); return v; };
+    const float* const* T_ = tensors;
+    const size_t DD = (size_t)D * D, MD = (size_t)e->M * D;
+    std::vector<size_t> o;                                               // offsets in `host`, consumed in the same order below
+    o.push_back(put(T_[0], (size_t)D * F * 3)); o.push_back(put(T_[1], D)); o.push_back(put(T_[2], (size_t)F * D * 3)); o.push_back(put(T_[3], F));
+    o.push_back(put(T_[4], (size_t)F * D * d->combine_taps)); o.push_back(put(T_[5], d->n_dec)); o.push_back(put(T_[6], (size_t)L * D));
+    o.push_back(put(T_[7], (size_t)L * D));
+    int k = 8;
+    for (int i = 0; i < d->n_enc; ++i, k += 14) {
+        // order: ln2.w, ln2.b, key.w, key.b, query.w, query.b, value.w, value.b, proj.w, proj.b, mlp0.w, mlp0.b, mlp2.w, mlp2.b
+        const std::vector<float> wqkv = cat({{T_[k + 4], DD}, {T_[k + 2], DD}, {T_[k + 6], DD}});          // rows: query | key | value
+        const std::vector<float> bqkv = cat({{T_[k + 5], (size_t)D}, {T_[k + 3], (size_t)D}, {T_[k + 7], (size_t)D}});
+        o.push_back(put(T_[k], D)); o.push_back(put(T_[k + 1], D)); o.push_back(putv(wqkv)); o.push_back(putv(bqkv));
+        o.push_back(put(T_[k + 8], DD)); o.push_back(put(T_[k + 9], D)); o.push_back(put(T_[k + 10], MD)); o.push_back(put(T_[k + 11], e->M));
+        o.push_back(put(T_[k + 12], MD)); o.push_back(put(T_[k + 13], D));
+        o.push_back(putv(transposed2(wqkv.data(), 3 * D, D))); o.push_back(putv(transposed2(T_[k + 8], D, D)));
+        o.push_back(putv(transposed2(T_[k + 10], e->M, D))); o.push_back(putv(transposed2(T_[k + 12], D, e->M)));
+    }
+    for (int i = 0; i < d->n_dec; ++i, k += 30) {
+        // order: ln2.w, ln2.b, attn1.{key,query,value,proj}.{w,b} (8), attn2.{key,query,value,proj}.{w,b} (8),
+        //        trend.0.w, trend.0.b, trend.3.w, trend.3.b, mlp0.w, mlp0.b, mlp2.w, mlp2.b, proj.w, proj.b, linear.w, linear.b
+        const float* const* A1 = T_ + k + 2;
+        const float* const* A2 = T_ + k + 10;
+        const std::vector<float> wqkv1 = cat({{A1[2], DD}, {A1[0], DD}, {A1[4], DD}});
+        const std::vector<float> bqkv1 = cat({{A1[3], (size_t)D}, {A1[1], (size_t)D}, {A1[5], (size_t)D}});
+        const std::vector<float> wkv2 = cat({{A2[0], DD}, {A2[4], DD}});
+        const std::vector<float> bkv2 = cat({{A2[1], (size_t)D}, {A2[5], (size_t)D}});
+        o.push_back(put(T_[k], D)); o.push_back(put(T_[k + 1], D));
+        o.push_back(putv(wqkv1)); o.push_back(putv(bqkv1)); o.push_back(put(A1[6], DD)); o.push_back(put(A1[7], D));
+        o.push_back(putv(transposed2(wqkv1.data(), 3 * D, D))); o.push_back(putv(transposed2(A1[6], D, D)));
+        o.push_back(put(A2[2], DD)); o.push_back(put(A2[3], D)); o.push_back(putv(wkv2)); o.push_back(putv(bkv2)); o.push_back(put(A2[6], DD));
+        o.push_back(put(A2[7], D));
+        o.push_back(putv(transposed2(A2[2], D, D))); o.push_back(putv(transposed2(wkv2.data(), 2 * D, D))); o.push_back(putv(transposed2(A2[6], D, D)));
+        o.push_back(put(T_[k + 18], (size_t)3 * L * 3)); o.push_back(put(T_[k + 19], 3)); o.push_back(put(T_[k + 20], (size_t)F * D * 3));
+        o.push_back(put(T_[k + 21], F));
+        o.push_back(put(T_[k + 22], MD)); o.push_back(put(T_[k + 23], e->M)); o.push_back(put(T_[k + 24], MD)); o.push_back(put(T_[k + 25], D));
+        o.push_back(putv(transposed2(T_[k + 22], e->M, D))); o.push_back(putv(transposed2(T_[k + 24], D, e->M)));
+        o.push_back(putv(padded(T_[k + 26], 2 * L, L, e->L2p, e->Lp))); o.push_back(put(T_[k + 27], (size_t)2 * L));
+        const std::vector<float> pt = transposed2(T_[k + 26], 2 * L, L);                                  // [L][2L]
+        o.push_back(putv(padded(pt.data(), L, 2 * L, e->Lp, e->L2p)));
+        o.push_back(put(T_[k + 28], (size_t)F * D)); o.push_back(put(T_[k + 29], F));
+    }
+    const size_t o_ada = put(ada_tables, (size_t)d->timesteps * e->n_ada * 2 * D);
+    const size_t o_freq = put(rfftfreq, (size_t)L / 2 + 1);
+    const size_t o_poly = put(poly, (size_t)3 * L);
+    // real-DFT basis of bins 1..NF: rows [0, NF) cos(2 pi k t / L), rows [NFp, NFp + NF) -sin(.), angles reduced exactly mod L
+    std::vector<float> dft((size_t)2 * e->NFp * e->Lp, 0.0f), cosT(L), sinT(L);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int m = 0; m < L; ++m) {
+        cosT[m] = (float)std::cos(two_pi * m / L);
+        sinT[m] = (float)std::sin(two_pi * m / L);
+    }
+    for (int kk = 0; kk < e->NF; ++kk)
+        for (int t = 0; t < L; ++t) {
+            const int m = (int)(((long long)(kk + 1) * t) % L);
+            dft[(size_t)kk * e->Lp + t] = cosT[m];
+            dft[(size_t)(e->NFp + kk) * e->Lp + t] = -sinT[m];
+        }
+    const size_t o_dft = putv(dft), o_cos = putv(cosT), o_sin = putv(sinT);
+    if (hipMalloc(&e->blob, host.size() * sizeof(float)) != hipSuccess) { delete e; return mpv_fail(ctx, MPV_ENOMEM, "mpv_dts_load: weight blob"); }
+    if (hipMemcpy(e->blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        dts_engine_destroy(e);
+        return mpv_fail(ctx, MPV_EHIP, "mpv_dts_load: upload failed");
+    }
+    size_t at = 0;
+    auto nx = [&]() { return (const float*)(e->blob + o[at++]); };
+    e->wemb = nx(); e->bemb = nx(); e->winv = nx(); e->binv = nx(); e->wcs = nx(); e->wcm = nx(); e->pe_enc = nx(); e->pe_dec = nx();
+    e->enc.resize(d->n_enc);
+    for (auto& w : e->enc) {
+        w.ln2w = nx(); w.ln2b = nx(); w.wqkv = nx(); w.bqkv = nx(); w.wp = nx(); w.bp = nx(); w.w0 = nx(); w.b0 = nx(); w.w2 = nx(); w.b2 = nx();
+        w.wqkv_t = nx(); w.wp_t = nx(); w.w0_t = nx(); w.w2_t = nx();
+    }
+    e->dec.resize(d->n_dec);
+    for (auto& w : e->dec) {
+        w.ln2w = nx(); w.ln2b = nx();
+        w.wqkv1 = nx(); w.bqkv1 = nx(); w.wp1 = nx(); w.bp1 = nx(); w.wqkv1_t = nx(); w.wp1_t = nx();
+        w.wq2 = nx(); w.bq2 = nx(); w.wkv2 = nx(); w.bkv2 = nx(); w.wp2 = nx(); w.bp2 = nx(); w.wq2_t = nx(); w.wkv2_t = nx(); w.wp2_t = nx();
+        w.tw0 = nx(); w.tb0 = nx(); w.tw3 = nx(); w.tb3 = nx();
+        w.w0 = nx(); w.b0 = nx(); w.w2 = nx(); w.b2 = nx(); w.w0_t = nx(); w.w2_t = nx();
+        w.wproj = nx(); w.bproj = nx(); w.wproj_t = nx(); w.wlin = nx(); w.blin = nx();
+    }
+    e->ada = e->blob + o_ada; e->freq = e->blob + o_freq; e->poly = e->blob + o_poly; e->dft = e->blob + o_dft; e->cosT = e->blob + o_cos;
+    e->sinT = e->blob + o_sin;
+    ctx->dts = e;
+    return MPV_OK;
+}
+
+static int dts_check(mpv_ctx* ctx, const char* fn, int32_t B, int32_t t) {
+    if (!ctx->dts) return mpv_fail(ctx, MPV_ESTATE, std::string(fn) + ": call mpv_dts_load first");
+    if (B < 1 || t < 0 || t >= ctx->dts->d.timesteps) return mpv_fail(ctx, MPV_EINVAL, std::string(fn) + ": need B >= 1 and 0 <= t < timesteps");
+    return MPV_OK;
+}
+
+int mpv_dts_forward(mpv_ctx* ctx, const float* x, int32_t B, int32_t t, float* trend, float* season) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_dts_forward: ctx is NULL");
+    if (int rc = dts_check(ctx, "mpv_dts_forward", B, t)) return rc;
+    if (!x || !trend || !season) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_forward: NULL argument");
+    DeviceGuard dg_(ctx->device);
+    DtsEngine& e = *ctx->dts;
+    DTS_TRY(carve(ctx, e, B));
+    DTS_TRY(forward(ctx, e, x, B, t));
+    const size_t n = sizeof(float) * (size_t)B * e.L * e.F;
+    MPV_HIP_TRY(ctx, hipMemcpyAsync(trend, e.trend, n, hipMemcpyDeviceToDevice, ctx->stream));
+    MPV_HIP_TRY(ctx, hipMemcpyAsync(season, e.season, n, hipMemcpyDeviceToDevice, ctx->stream));
+    return MPV_OK;
+}
+
+int mpv_dts_vjp(mpv_ctx* ctx, const float* x, int32_t B, int32_t t, const float* g_out, float* g_x) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_dts_vjp: ctx is NULL");
+    if (int rc = dts_check(ctx, "mpv_dts_vjp", B, t)) return rc;
+    if (!x || !g_out || !g_x) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_vjp: NULL argument");
+    DeviceGuard dg_(ctx->device);
+    DtsEngine& e = *ctx->dts;
+    DTS_TRY(carve(ctx, e, B));
+    DTS_TRY(forward(ctx, e, x, B, t));
+    DTS_TRY(backward(ctx, e, g_out, g_x, B, t));
+    return MPV_OK;
+}
+
+int mpv_dts_debug_tensor(mpv_ctx* ctx, const char* name, int32_t index, float* out, int64_t n_floats) {
+    if (!ctx || !ctx->dts || !name || !out) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_debug_tensor: bad argument");
+    DtsEngine& e = *ctx->dts;
+    const std::string s(name);
+    const float* src = nullptr;
+    if (s == "enc_x" && index >= 0 && index <= e.d.n_enc) src = e.xe[index];
+    else if (s == "dec_x" && index >= 0 && index <= e.d.n_dec) src = e.xd[index];
+    else if (s == "trend_sum") src = e.trend_sum;
+    else if (s == "season_sum") src = e.season_sum;
+    else if (s == "means") src = e.means;
+    else if (s == "g_dec" ) src = e.gA;
+    else if (s == "g_enc") src = e.genc;
+    if (!src) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_debug_tensor: unknown tensor");
+    DeviceGuard dg_(ctx->device);
+    MPV_HIP_TRY(ctx, hipMemcpyAsync(out, src, sizeof(float) * (size_t)n_floats, hipMemcpyDeviceToDevice, ctx->stream));
+    return MPV_OK;
+}
+
+int mpv_dts_sample(mpv_ctx* ctx, const mpv_dts_sample_shape* s, const float* history, const float* plan, const float* noise, float* samples) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_dts_sample: ctx is NULL");
+    if (!ctx->dts) return mpv_fail(ctx, MPV_ESTATE, "mpv_dts_sample: call mpv_dts_load first");
+    if (!s || !history || !plan || !samples) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_sample: NULL argument");
+    DtsEngine& e = *ctx->dts;
+    const int L = e.L, F = e.F;
+    if (s->n_windows < 1 || s->nodes < 1 || s->n_samples < 1 || s->chunk < 1 || s->n_samples % s->chunk != 0 || s->windows < 1 || s->windows >= L ||
+        s->n_pairs < 1)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_sample: need n_windows, nodes >= 1, n_samples a positive multiple of chunk, 1 <= windows < seq_len, n_pairs >= 1");
+    DeviceGuard dg_(ctx->device);
+    const int par = s->chunk, V = s->nodes, W = s->n_windows;
+    const long long rows = (long long)W * par * V;                       // sequences per chunk pass
+    if (rows > 0x7fffffffLL / std::max(L, 1)) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_sample: batch too large for one call");
+    const int B = (int)rows;
+    DTS_TRY(carve(ctx, e, B));
+    hipStream_t st = ctx->stream;
+    const long long n = rows * L * F;
+    const int Bw = par * V;                                              // batch of ONE evaluation_step chunk: the loss normalisers
+    const float inv_nmask = 1.0f / (float)((long long)Bw * s->windows * F);
+    const float coef_over_b = s->infill_coef / (float)Bw;
+    const unsigned seed_lo = (unsigned)s->seed, seed_hi = (unsigned)(s->seed >> 32);
+    // injected noise: per chunk, draws in the reference's order, each [W][Bw][L][F]: img, then per pair with
+    // time_next >= 0: `noise` (unused: sigma = 0), K Langevin epsilons (unused: coef_ = 0), q_sample noise
+    long long draws_per_chunk = 1;
+    for (int pi = 0; pi < s->n_pairs; ++pi)
+        if (plan[pi * MPV_DTS_PLAN_COLS + 1] >= 0.0f) draws_per_chunk += 2 + (long long)plan[pi * MPV_DTS_PLAN_COLS + 6];
+    hipLaunchKernelGGL(dts_build_target_kernel, g1d(n), dim3(256), 0, st, history, V, par, L, F, s->windows, n, e.target);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    for (int c = 0; c < s->n_samples / par; ++c) {
+        long long draw = (long long)c * draws_per_chunk;
+        unsigned stream_id = (unsigned)c * 65536u;
+        auto next_noise = [&](bool used, float* dst) -> int {            // consume one draw of the reference's stream
+            if (noise) {
+                if (used) MPV_HIP_TRY(ctx, hipMemcpyAsync(dst, noise + draw * n, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+            } else if (used) {
+                hipLaunchKernelGGL(dts_philox_kernel, g1d((n + 3) / 4), dim3(256), 0, st, seed_lo, seed_hi, stream_id, n, dst);
+                MPV_HIP_TRY(ctx, hipGetLastError());
+            }
+            ++draw;
+            ++stream_id;
+            return MPV_OK;
+        };
+        DTS_TRY(next_noise(true, e.img));                                // img = randn(shape), :285
+        for (int pi = 0; pi < s->n_pairs; ++pi) {
+            const float* pr = plan + pi * MPV_DTS_PLAN_COLS;
+            const int time = (int)pr[0];
+            const bool last = pr[1] < 0.0f;
+            const PairCoef kc{pr[2], pr[3], pr[4], pr[5], pr[8], pr[9]};
+            if (time < 0 || time >= e.d.timesteps) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_sample: plan row with a time outside [0, timesteps)");
+            DTS_TRY(forward(ctx, e, e.img, B, time));
+            hipLaunchKernelGGL(dts_predict_kernel, g1d(n), dim3(256), 0, st, e.img, e.trend, e.season, kc, last ? 1 : 0, n, e.xstart, e.pmean);
+            MPV_HIP_TRY(ctx, hipGetLastError());
+            if (last) break;
+            DTS_TRY(next_noise(false, nullptr));                         // `noise` of :300, multiplied by sigma = 0
+            // img = pred_mean; Langevin refinement of the whole tensor (:359-407)
+            MPV_HIP_TRY(ctx, hipMemcpyAsync(e.img, e.pmean, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+            const int K = (int)pr[6];
+            for (int it = 0; it < K; ++it) {
+                DTS_TRY(forward(ctx, e, e.img, B, time));
+                hipLaunchKernelGGL(dts_infill_grad_kernel, g1d(n), dim3(256), 0, st, e.trend, e.season, e.target, L, F, s->windows, inv_nmask, n, e.gout);
+                MPV_HIP_TRY(ctx, hipGetLastError());
+                DTS_TRY(backward(ctx, e, e.gout, e.gx, B, time));
+                hipLaunchKernelGGL(dts_langevin_step_kernel, g1d(n), dim3(256), 0, st, e.gx, e.pmean, coef_over_b, pr[7], n, e.img);
+                MPV_HIP_TRY(ctx, hipGetLastError());
+                DTS_TRY(next_noise(false, nullptr));                     // epsilon of :403, multiplied by coef_ = 0
+            }
+            DTS_TRY(next_noise(true, e.noise));                          // q_sample's noise, :305
+            hipLaunchKernelGGL(dts_overwrite_kernel, g1d(n), dim3(256), 0, st, e.img, e.target, e.noise, kc, L, F, s->windows, n, e.img);
+            MPV_HIP_TRY(ctx, hipGetLastError());
+        }
+        const long long no = rows * (L - s->windows) * F;
+        hipLaunchKernelGGL(dts_gather_kernel, g1d(no), dim3(256), 0, st, e.xstart, V, par, L, F, s->windows, s->n_samples, c, no, samples);
+        MPV_HIP_TRY(ctx, hipGetLastError());
+    }
+    return MPV_OK;
+}
+
+}  // extern "C"

@@ -10,18 +10,6 @@ namespace {
 std::mutex g_err_mu;
 std::string g_err;   // last context-less failure
 
-struct DeviceGuard {     // run on ctx->device without disturbing the caller's current device
-    int prev = -1;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) (void)hipSetDevice(dev);
-    }
-    ~DeviceGuard() {
-        int cur = -1;
-        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
-    }
-};
-
 size_t align4(size_t n) { return (n + 3) & ~size_t(3); }   // keep every sub-array 16-B aligned
 
 // lay out `parts` (host arrays) back to back in one device allocation; returns device sub-pointers
@@ -253,6 +241,7 @@ void mpv_ctx_destroy(mpv_ctx* ctx) {
     if (ctx->chain_stats) (void)hipFree(ctx->chain_stats);
     if (ctx->summary_acc) (void)hipFree(ctx->summary_acc);
     if (ctx->sample_ws) (void)hipFree(ctx->sample_ws);
+    dts_engine_destroy(ctx->dts);
     delete ctx;
 }
 

@@ -28,6 +28,21 @@ struct SigmaModel {
     const float *w0t, *b0, *ln0w, *ln0b, *w1t, *b1, *ln1w, *ln1b, *w2t, *b2;
 };
 
+struct DtsEngine;                      // DiffusionTS weights + workspace (dts.hip)
+void dts_engine_destroy(DtsEngine* e);
+
+struct DeviceGuard {     // run on ctx->device without disturbing the caller's current device
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
 struct mpv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -35,6 +50,7 @@ struct mpv_ctx {
     NsdiffModel ns;
     NsdiffModel tm;                // TMDM sampler weights (fp32 fields only)
     SigmaModel sg;
+    DtsEngine* dts = nullptr;
     double* reduce_ws = nullptr;   // partial sums of mpv_reduce
     unsigned long long* tile_counter = nullptr;   // work queue head of the split-f16 chain kernel (zeroed per launch)
     unsigned long long* chain_stats = nullptr;    // [0] steps re-run through the exact routine (device counter)

@@ -13,7 +13,10 @@ def diffusion_models(task_model, net_param, **kwargs):
     if task_model == "TMDM":
         from .Diffusion_model.TMDM.tmdm_adapter import TMDM_model
         return TMDM_model(net_param=net_param)
-    if task_model in ("DiffSTG", "DiffusionTS", "NsDiff_spatial"):
+    if task_model == "DiffusionTS":
+        from .Diffusion_model.DiffusionTS.DiffusionTS_model import DiffusionTS_model
+        return DiffusionTS_model(net_param=net_param)
+    if task_model in ("DiffSTG", "NsDiff_spatial"):
         raise NotImplementedError(
             "task_model {!r} is a later row of the hot-path scope table (SURVEY.md section 8): the NsDiff "
             "pointwise sampler is built first; this model family has no HIP path yet".format(task_model))
