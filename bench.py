@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--max-windows", type=int, default=None, help="profiling aid: cut the trajectory to this many windows "
                     "(the reported metric is then NOT the BASELINE workload and says so)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: rehearse the N>1 launch path on a 1-GPU box")
+    ap.add_argument("--dts-windows", type=int, default=1, help="--config c3: rolling windows per step (each 3200 sequences)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -236,7 +236,7 @@ int mpv_dts_forward(mpv_ctx* ctx, const float* x, int32_t B, int32_t t, float* t
 int mpv_dts_vjp(mpv_ctx* ctx, const float* x, int32_t B, int32_t t, const float* g_out, float* g_x);
 
 /* Validation aid: copy an internal tensor of the last forward / vjp ("enc_x", "dec_x" with a block index; "trend_sum",
- * "season_sum", "means", "g_dec", "g_enc") into out (dev). */
+ * "season_sum", "means"; after mpv_dts_vjp also "g_enc", the gradient at the encoder output) into out (dev). */
 int mpv_dts_debug_tensor(mpv_ctx* ctx, const char* name, int32_t index, float* out, int64_t n_floats);
 
 #define MPV_DTS_PLAN_COLS 10

@@ -44,6 +44,46 @@ class Tap:
         return np.concatenate([d.reshape(-1).numpy() for d in self.draws])
 
 
+class Replay:
+    """torch.randn / randn_like return the recorded draws again (cast to the requested dtype): the float64 re-run of a case."""
+    def __init__(self, draws):
+        self.draws = list(draws)
+
+    def __enter__(self):
+        self._r, self._rl = torch.randn, torch.randn_like
+        nxt = lambda: self.draws.pop(0)
+        torch.randn = lambda *a, **k: nxt().to(k.get("dtype") or torch.get_default_dtype())
+        torch.randn_like = lambda x, *a, **k: nxt().to(x.dtype)
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.randn_like = self._r, self._rl
+
+
+def record_float64(out, tag, m, x, t, batch, draws):
+    """The same case evaluated by the reference's own modules in float64 (weights, inputs and the recorded normal draws cast up):
+    the yardstick for what a float32 implementation can be asked to reproduce -- the reference's float32 run is itself only
+    within |ref32 - ref64| of the exact result (2.8e-4 elementwise on the C3-dimension model)."""
+    import copy
+    m64 = copy.deepcopy(m).double()
+    for mod in m64.modules():                      # TrendBlock keeps its polynomial basis as a plain attribute, not a buffer
+        if hasattr(mod, "poly_space"):
+            mod.poly_space = mod.poly_space.double()
+    torch.set_default_dtype(torch.float64)
+    try:
+        xin = x.double().clone().requires_grad_(True)
+        tt = torch.full((x.shape[0],), t, dtype=torch.long)
+        with torch.enable_grad():
+            y = m64.model.output(xin, tt)
+            (gx,) = torch.autograd.grad((y * torch.from_numpy(out["vjp_%s_gout" % tag]).double()).sum(), xin)
+        out["vjp_%s_y64" % tag], out["vjp_%s_gx64" % tag] = y.detach().numpy(), gx.detach().numpy()
+        with Replay(draws):
+            outs, _ = m64.evaluation_step(batch.double().clone())
+        out["eval_%s_out64" % tag] = outs.numpy()
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
 def record_blocks_and_grads(out, tag, m, x, t):
     """Per-block forward outputs of Transformer.forward (forward hooks on the reference's own blocks) and the input gradient of
     model_output for a seeded upstream gradient, with the gradients that reach the encoder output and the decoder input."""
@@ -113,6 +153,7 @@ def main():
         out["eval_%s_out" % tag], out["eval_%s_noise" % tag] = G.npy(outs), tap.flat()
         out["eval_%s_ndraws" % tag] = np.array([d.numel() for d in tap.draws], dtype=np.int64)
         record_blocks_and_grads(out, tag, m, x, par["timesteps"] // 2)
+        record_float64(out, tag, m, x, par["timesteps"] // 2, batch, tap.draws)
     # BASELINE configs[2] dimensions (d_model 64, 4 heads x 16, L = 200, 3 + 6 blocks): weights = seeded default init of the
     # build's own parameter holders (same names and shapes; loaded strictly into the reference model), so no state dict is stored
     sys.path.insert(0, str(HERE.parents[1]))
@@ -138,6 +179,7 @@ def main():
     with Tap() as tap:
         outs, _ = m.evaluation_step(batch.clone())
     out["eval_c3_out"], out["eval_c3_noise"] = G.npy(outs), tap.flat()
+    record_float64(out, "c3", m, x, 50, batch, tap.draws)
     np.savez_compressed(HERE / "diffusionts_cases.npz", **out)
     f = HERE / "diffusionts_cases.npz"
     print("%-28s %8.1f KiB" % (f.name, f.stat().st_size / 1024))

@@ -48,6 +48,7 @@ struct DtsEngine {
           *delta = nullptr, *gseason = nullptr, *gmeans = nullptr, *gout = nullptr, *gx = nullptr;
     // sampler state [B][L][F]
     float *img = nullptr, *target = nullptr, *xstart = nullptr, *pmean = nullptr, *noise = nullptr;
+    bool snapshots = false;                          // mpv_dts_vjp: keep the gradient at the encoder output for mpv_dts_debug_tensor
 };
 
 namespace {
@@ -314,6 +315,8 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
         DTS_TRY(lin(ctx, e.gqkv, 3 * D, w.wqkv1_t, nullptr, 3 * D, D, T, e.gC, D));
         DTS_TRY(ln_bwd(ctx, D, e.gC, e.xd[i], sc1, 1, gcur, 1, T));    // gcur = d_x0 = gradient w.r.t. the previous block's output
     }
+    if (e.snapshots)                                                     // "g_enc" of mpv_dts_debug_tensor (gseason is free from here on)
+        MPV_HIP_TRY(ctx, hipMemcpyAsync(e.gseason, e.genc, sizeof(float) * T * D, hipMemcpyDeviceToDevice, st));
     float* gdec0 = gcur;                                                 // d(h_dec0)
     float* genc = e.genc;                                                // d(encoder output), accumulated over the decoder blocks
     float* tmp = (gcur == e.gA) ? e.gB : e.gA;
@@ -506,8 +509,10 @@ int mpv_dts_vjp(mpv_ctx* ctx, const float* x, int32_t B, int32_t t, const float*
     DtsEngine& e = *ctx->dts;
     DTS_TRY(carve(ctx, e, B));
     DTS_TRY(forward(ctx, e, x, B, t));
-    DTS_TRY(backward(ctx, e, g_out, g_x, B, t));
-    return MPV_OK;
+    e.snapshots = true;
+    const int rc = backward(ctx, e, g_out, g_x, B, t);
+    e.snapshots = false;
+    return rc;
 }
 
 int mpv_dts_debug_tensor(mpv_ctx* ctx, const char* name, int32_t index, float* out, int64_t n_floats) {
@@ -520,8 +525,7 @@ int mpv_dts_debug_tensor(mpv_ctx* ctx, const char* name, int32_t index, float* o
     else if (s == "trend_sum") src = e.trend_sum;
     else if (s == "season_sum") src = e.season_sum;
     else if (s == "means") src = e.means;
-    else if (s == "g_dec" ) src = e.gA;
-    else if (s == "g_enc") src = e.genc;
+    else if (s == "g_enc") src = e.gseason;
     if (!src) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_debug_tensor: unknown tensor");
     DeviceGuard dg_(ctx->device);
     MPV_HIP_TRY(ctx, hipMemcpyAsync(out, src, sizeof(float) * (size_t)n_floats, hipMemcpyDeviceToDevice, ctx->stream));

@@ -111,3 +111,54 @@ def seeded_nsdiff_state(model, series: torch.Tensor, seed: int = 123):
     model.scaler_std = std.to(model.scaler_std.device)
     model.refresh_native()
     return model
+
+
+def er_graph(n: int, p: float = 0.05, seed: int = 0) -> np.ndarray:
+    """Dense symmetric 0/1 adjacency of an Erdos-Renyi graph (isolated nodes get one random neighbour)."""
+    rng = np.random.default_rng(seed)
+    upper = np.triu(rng.random((n, n)) < p, 1)
+    adj = (upper | upper.T).astype(np.float64)
+    for i in np.nonzero(adj.sum(axis=1) == 0)[0]:
+        j = int(rng.integers(n - 1))
+        j += j >= i
+        adj[i, j] = adj[j, i] = 1.0
+    return adj
+
+
+def _euler_maruyama(drift, x0, ticks, burn_ticks, dt, eta, eps_start, eps_end, rng):
+    sq = np.sqrt(dt)
+    x = x0.copy()
+    for _ in range(burn_ticks):
+        x = x + drift(x, eps_start) * dt + eta * sq * rng.standard_normal(x.shape[0])
+    ys = np.empty((ticks, x.shape[0]), dtype=np.float32)
+    ramp = np.linspace(eps_start, eps_end, ticks)
+    for i in range(ticks):
+        x = x + drift(x, ramp[i]) * dt + eta * sq * rng.standard_normal(x.shape[0])
+        ys[i] = x
+    return ys, ramp
+
+
+def sis_trajectory(nodes: int = 100, ticks: int = 10_000, seed: int = 0, d: float = 0.5, eta: float = 1e-4, dt: float = 0.1,
+                   burn_ticks: int = 500, eps_start: float = 0.2, eps_end: float = 0.0, m: int = 3):
+    """SIS network dynamics dx_i = [-d x_i + eps(t) (1 - x_i) sum_j A_ij x_j] dt + eta dW_i (reference
+    dataset/spdata_sde_SIS_dynamic_gene.py:44-52; d = 0.5, eta = 1e-4 as in paper_figures/common.py:45), the infection rate eps(t)
+    ramped down through the epidemic threshold.  -> record dict like `biomass_trajectory`."""
+    rng = np.random.default_rng(seed)
+    A = ba_graph(nodes, m=m, seed=seed)
+    x0 = rng.uniform(0.2, 0.8, nodes)
+    ys, ramp = _euler_maruyama(lambda x, e: -d * x + e * (1 - x) * (A @ x), x0, ticks, burn_ticks, dt, eta, eps_start, eps_end, rng)
+    return {"ys_dynamic": torch.from_numpy(ys), "ts_dynamic": torch.arange(ticks, dtype=torch.float32) * dt,
+            "tp_values": torch.from_numpy(ramp.astype(np.float32))}
+
+
+def neuronal_trajectory(nodes: int = 500, ticks: int = 100_000, seed: int = 0, tau: float = 2.0, mu: float = 1.5, eta: float = 0.01,
+                        dt: float = 0.1, burn_ticks: int = 500, eps_start: float = 0.0, eps_end: float = 0.9, p: float = 0.02):
+    """Wilson-Cowan network dynamics dx_i = [-x_i + (1 - eps(t)) sum_j A_ij sigmoid(tau (x_j - mu))] dt + eta dW_i (reference
+    dataset/spdata_sde_neuronal_dynamic_gene.py:50-63; tau = 2, mu = 1.5, eta = 0.01) on an Erdos-Renyi graph."""
+    rng = np.random.default_rng(seed)
+    A = er_graph(nodes, p=p, seed=seed)
+    x0 = rng.uniform(2.0, 6.0, nodes)
+    ys, ramp = _euler_maruyama(lambda x, e: -x + (1 - e) * (A @ (1.0 / (1.0 + np.exp(-tau * (x - mu))))), x0, ticks, burn_ticks, dt, eta,
+                               eps_start, eps_end, rng)
+    return {"ys_dynamic": torch.from_numpy(ys), "ts_dynamic": torch.arange(ticks, dtype=torch.float32) * dt,
+            "tp_values": torch.from_numpy(ramp.astype(np.float32))}
