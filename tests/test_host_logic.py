@@ -167,7 +167,7 @@ def test_factory_and_config_errors(ckpt_wofx):
     from mpv_amd.models.models import diffusion_models
     with pytest.raises(ValueError, match="don't exit"):
         diffusion_models("nope", {})
-    for later in ("DiffSTG", "NsDiff_spatial"):
+    for later in ("NsDiff_spatial",):
         with pytest.raises(NotImplementedError):
             diffusion_models(later, {})
     dts = diffusion_models("DiffusionTS", dict(device="cpu", dataset_nf=1, windows=12, pred_len=8, d_model=16, n_layer_enc=1, n_layer_dec=1,

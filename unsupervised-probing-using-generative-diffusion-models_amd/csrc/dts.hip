@@ -133,6 +133,31 @@ int ln_bwd(mpv_ctx* ctx, int D, const float* g, const float* x, const float* gam
     return MPV_OK;
 }
 
+int mlp_fwd(mpv_ctx* ctx, int D, int M, const float* X, const float* W0, const float* b0, const float* W2, const float* b2, const float* lnw,
+            const float* lnb, float* Y, float* U, long long rows) {
+    MlpArgs a{X, W0, b0, W2, b2, lnw, lnb, Y, U, rows};
+    const size_t lds = sizeof(float) * ((size_t)M * (D + 4) + (size_t)D * (M + 4) + 64 * (D + 4));
+    const long long tiles = (rows + 63) / 64;
+    const long long per_cu = std::max<long long>(1, std::min<long long>(4, (long long)ctx->max_lds / (long long)lds));
+    const int grid = (int)std::min<long long>(tiles, per_cu * ctx->cu_count);
+#define DTS_MLP(DT_, MT_)                                                                              \
+    do {                                                                                               \
+        if (int rc = set_lds(ctx, dts_mlp_fwd_kernel<DT_, MT_>, lds)) return rc;                       \
+        hipLaunchKernelGGL((dts_mlp_fwd_kernel<DT_, MT_>), dim3(grid), dim3(256), lds, ctx->stream, a); \
+    } while (0)
+    if (D == 64 && M == 256) DTS_MLP(4, 16);
+    else if (D == 32 && M == 128) DTS_MLP(2, 8);
+    else if (D == 16 && M == 64) DTS_MLP(1, 4);
+    else return -100;                                                     // no fused instance: the caller falls back to two dts_lin launches
+#undef DTS_MLP
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+// x_out = x + mlp(ln2(x)); u (pre-GELU hidden) is kept only when the backward pass will read it
+int mlp_block(mpv_ctx* ctx, DtsEngine& e, const float* x, const float* lnw, const float* lnb, const float* w0, const float* b0, const float* w2,
+              const float* b2, float* u, float* out, long long T, bool save);
+
 inline dim3 g1d(long long n, int threads = 256) { return dim3((unsigned)((n + threads - 1) / threads)); }
 
 #define DTS_TRY(expr)            \
@@ -195,8 +220,16 @@ int carve(mpv_ctx* ctx, DtsEngine& e, int B) {
     return MPV_OK;
 }
 
-// ---- forward: Transformer.forward (transformer.py:422-438) ----------------------------------------------------------
-int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t) {
+int mlp_block(mpv_ctx* ctx, DtsEngine& e, const float* x, const float* lnw, const float* lnb, const float* w0, const float* b0, const float* w2,
+              const float* b2, float* u, float* out, long long T, bool save) {
+    const int rc = mlp_fwd(ctx, e.D, e.M, x, w0, b0, w2, b2, lnw, lnb, out, save ? u : nullptr, T);
+    if (rc != -100) return rc;
+    DTS_TRY(lin(ctx, x, e.D, w0, b0, e.D, e.M, T, u, e.M, PRO_LN, lnw, lnb));
+    return lin(ctx, u, e.M, w2, b2, e.M, e.D, T, out, e.D, PRO_GELU, nullptr, nullptr, 0, x, e.D);
+}
+
+// ---- forward: Transformer.forward (transformer.py:422-438); save = the input-gradient pass follows ----------------------------
+int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t, bool save) {
     const int L = e.L, F = e.F, D = e.D, H = e.H, M = e.M;
     const long long T = (long long)B * L;
     const float scale = 1.0f / std::sqrt((float)e.hd);
@@ -213,8 +246,7 @@ int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t) {
         AttnArgs a{s.qkv, s.qkv + D, s.qkv + 2 * D, 3 * D, 3 * D, 3 * D, nullptr, nullptr, D, s.att, D, nullptr, 0, s.lse, nullptr, H, L, L, e.hd, scale};
         DTS_TRY(attn(ctx, 0, a, B));
         DTS_TRY(lin(ctx, s.att, D, w.wp, w.bp, D, D, T, s.x1, D, PRO_NONE, nullptr, nullptr, 0, e.xe[i], D));
-        DTS_TRY(lin(ctx, s.x1, D, w.w0, w.b0, D, M, T, s.u, M, PRO_LN, w.ln2w, w.ln2b));
-        DTS_TRY(lin(ctx, s.u, M, w.w2, w.b2, M, D, T, e.xe[i + 1], D, PRO_GELU, nullptr, nullptr, 0, s.x1, D));
+        DTS_TRY(mlp_block(ctx, e, s.x1, w.ln2w, w.ln2b, w.w0, w.b0, w.w2, w.b2, s.u, e.xe[i + 1], T, save));
     }
     const float* encout = e.xe[e.d.n_enc];
     MPV_HIP_TRY(ctx, hipMemsetAsync(e.trend_sum, 0, sizeof(float) * T * F, st));
@@ -243,9 +275,8 @@ int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t) {
                            e.famp, e.fph);
         hipLaunchKernelGGL(dts_fourier_synth_kernel, g1d(T * D), dim3(256), 0, st, s.fidx, e.famp, e.fph, e.freq + 1, L, D, e.topk, T * D, e.season_sum);
         MPV_HIP_TRY(ctx, hipGetLastError());
-        DTS_TRY(lin(ctx, s.x2, D, w.w0, w.b0, D, M, T, s.u, M, PRO_LN, w.ln2w, w.ln2b));
-        DTS_TRY(lin(ctx, s.u, M, w.w2, w.b2, M, D, T, e.x3, D, PRO_GELU, nullptr, nullptr, 0, s.x2, D));
-        hipLaunchKernelGGL(dts_meansub_fwd_kernel, dim3(B), dim3(256), sizeof(float) * D, st, e.x3, w.wlin, w.blin, L, F, D, e.xd[i + 1],
+        DTS_TRY(mlp_block(ctx, e, s.x2, w.ln2w, w.ln2b, w.w0, w.b0, w.w2, w.b2, s.u, e.x3, T, save));
+        hipLaunchKernelGGL(dts_meansub_fwd_kernel, dim3(B), dim3(256), sizeof(float) * (256 + D), st, e.x3, w.wlin, w.blin, L, F, D, e.xd[i + 1],
                            e.means + (size_t)i * F, e.d.n_dec * F);
         MPV_HIP_TRY(ctx, hipGetLastError());
     }
@@ -260,7 +291,7 @@ int attn_bwd(mpv_ctx* ctx, DtsEngine& e, int B, const float* Q, int ldq, const f
              float* lse, float* dq, int lddq, float* dk, float* dv, int lddkv) {
     const long long n = (long long)B * e.H * e.L;
     const float scale = 1.0f / std::sqrt((float)e.hd);
-    hipLaunchKernelGGL(dts_attn_delta_kernel, g1d(n), dim3(256), 0, ctx->stream, dO, O, e.D, e.H, e.L, e.hd, n, e.delta);
+    hipLaunchKernelGGL(dts_attn_delta_kernel, g1d(n), dim3(256), 0, ctx->stream, dO, O, e.D, e.H, e.L, e.hd, n, e.delta);   // n = tokens * heads
     MPV_HIP_TRY(ctx, hipGetLastError());
     AttnArgs a{Q, K, V, ldq, ldkv, ldkv, dO, O, e.D, dq, lddq, nullptr, 0, lse, e.delta, e.H, e.L, e.L, e.hd, scale};
     DTS_TRY(attn(ctx, 1, a, B));
@@ -289,7 +320,7 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
         const float* sc1 = ada_t + (size_t)ada_i * 2 * D;
         const float* sc2 = sc1 + 2 * D;
         // out = x3 - mean(x3), mean_i = Linear(mean): d_x3 -> gnext
-        hipLaunchKernelGGL(dts_meansub_bwd_kernel, dim3(B), dim3(256), sizeof(float) * D, st, gcur, w.wlin, e.gmeans + (size_t)i * F, e.d.n_dec * F, L, F, D, gnext);
+        hipLaunchKernelGGL(dts_meansub_bwd_kernel, dim3(B), dim3(256), sizeof(float) * (256 + D), st, gcur, w.wlin, e.gmeans + (size_t)i * F, e.d.n_dec * F, L, F, D, gnext);
         MPV_HIP_TRY(ctx, hipGetLastError());
         std::swap(gcur, gnext);                                          // gcur = d_x3
         // x3 = x2 + mlp(ln2(x2))
@@ -333,7 +364,7 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
         DTS_TRY(ln_bwd(ctx, D, e.gC, e.xe[i], sc, 1, genc, 1, T));     // genc = d_x0
     }
     (void)tmp;
-    hipLaunchKernelGGL(dts_embed_bwd_kernel, g1d(T * F), dim3(256), 0, st, genc, gdec0, e.wemb, L, F, D, T * F, gx);
+    hipLaunchKernelGGL(dts_embed_bwd_kernel, g1d(T * F * 16), dim3(256), 0, st, genc, gdec0, e.wemb, L, F, D, T * F, gx);
     MPV_HIP_TRY(ctx, hipGetLastError());
     return MPV_OK;
 }
@@ -494,7 +525,7 @@ int mpv_dts_forward(mpv_ctx* ctx, const float* x, int32_t B, int32_t t, float* t
     DeviceGuard dg_(ctx->device);
     DtsEngine& e = *ctx->dts;
     DTS_TRY(carve(ctx, e, B));
-    DTS_TRY(forward(ctx, e, x, B, t));
+    DTS_TRY(forward(ctx, e, x, B, t, false));
     const size_t n = sizeof(float) * (size_t)B * e.L * e.F;
     MPV_HIP_TRY(ctx, hipMemcpyAsync(trend, e.trend, n, hipMemcpyDeviceToDevice, ctx->stream));
     MPV_HIP_TRY(ctx, hipMemcpyAsync(season, e.season, n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -508,7 +539,7 @@ int mpv_dts_vjp(mpv_ctx* ctx, const float* x, int32_t B, int32_t t, const float*
     DeviceGuard dg_(ctx->device);
     DtsEngine& e = *ctx->dts;
     DTS_TRY(carve(ctx, e, B));
-    DTS_TRY(forward(ctx, e, x, B, t));
+    DTS_TRY(forward(ctx, e, x, B, t, true));
     e.snapshots = true;
     const int rc = backward(ctx, e, g_out, g_x, B, t);
     e.snapshots = false;
@@ -581,7 +612,7 @@ int mpv_dts_sample(mpv_ctx* ctx, const mpv_dts_sample_shape* s, const float* his
             const bool last = pr[1] < 0.0f;
             const PairCoef kc{pr[2], pr[3], pr[4], pr[5], pr[8], pr[9]};
             if (time < 0 || time >= e.d.timesteps) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_sample: plan row with a time outside [0, timesteps)");
-            DTS_TRY(forward(ctx, e, e.img, B, time));
+            DTS_TRY(forward(ctx, e, e.img, B, time, false));
             hipLaunchKernelGGL(dts_predict_kernel, g1d(n), dim3(256), 0, st, e.img, e.trend, e.season, kc, last ? 1 : 0, n, e.xstart, e.pmean);
             MPV_HIP_TRY(ctx, hipGetLastError());
             if (last) break;
@@ -590,7 +621,7 @@ int mpv_dts_sample(mpv_ctx* ctx, const mpv_dts_sample_shape* s, const float* his
             MPV_HIP_TRY(ctx, hipMemcpyAsync(e.img, e.pmean, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
             const int K = (int)pr[6];
             for (int it = 0; it < K; ++it) {
-                DTS_TRY(forward(ctx, e, e.img, B, time));
+                DTS_TRY(forward(ctx, e, e.img, B, time, true));
                 hipLaunchKernelGGL(dts_infill_grad_kernel, g1d(n), dim3(256), 0, st, e.trend, e.season, e.target, L, F, s->windows, inv_nmask, n, e.gout);
                 MPV_HIP_TRY(ctx, hipGetLastError());
                 DTS_TRY(backward(ctx, e, e.gout, e.gx, B, time));

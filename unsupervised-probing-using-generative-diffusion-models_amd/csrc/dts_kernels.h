@@ -364,19 +364,22 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_kernel(const AttnArgs p) {
     }
 }
 
-// delta[b][h][q] = sum_d dO[q][d] O[q][d]
-__global__ void dts_attn_delta_kernel(const float* dO, const float* O, int ld, int H, int L, int hd, long long n, float* delta) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // (b*H + h)*L + q
+// delta[b][h][q] = sum_d dO[q][d] O[q][d]; thread per (token, head), heads fastest: a wave reads 64 consecutive head slices
+__global__ void dts_attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O, int ld, int H, int L, int hd, long long n, float* delta) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // tok*H + h
     if (i >= n) return;
-    const int q = (int)(i % L);
-    const long long bh = i / L;
-    const int h = (int)(bh % H);
-    const long long b = bh / H;
-    const float* a = dO + (b * L + q) * ld + h * hd;
-    const float* o = O + (b * L + q) * ld + h * hd;
+    const int h = (int)(i % H);
+    const long long tok = i / H;
+    const long long b = tok / L;
+    const int q = (int)(tok - b * L);
+    const float* a = dO + tok * ld + h * hd;
+    const float* o = O + tok * ld + h * hd;
     float s = 0.0f;
-    for (int d = 0; d < hd; ++d) s += a[d] * o[d];
-    delta[i] = s;
+    for (int d = 0; d < hd; d += 4) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a + d), y = *reinterpret_cast<const f32x4*>(o + d);
+        s += (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]);
+    }
+    delta[(b * H + h) * L + q] = s;
 }
 
 template <int E>
@@ -485,6 +488,117 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_kernel(const AttnArgs p) {
         if (jl && 4 * g < HD) {
             *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lk + j) * p.ldout + h * HD + 4 * g) = dk;
             *reinterpret_cast<f32x4*>(p.out2 + ((long long)b * p.Lk + j) * p.ldout2 + h * HD + 4 * g) = dv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fused MLP of a block:  Y = X + W2 gelu(W0 LayerNorm(X) + b0) + b2   (transformer.py:227-232, 238).  The hidden activation
+// of a wave's 16 tokens stays in accumulator registers (M/16 tiles x 4) and is the B operand of the second product as it
+// stands; it goes to HBM only when the backward pass will need it (U != null).  D = 16*DT, M = 16*MT.
+// ---------------------------------------------------------------------------------------------------------------------
+struct MlpArgs {
+    const float *X, *W0, *b0, *W2, *b2, *lnw, *lnb;
+    float* Y;
+    float* U;                       // [rows][M] pre-GELU hidden, or null
+    long long rows;
+};
+
+template <int DT, int MT>
+__global__ __launch_bounds__(256) void dts_mlp_fwd_kernel(const MlpArgs p) {
+    constexpr int D = 16 * DT, M = 16 * MT, KS = D + 4, MS = M + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* W0l = lds;                     // [M][KS]
+    float* W2l = W0l + M * KS;            // [D][MS]
+    float* Xl = W2l + D * MS;             // [64][KS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    for (int i = tid; i < M * (D / 4); i += 256) {
+        const int n = i / (D / 4), c = i - n * (D / 4);
+        *reinterpret_cast<f32x4*>(W0l + n * KS + 4 * c) = *reinterpret_cast<const f32x4*>(p.W0 + (size_t)n * D + 4 * c);
+    }
+    for (int i = tid; i < D * (M / 4); i += 256) {
+        const int n = i / (M / 4), c = i - n * (M / 4);
+        *reinterpret_cast<f32x4*>(W2l + n * MS + 4 * c) = *reinterpret_cast<const f32x4*>(p.W2 + (size_t)n * M + 4 * c);
+    }
+    const long long n_tiles = (p.rows + 63) / 64;
+    const int srow = tid >> 2, spart = tid & 3;
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();
+        {   // stage 64 rows, LayerNorm applied (4 threads per row)
+            const long long tok = tile * 64 + srow;
+            const bool live = tok < p.rows;
+            const float* xr = p.X + (live ? tok : 0) * (long long)D;
+            float* dst = Xl + srow * KS;
+            f32x4 v[(DT + 3) / 4 > 0 ? DT : 1];
+            float s = 0.0f;
+            int cnt = 0;
+            for (int c = spart; c < D / 4; c += 4, ++cnt) {
+                v[cnt] = live ? *reinterpret_cast<const f32x4*>(xr + 4 * c) : f32x4{0, 0, 0, 0};
+                s += (v[cnt][0] + v[cnt][1]) + (v[cnt][2] + v[cnt][3]);
+            }
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            const float mean = s / (float)D;
+            float q = 0.0f;
+            for (int k = 0; k < cnt; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[k][e] -= mean;
+                    q += v[k][e] * v[k][e];
+                }
+            q += __shfl_xor(q, 1);
+            q += __shfl_xor(q, 2);
+            const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
+            cnt = 0;
+            for (int c = spart; c < D / 4; c += 4, ++cnt) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(p.lnw + 4 * c), bb = *reinterpret_cast<const f32x4*>(p.lnb + 4 * c);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = v[cnt][e] * rstd * a[e] + bb[e];
+                *reinterpret_cast<f32x4*>(dst + 4 * c) = o;
+            }
+        }
+        __syncthreads();
+        const long long tok = tile * 64 + 16 * wave + r16;
+        const bool live = tok < p.rows;
+        f32x4 xb[DT];
+#pragma unroll
+        for (int s = 0; s < DT; ++s) xb[s] = *reinterpret_cast<const f32x4*>(Xl + (16 * wave + r16) * KS + 16 * s + 4 * g);
+        f32x4 u[MT];
+#pragma unroll
+        for (int nt = 0; nt < MT; ++nt) {
+            f32x4 acc = *reinterpret_cast<const f32x4*>(p.b0 + 16 * nt + 4 * g);
+            const float* wa = W0l + (16 * nt + r16) * KS + 4 * g;
+#pragma unroll
+            for (int s = 0; s < DT; ++s) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(wa + 16 * s);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) DTS_MMA(acc, a[e], xb[s][e]);
+            }
+            if (p.U && live) *reinterpret_cast<f32x4*>(p.U + tok * (long long)M + 16 * nt + 4 * g) = acc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = gelu_f(acc[e]);
+            u[nt] = acc;
+        }
+#pragma unroll
+        for (int mt = 0; mt < DT; ++mt) {
+            f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            const float* wa = W2l + (16 * mt + r16) * MS + 4 * g;
+#pragma unroll
+            for (int nt = 0; nt < MT; nt += 2) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(wa + 16 * nt), a1 = *reinterpret_cast<const f32x4*>(wa + 16 * nt + 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    DTS_MMA(acc0, a0[r], u[nt][r]);
+                    DTS_MMA(acc1, a1[r], u[nt + 1][r]);
+                }
+            }
+            if (live) {
+                const int n0 = 16 * mt + 4 * g;
+                f32x4 v = (acc0 + acc1) + *reinterpret_cast<const f32x4*>(p.b2 + n0);
+                v += *reinterpret_cast<const f32x4*>(p.X + tok * (long long)D + n0);
+                *reinterpret_cast<f32x4*>(p.Y + tok * (long long)D + n0) = v;
+            }
         }
     }
 }

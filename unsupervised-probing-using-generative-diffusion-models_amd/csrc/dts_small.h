@@ -27,42 +27,52 @@ __global__ void dts_embed_fwd_kernel(const float* __restrict__ x, const float* _
     h_dec[i] = a + pe_dec[l * D + d];
 }
 
-// d_x[b][l][f] = sum_d sum_tap w[d][f][tap] (g1 + g2)[b][l - tap + 1][d]
+// d_x[b][l][f] = sum_d sum_tap w[d][f][tap] (g1 + g2)[b][l - tap + 1][d]; 16 lanes per output, channels strided over the lanes
 __global__ void dts_embed_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2, const float* __restrict__ w, int L, int F, int D,
                                      long long n, float* dx) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int f = (int)(i % F);
-    const long long tok = i / F;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;       // (tok, f)
+    const int li = threadIdx.x & 15;
+    const bool live = i < n;
+    const int f = live ? (int)(i % F) : 0;
+    const long long tok = live ? i / F : 0;
     const int l = (int)(tok % L);
     float a = 0.0f;
     for (int tap = 0; tap < 3; ++tap) {
         const int ll = l - tap + 1;
-        if (ll < 0 || ll >= L) continue;
+        if (!live || ll < 0 || ll >= L) continue;
         const float* ga = g1 + (tok - tap + 1) * D;
         const float* gb = g2 + (tok - tap + 1) * D;
-        for (int d = 0; d < D; ++d) a += w[(d * F + f) * 3 + tap] * (ga[d] + gb[d]);
+        for (int d = li; d < D; d += 16) a += w[(d * F + f) * 3 + tap] * (ga[d] + gb[d]);
     }
-    dx[i] = a;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) a += __shfl_xor(a, m);
+    if (live && li == 0) dx[i] = a;
 }
 
 // ---- decoder block tail (transformer.py:330-332): m = mean over tokens, out = x - m, mean_i = Linear(m).  block per sequence.
 __global__ __launch_bounds__(256) void dts_meansub_fwd_kernel(const float* __restrict__ x3, const float* __restrict__ wlin /*[F][D]*/,
                                                               const float* __restrict__ blin, int L, int F, int D, float* xout,
                                                               float* mean_i /*[B][n_dec][F] slice*/, int mean_stride) {
-    extern __shared__ float sm[];                 // [D]
+    extern __shared__ float sm[];                 // part[256], mean[D]
+    float* part = sm;
+    float* mean = sm + 256;
     const int b = blockIdx.x;
     const float* xb = x3 + (long long)b * L * D;
-    for (int d = threadIdx.x; d < D; d += 256) {
-        float s = 0.0f;
-        for (int l = 0; l < L; ++l) s += xb[l * D + d];
-        sm[d] = s / (float)L;
+    const int d = threadIdx.x % D, rg = threadIdx.x / D, ngroups = 256 / D;
+    float s = 0.0f;
+    for (int l = rg; l < L; l += ngroups) s += xb[l * D + d];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < D) {
+        float t = 0.0f;
+        for (int k = 0; k < ngroups; ++k) t += part[k * D + threadIdx.x];
+        mean[threadIdx.x] = t / (float)L;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < L * D; i += 256) xout[(long long)b * L * D + i] = xb[i] - sm[i % D];
+    for (int i = threadIdx.x; i < L * D; i += 256) xout[(long long)b * L * D + i] = xb[i] - mean[i % D];
     for (int f = threadIdx.x; f < F; f += 256) {
         float a = blin[f];
-        for (int d = 0; d < D; ++d) a += wlin[f * D + d] * sm[d];
+        for (int k = 0; k < D; ++k) a += wlin[f * D + k] * mean[k];
         mean_i[(long long)b * mean_stride + f] = a;
     }
 }
@@ -71,18 +81,24 @@ __global__ __launch_bounds__(256) void dts_meansub_fwd_kernel(const float* __res
 __global__ __launch_bounds__(256) void dts_meansub_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ wlin,
                                                               const float* __restrict__ dmean /*[B][stride] slice*/, int mean_stride, int L, int F,
                                                               int D, float* dx3) {
-    extern __shared__ float sm[];                 // [D]
+    extern __shared__ float sm[];                 // part[256], corr[D]
+    float* part = sm;
+    float* corr = sm + 256;
     const int b = blockIdx.x;
     const float* gb = dout + (long long)b * L * D;
-    for (int d = threadIdx.x; d < D; d += 256) {
-        float s = 0.0f;
-        for (int l = 0; l < L; ++l) s += gb[l * D + d];
-        float t = 0.0f;
-        for (int f = 0; f < F; ++f) t += wlin[f * D + d] * dmean[(long long)b * mean_stride + f];
-        sm[d] = (t - s) / (float)L;
+    const int d = threadIdx.x % D, rg = threadIdx.x / D, ngroups = 256 / D;
+    float s = 0.0f;
+    for (int l = rg; l < L; l += ngroups) s += gb[l * D + d];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < D) {
+        float t = 0.0f, sum = 0.0f;
+        for (int k = 0; k < ngroups; ++k) sum += part[k * D + threadIdx.x];
+        for (int f = 0; f < F; ++f) t += wlin[f * D + threadIdx.x] * dmean[(long long)b * mean_stride + f];
+        corr[threadIdx.x] = (t - sum) / (float)L;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < L * D; i += 256) dx3[(long long)b * L * D + i] = gb[i] + sm[i % D];
+    for (int i = threadIdx.x; i < L * D; i += 256) dx3[(long long)b * L * D + i] = gb[i] + corr[i % D];
 }
 
 // ---- TrendBlock (transformer.py:12-34).  x1 = rows [0, L) of the projected [2L][D] block (token axis = conv channels).
@@ -213,17 +229,16 @@ __global__ void dts_fourier_synth_kernel(const int* __restrict__ idx, const floa
     const long long bt = i / D;
     const int t = (int)(bt % L);
     const long long b = bt / L;
+    // the conjugate half has f -> -f, phase -> -phase: the same cosines again (rounding is symmetric), so the sum over the 2*topk
+    // terms is twice the sum over the selected bins (to within the order of the additions)
     float s = 0.0f;
     const float tf = (float)t, two_pi = 6.283185307179586f;
-    for (int half = 0; half < 2; ++half)
-        for (int j = 0; j < topk; ++j) {
-            const long long o = (b * topk + j) * D + d;
-            float f = freq[idx[o]], ph = phase[o];
-            if (half) { f = -f; ph = -ph; }
-            const float arg = (two_pi * f) * tf + ph;
-            s += amp[o] * cosf(arg);
-        }
-    season[i] += s;
+    for (int j = 0; j < topk; ++j) {
+        const long long o = (b * topk + j) * D + d;
+        const float arg = (two_pi * freq[idx[o]]) * tf + phase[o];
+        s += amp[o] * cosf(arg);
+    }
+    season[i] += 2.0f * s;
 }
 
 // exact-arithmetic transpose of the layer: out[t] = 2 sum_j (Re_j cos th_j t - Im_j sin th_j t) is linear in x through the
@@ -281,21 +296,29 @@ __global__ __launch_bounds__(256) void dts_tail_fwd_kernel(const float* __restri
     const int b = blockIdx.x, pad = (taps - 1) / 2;
     const float* hb = h + (long long)b * L * D;
     const float* sb = season + (long long)b * L * D;
-    for (int i = threadIdx.x; i < L * F; i += 256) {
+    const int li = threadIdx.x & 15, grp = threadIdx.x >> 4;       // 16 lanes per output (l, f), channels strided over the lanes
+    for (int i = grp; i < L * F; i += 16) {
         const int l = i / F, f = i - l * F;
-        float a = binv[f], c = 0.0f;
+        float a = 0.0f, c = 0.0f;
         for (int tap = 0; tap < 3; ++tap) {
             const int ll = l + tap - 1;
             if (ll < 0 || ll >= L) continue;
-            for (int d = 0; d < D; ++d) a += winv[(f * D + d) * 3 + tap] * hb[ll * D + d];
+            for (int d = li; d < D; d += 16) a += winv[(f * D + d) * 3 + tap] * hb[ll * D + d];
         }
         for (int tap = 0; tap < taps; ++tap) {
             int ll = l + tap - pad;
             ll = ll < 0 ? ll + L : (ll >= L ? ll - L : ll);
-            for (int d = 0; d < D; ++d) c += wcs[(f * D + d) * taps + tap] * sb[ll * D + d];
+            for (int d = li; d < D; d += 16) c += wcs[(f * D + d) * taps + tap] * sb[ll * D + d];
         }
-        res[i] = a;
-        cs[i] = c;
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+            a += __shfl_xor(a, m);
+            c += __shfl_xor(c, m);
+        }
+        if (li == 0) {
+            res[i] = a + binv[f];
+            cs[i] = c;
+        }
     }
     __syncthreads();
     for (int f = threadIdx.x; f < F; f += 256) {

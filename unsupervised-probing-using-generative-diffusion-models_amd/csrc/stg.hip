@@ -1,0 +1,662 @@
+// DiffSTG on gfx950: UGnet epsilon-network + DDIM / DDPM posterior sampler (reference models/Diffusion_model/DiffSTG/ugnet.py:55-295,
+// graph_diffusion_model.py:46-101, 193-282), behind the mpv_stg_* entry points of include/mpv_hip.h.
+//
+// Activations are fp32 [N][c][T'] (N = windows x parallel samples x graph nodes; channels x time of one node contiguous).
+// Per ResidualBlock (ugnet.py:115-135):
+//   stg_tcn_ln_kernel   one workgroup per node row, everything in LDS: causal k=3 TCN + 1x1 skip, time-embedding add, second TCN,
+//                       LayerNorm over channels.  (The Conv2d kernels are 3x3 over a height-1 axis: only their middle row acts.)
+//   stg_gemm_kernel     fp32 MFMA (v_mfma_f32_16x16x4_f32) GEMM over all rows: the k = T+1 "downsampling" convolution as
+//                       [Td_h*c] x [c*T] (its 10 output taps are 10 shifted copies of the kernel, built at load time), the four
+//                       Linear maps of the gated graph convolution as one [4C] x [C] product, the transposed k = T+1 convolution
+//                       as [c*T] x [Td_h*c], and the final Linear(2T -> T).
+//   stg_gate_kernel     ResGatedGraphConv aggregation: CSR gather over the incoming edges of each node, sigmoid gate, skip, bias,
+//                       ReLU.  The graph is stored once; sample copy p of window w uses node offset (w*P + p)*V (the reference
+//                       duplicates the edge index instead, graph_diffusion_model.py:77-84).
+//   stg_res_out_kernel  + shortcut (1x1 conv or identity) of the block input.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "chain_common.h"
+#include "dts_kernels.h"
+
+using dts::gelu_f;   // (unused; keeps the shared header's helpers referenced)
+
+namespace {
+
+#define STG_MMA(acc, a, b) (acc) = __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (acc), 0, 0, 0)
+
+// ---- general fp32 MFMA GEMM: Y[rows][N] (+)= X[rows][K] W[N][K]^T + bias[N]; K, N multiples of 4 -----------------------------
+struct GemmArgs {
+    const float* X; long long ldx;
+    const float* W;                 // [N][K]
+    const float* bias;              // [N] | null
+    float* Y; long long ldy;
+    long long rows;
+    int K, N, KC;                   // KC: K chunk staged per iteration (multiple of 16)
+    int relu;
+};
+constexpr int GEMM_NT = 10;         // 16-wide column tiles per workgroup (N tile = 160)
+
+__global__ __launch_bounds__(256) void stg_gemm_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int KS = p.KC + 4;
+    float* Wl = lds;                          // [160][KS]
+    float* Xl = lds + 16 * GEMM_NT * KS;      // [64][KS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    const long long tok0 = (long long)blockIdx.x * 64;
+    const int n0 = blockIdx.y * 16 * GEMM_NT;
+    f32x4 acc[GEMM_NT];
+#pragma unroll
+    for (int i = 0; i < GEMM_NT; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    const int C4 = p.KC >> 2;
+    for (int k0 = 0; k0 < p.K; k0 += p.KC) {
+        __syncthreads();
+        for (int i = tid; i < 16 * GEMM_NT * C4; i += 256) {
+            const int n = i / C4, c = i - n * C4;
+            const bool ok = (n0 + n) < p.N && (k0 + 4 * c) < p.K;
+            *reinterpret_cast<f32x4*>(Wl + n * KS + 4 * c) = ok ? *reinterpret_cast<const f32x4*>(p.W + (long long)(n0 + n) * p.K + k0 + 4 * c) : f32x4{0, 0, 0, 0};
+        }
+        for (int i = tid; i < 64 * C4; i += 256) {
+            const int r = i / C4, c = i - r * C4;
+            const bool ok = (tok0 + r) < p.rows && (k0 + 4 * c) < p.K;
+            *reinterpret_cast<f32x4*>(Xl + r * KS + 4 * c) = ok ? *reinterpret_cast<const f32x4*>(p.X + (tok0 + r) * p.ldx + k0 + 4 * c) : f32x4{0, 0, 0, 0};
+        }
+        __syncthreads();
+        const float* xb = Xl + (16 * wave + r16) * KS + 4 * g;
+        for (int s = 0; s < (p.KC >> 4); ++s) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(xb + 16 * s);
+#pragma unroll
+            for (int nt = 0; nt < GEMM_NT; ++nt) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(Wl + (16 * nt + r16) * KS + 16 * s + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) STG_MMA(acc[nt], a[e], b[e]);
+            }
+        }
+    }
+    const long long tok = tok0 + 16 * wave + r16;
+    if (tok < p.rows) {
+#pragma unroll
+        for (int nt = 0; nt < GEMM_NT; ++nt) {
+            const int n = n0 + 16 * nt + 4 * g;
+            if (n < p.N) {
+                f32x4 v = acc[nt];
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                }
+                *reinterpret_cast<f32x4*>(p.Y + tok * p.ldy + n) = v;
+            }
+        }
+    }
+}
+
+// ---- per-row TCN + time embedding + TCN + LayerNorm -----------------------------------------------------------------------------
+struct TcnArgs {
+    const float* src1; int c1;      // [N][c1][T]
+    const float* src2; int c2;      // concatenated skip [N][c2][T] | null
+    const float *w1, *b1;           // [co][ci][3] (middle row of the 3x3 kernel), [co]
+    const float *ws1, *bs1;         // tcn1.shortcut [co][ci], [co] | null (identity)
+    const float *wt, *bt;           // t_conv [co][d_h], [co]
+    const float* temb;              // [d_h] sinusoidal embedding of this step's t
+    const float *w2, *b2;           // tcn2 [co][co][3], [co]
+    const float *lnw, *lnb;         // [co]
+    float* out;                     // [N][co][T]
+    int co, T, d_h;
+};
+
+__global__ __launch_bounds__(256) void stg_tcn_ln_kernel(const TcnArgs p) {
+    extern __shared__ float sm[];
+    const int ci = p.c1 + p.c2, T = p.T, TP = T + 2;
+    float* xs = sm;                           // [ci][T+2], two zeros in front (causal padding)
+    float* h1 = xs + ci * TP;                 // [co][T+2]
+    float* h2 = h1 + p.co * TP;               // [co][T]
+    float* tv = h2 + p.co * T;                // [co]
+    const long long n = blockIdx.x;
+    for (int i = threadIdx.x; i < ci * TP; i += 256) {
+        const int c = i / TP, t = i - c * TP - 2;
+        float v = 0.0f;
+        if (t >= 0) v = c < p.c1 ? p.src1[(n * p.c1 + c) * T + t] : p.src2[(n * p.c2 + (c - p.c1)) * T + t];
+        xs[i] = v;
+    }
+    for (int c = threadIdx.x; c < p.co; c += 256) {
+        float a = p.bt[c];
+        for (int d = 0; d < p.d_h; ++d) a += p.wt[c * p.d_h + d] * p.temb[d];
+        tv[c] = a;
+        h1[c * TP] = h1[c * TP + 1] = 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.co * T; i += 256) {
+        const int c = i / T, t = i - c * T;
+        float a = p.b1[c];
+        for (int k = 0; k < ci; ++k) {
+            const float* w = p.w1 + (c * ci + k) * 3;
+            const float* x = xs + k * TP + t;
+            a += w[0] * x[0] + w[1] * x[1] + w[2] * x[2];
+        }
+        float s;
+        if (p.ws1) {
+            s = p.bs1[c];
+            for (int k = 0; k < ci; ++k) s += p.ws1[c * ci + k] * xs[k * TP + t + 2];
+        } else {
+            s = xs[c * TP + t + 2];
+        }
+        h1[c * TP + t + 2] = (a + s) + tv[c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.co * T; i += 256) {
+        const int c = i / T, t = i - c * T;
+        float a = p.b2[c];
+        for (int k = 0; k < p.co; ++k) {
+            const float* w = p.w2 + (c * p.co + k) * 3;
+            const float* x = h1 + k * TP + t;
+            a += w[0] * x[0] + w[1] * x[1] + w[2] * x[2];
+        }
+        h2[i] = a + h1[c * TP + t + 2];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {                 // LayerNorm([1, co]) over the channels of one time step
+        float s = 0.0f;
+        for (int c = 0; c < p.co; ++c) s += h2[c * T + t];
+        const float mean = s / (float)p.co;
+        float q = 0.0f;
+        for (int c = 0; c < p.co; ++c) {
+            const float d = h2[c * T + t] - mean;
+            q += d * d;
+        }
+        const float rstd = 1.0f / sqrtf(q / (float)p.co + 1e-5f);
+        for (int c = 0; c < p.co; ++c) p.out[(n * p.co + c) * T + t] = (h2[c * T + t] - mean) * rstd * p.lnw[c] + p.lnb[c];
+    }
+}
+
+// ---- ResGatedGraphConv aggregation + ReLU: kqvs [N][4C] = (key | query | value | skip) -> out [N][C] ------------------------------
+__global__ void stg_gate_kernel(const float* __restrict__ kqvs, const float* __restrict__ bias, const int* __restrict__ row_ptr,
+                                const int* __restrict__ col_idx, int V, int C, long long n, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // node*C + ch
+    if (i >= n) return;
+    const int ch = (int)(i % C);
+    const long long node = i / C;
+    const int v = (int)(node % V);
+    const long long base = node - v;                                            // first node of this graph copy
+    const float k = kqvs[node * 4 * C + ch];
+    float a = 0.0f;
+    for (int e = row_ptr[v]; e < row_ptr[v + 1]; ++e) {
+        const float* src = kqvs + (base + col_idx[e]) * 4 * C;
+        const float gate = 1.0f / (1.0f + __expf(-(k + src[C + ch])));
+        a += gate * src[2 * C + ch];
+    }
+    a = (a + kqvs[node * 4 * C + 3 * C + ch]) + bias[ch];
+    out[i] = fmaxf(a, 0.0f);
+}
+
+// ---- block output: up [N][co*T] + shortcut(x) ---------------------------------------------------------------------------------------
+__global__ void stg_res_out_kernel(const float* __restrict__ up, const float* __restrict__ src1, int c1, const float* __restrict__ src2, int c2,
+                                   const float* __restrict__ ws, const float* __restrict__ bs, int co, int T, long long n, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // (node*co + c)*T + t
+    if (i >= n) return;
+    const int t = (int)(i % T);
+    const int c = (int)((i / T) % co);
+    const long long node = i / ((long long)T * co);
+    float s;
+    if (ws) {
+        s = bs[c];
+        for (int k = 0; k < c1; ++k) s += ws[c * (c1 + c2) + k] * src1[(node * c1 + k) * T + t];
+        for (int k = 0; k < c2; ++k) s += ws[c * (c1 + c2) + c1 + k] * src2[(node * c2 + k) * T + t];
+    } else {
+        s = src1[(node * c1 + c) * T + t];
+    }
+    out[i] = up[i] + s;
+}
+
+// ---- Downsample: Conv2d(c, c, (1,3), stride 2, pad 1); Upsample: ConvTranspose2d(c, c, (1,4), stride 2, pad 1) ---------------
+__global__ void stg_down_kernel(const float* __restrict__ x, const float* __restrict__ w /*[c][c][3]*/, const float* __restrict__ b, int c, int T, int To,
+                                long long n, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // (node*c + co)*To + t
+    if (i >= n) return;
+    const int t = (int)(i % To);
+    const int co = (int)((i / To) % c);
+    const long long node = i / ((long long)To * c);
+    float a = b[co];
+    for (int ci = 0; ci < c; ++ci)
+        for (int k = 0; k < 3; ++k) {
+            const int ti = 2 * t + k - 1;
+            if (ti >= 0 && ti < T) a += w[(co * c + ci) * 3 + k] * x[(node * c + ci) * T + ti];
+        }
+    out[i] = a;
+}
+
+__global__ void stg_up_kernel(const float* __restrict__ x, const float* __restrict__ w /*[ci][co][4]*/, const float* __restrict__ b, int c, int T, int To,
+                              long long n, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // (node*c + co)*To + t
+    if (i >= n) return;
+    const int t = (int)(i % To);
+    const int co = (int)((i / To) % c);
+    const long long node = i / ((long long)To * c);
+    float a = b[co];
+    for (int k = 0; k < 4; ++k) {
+        const int num = t - k + 1;                                              // t = 2 j + k - 1
+        if (num < 0 || (num & 1)) continue;
+        const int j = num >> 1;
+        if (j >= T) continue;
+        for (int ci = 0; ci < c; ++ci) a += w[(ci * c + co) * 4 + k] * x[(node * c + ci) * T + j];
+    }
+    out[i] = a;
+}
+
+// ---- input projection (ugnet.py:271-277) and output 1x1 conv (:292) -----------------------------------------------------------------
+__global__ void stg_xproj_kernel(const float* __restrict__ xt, const float* __restrict__ xm, const float* __restrict__ w /*[d_h][F]*/,
+                                 const float* __restrict__ b, int T, int F, int d_h, long long n, float* out /*[N][d_h][2T]*/) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = (int)(i % (2 * T));
+    const int c = (int)((i / (2 * T)) % d_h);
+    const long long node = i / ((long long)2 * T * d_h);
+    const float* src = t < T ? xt + (node * T + t) * F : xm + (node * T + (t - T)) * F;
+    float a = b[c];
+    for (int f = 0; f < F; ++f) a += w[c * F + f] * src[f];
+    out[i] = a;
+}
+
+__global__ void stg_outconv_kernel(const float* __restrict__ x /*[N][d_h][T2]*/, const float* __restrict__ w /*[F][d_h]*/, const float* __restrict__ b,
+                                   int T2, int F, int d_h, long long n, float* out /*[N][F][T2]*/) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = (int)(i % T2);
+    const int f = (int)((i / T2) % F);
+    const long long node = i / ((long long)T2 * F);
+    float a = b[f];
+    for (int c = 0; c < d_h; ++c) a += w[f * d_h + c] * x[(node * d_h + c) * T2 + t];
+    out[i] = a;
+}
+
+// eps [N][F][T] -> posterior update of xt [N][T][F] (graph_diffusion_model.py:46-73); the coefficients are the reference's Python
+// floats rounded to fp32 by the scalar-tensor product
+__global__ void stg_posterior_kernel(const float* __restrict__ eps, const float* __restrict__ z, float c1, float c2, float c3, int ddpm, int T, int F,
+                                     long long n, float* xt) {
+#pragma clang fp contract(off)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // (node*T + t)*F + f
+    if (i >= n) return;
+    const int f = (int)(i % F);
+    const int t = (int)((i / F) % T);
+    const long long node = i / ((long long)F * T);
+    const float pred = eps[(node * F + f) * T + t];
+    const float a = c1 * (xt[i] - c2 * pred);
+    xt[i] = ddpm ? a + c3 * z[i] : a + c3 * pred;
+}
+
+// x_masked rows: r = (w*P + p)*V + v  <-  history[w][v][t][f] for t < T_h, 0 after
+__global__ void stg_build_masked_kernel(const float* __restrict__ hist, int V, int P, int T, int T_h, int F, long long n, float* xm) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int f = (int)(i % F);
+    const int t = (int)((i / F) % T);
+    const long long r = i / ((long long)F * T);
+    const int v = (int)(r % V);
+    const long long w = r / ((long long)V * P);
+    xm[i] = t < T_h ? hist[((w * V + v) * T_h + t) * F + f] : 0.0f;
+}
+
+// xt [W*P*V][T][F] of sequential pass s -> samples[w][v][t][f][s*P + p]
+__global__ void stg_gather_kernel(const float* __restrict__ xt, int V, int P, int T, int F, int S_total, int s_pass, long long n, float* samples) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long r = i / ((long long)F * T);
+    const long long tf = i - r * (long long)F * T;
+    const int v = (int)(r % V);
+    const int pcopy = (int)((r / V) % P);
+    const long long w = r / ((long long)V * P);
+    samples[((w * V + v) * (long long)T * F + tf) * S_total + s_pass * P + pcopy] = xt[i];
+}
+
+__global__ void stg_philox_kernel(unsigned seed_lo, unsigned seed_hi, unsigned stream, long long n, float* out) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (4 * q >= n) return;
+    float z[4];
+    chain::philox_normals((unsigned long long)q, stream, seed_lo, seed_hi, 0x53544700u, z);
+    for (int e = 0; e < 4 && 4 * q + e < n; ++e) out[4 * q + e] = z[e];
+}
+
+struct ResW {
+    const float *w1, *b1, *ws1, *bs1, *wt, *bt, *w2, *b2, *lnw, *lnb, *wdown, *bdown, *wg, *bg4, *gbias, *wup, *bup, *ws, *bs;
+};
+struct Step {
+    int kind = 0, c_in = 0, c_out = 0, T = 0, pop = 0, push = 0;
+    ResW r{};
+    const float *cw = nullptr, *cb = nullptr;        // down / up sample conv
+};
+
+inline dim3 g1d(long long n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace
+
+struct StgEngine {
+    mpv_stg_desc d{};
+    std::vector<Step> steps;
+    float* blob = nullptr;
+    const float *wx = nullptr, *bx = nullptr, *wo = nullptr, *bo = nullptr, *wl = nullptr, *bl = nullptr, *temb = nullptr;
+    int* graph = nullptr;            // row_ptr [V+1] then col_idx [E] (incoming edges by target node)
+    int V = 0, E = 0;
+    float* ws = nullptr;
+    size_t ws_floats = 0;
+    long long cap_N = 0;
+    std::vector<float*> act;         // one output buffer per step (+ input projection at [0])
+    float *hn = nullptr, *z = nullptr, *kqvs = nullptr, *sp = nullptr, *up = nullptr, *e1 = nullptr, *eps = nullptr, *xt = nullptr, *xm = nullptr,
+          *noise = nullptr;
+};
+
+void stg_engine_destroy(StgEngine* e) {
+    if (!e) return;
+    if (e->blob) (void)hipFree(e->blob);
+    if (e->ws) (void)hipFree(e->ws);
+    if (e->graph) (void)hipFree(e->graph);
+    delete e;
+}
+
+namespace {
+
+#define STG_TRY(expr)            \
+    do {                         \
+        if (int rc_ = (expr)) return rc_; \
+    } while (0)
+
+int gemm(mpv_ctx* ctx, const float* X, long long ldx, const float* W, const float* bias, int K, int N, long long rows, float* Y, long long ldy, int relu = 0) {
+    int KC = 64;
+    if (K < 64) KC = (K + 15) & ~15;
+    GemmArgs a{X, ldx, W, bias, Y, ldy, rows, K, N, KC, relu};
+    const size_t lds = sizeof(float) * (size_t)(16 * GEMM_NT + 64) * (KC + 4);
+    MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(stg_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((N + 16 * GEMM_NT - 1) / (16 * GEMM_NT)));
+    hipLaunchKernelGGL(stg_gemm_kernel, grid, dim3(256), lds, ctx->stream, a);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+int carve(mpv_ctx* ctx, StgEngine& e, long long N) {
+    if (N <= e.cap_N) return MPV_OK;
+    const int T2 = 2 * (e.d.T_h + e.d.T_p), F = e.d.nf;
+    size_t total = 0;
+    auto take = [&](size_t n) { const size_t at = total; total += (n + 3) & ~size_t(3); return at; };
+    std::vector<size_t> o_act(e.steps.size() + 1);
+    size_t max_ct = (size_t)e.d.d_h * T2, max_c = 0;
+    o_act[0] = take((size_t)N * e.d.d_h * T2);
+    for (size_t i = 0; i < e.steps.size(); ++i) {
+        const Step& s = e.steps[i];
+        const int To = s.kind == 1 ? (s.T - 1) / 2 + 1 : (s.kind == 2 ? 2 * s.T : s.T);
+        o_act[i + 1] = take((size_t)N * s.c_out * To);
+        max_ct = std::max(max_ct, (size_t)s.c_out * To);
+        max_c = std::max(max_c, (size_t)s.c_out);
+    }
+    const size_t C = (size_t)e.d.Td_h * max_c;
+    const size_t o_hn = take((size_t)N * max_ct), o_z = take((size_t)N * C), o_kqvs = take((size_t)N * 4 * C), o_sp = take((size_t)N * C),
+                 o_up = take((size_t)N * max_ct), o_e1 = take((size_t)N * F * T2), o_eps = take((size_t)N * F * (T2 / 2)),
+                 o_xt = take((size_t)N * (T2 / 2) * F), o_xm = take((size_t)N * (T2 / 2) * F), o_nz = take((size_t)N * (T2 / 2) * F);
+    if (e.ws) {
+        MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(e.ws);
+        e.ws = nullptr;
+        e.cap_N = 0;
+    }
+    if (hipMalloc(&e.ws, total * sizeof(float)) != hipSuccess) return mpv_fail(ctx, MPV_ENOMEM, "DiffSTG workspace");
+    e.ws_floats = total;
+    e.cap_N = N;
+    e.act.resize(o_act.size());
+    for (size_t i = 0; i < o_act.size(); ++i) e.act[i] = e.ws + o_act[i];
+    e.hn = e.ws + o_hn; e.z = e.ws + o_z; e.kqvs = e.ws + o_kqvs; e.sp = e.ws + o_sp; e.up = e.ws + o_up; e.e1 = e.ws + o_e1; e.eps = e.ws + o_eps;
+    e.xt = e.ws + o_xt; e.xm = e.ws + o_xm; e.noise = e.ws + o_nz;
+    return MPV_OK;
+}
+
+// UGnet.forward (ugnet.py:252-295): xt, xm [N][T][F], timestep t -> e.eps [N][F][T]
+int forward(mpv_ctx* ctx, StgEngine& e, const float* xt, const float* xm, long long N, int t) {
+    const int T = e.d.T_h + e.d.T_p, T2 = 2 * T, F = e.d.nf, d_h = e.d.d_h, Td = e.d.Td_h;
+    hipStream_t st = ctx->stream;
+    const float* temb = e.temb + (size_t)t * d_h;
+    hipLaunchKernelGGL(stg_xproj_kernel, g1d(N * d_h * T2), dim3(256), 0, st, xt, xm, e.wx, e.bx, T, F, d_h, N * d_h * T2, e.act[0]);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    std::vector<std::pair<const float*, int>> skips;                    // (buffer, channels)
+    skips.push_back({e.act[0], d_h});
+    const float* cur = e.act[0];
+    int cur_c = d_h;
+    for (size_t i = 0; i < e.steps.size(); ++i) {
+        const Step& s = e.steps[i];
+        float* out = e.act[i + 1];
+        if (s.kind == 1) {
+            const int To = (s.T - 1) / 2 + 1;
+            hipLaunchKernelGGL(stg_down_kernel, g1d(N * s.c_out * To), dim3(256), 0, st, cur, s.cw, s.cb, s.c_out, s.T, To, N * s.c_out * To, out);
+        } else if (s.kind == 2) {
+            hipLaunchKernelGGL(stg_up_kernel, g1d(N * s.c_out * 2 * s.T), dim3(256), 0, st, cur, s.cw, s.cb, s.c_out, s.T, 2 * s.T, N * s.c_out * 2 * s.T, out);
+        } else {
+            const float* src2 = nullptr;
+            int c2 = 0;
+            if (s.pop) {
+                src2 = skips.back().first;
+                c2 = skips.back().second;
+                skips.pop_back();
+            }
+            if (cur_c + c2 != s.c_in) return mpv_fail(ctx, MPV_ESTATE, "DiffSTG: block input channels do not match the layout");
+            const int co = s.c_out, C = Td * co;
+            TcnArgs a{cur, cur_c, src2, c2, s.r.w1, s.r.b1, s.r.ws1, s.r.bs1, s.r.wt, s.r.bt, temb, s.r.w2, s.r.b2, s.r.lnw, s.r.lnb, e.hn, co, s.T, d_h};
+            const size_t lds = sizeof(float) * ((size_t)s.c_in * (s.T + 2) + (size_t)co * (s.T + 2) + (size_t)co * s.T + co);
+            if (lds > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "DiffSTG: a node row does not fit the LDS (sequence too long)");
+            MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(stg_tcn_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(stg_tcn_ln_kernel, dim3((unsigned)N), dim3(256), lds, st, a);
+            MPV_HIP_TRY(ctx, hipGetLastError());
+            STG_TRY(gemm(ctx, e.hn, (long long)co * s.T, s.r.wdown, s.r.bdown, co * s.T, C, N, e.z, C));
+            STG_TRY(gemm(ctx, e.z, C, s.r.wg, s.r.bg4, C, 4 * C, N, e.kqvs, 4 * C));
+            hipLaunchKernelGGL(stg_gate_kernel, g1d(N * C), dim3(256), 0, st, e.kqvs, s.r.gbias, e.graph, e.graph + e.V + 1, e.V, C, N * C, e.sp);
+            MPV_HIP_TRY(ctx, hipGetLastError());
+            STG_TRY(gemm(ctx, e.sp, C, s.r.wup, s.r.bup, C, co * s.T, N, e.up, (long long)co * s.T));
+            hipLaunchKernelGGL(stg_res_out_kernel, g1d(N * co * s.T), dim3(256), 0, st, e.up, cur, cur_c, src2, c2, s.r.ws, s.r.bs, co, s.T,
+                               N * co * s.T, out);
+        }
+        MPV_HIP_TRY(ctx, hipGetLastError());
+        cur = out;
+        cur_c = s.c_out;
+        if (s.push) skips.push_back({out, s.c_out});
+    }
+    hipLaunchKernelGGL(stg_outconv_kernel, g1d(N * F * T2), dim3(256), 0, st, cur, e.wo, e.bo, T2, F, d_h, N * F * T2, e.e1);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return gemm(ctx, e.e1, T2, e.wl, e.bl, T2, T, N * F, e.eps, T);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mpv_stg_load(mpv_ctx* ctx, const mpv_stg_desc* d, const mpv_stg_step* steps, int32_t n_steps, const float* const* head /*6*/, const float* temb) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_stg_load: ctx is NULL");
+    if (!d || !steps || !head || !temb || n_steps < 1) return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_load: NULL argument");
+    const int T = d->T_h + d->T_p, F = d->nf, d_h = d->d_h, Td = d->Td_h;
+    if (T < 2 || (T & 1) || F < 1 || d_h < 2 || Td < 2 || (Td & 1) || d->timesteps < 1)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_load: need an even T_h + T_p, F >= 1, d_h >= 2, an even Td_h >= 2");
+    for (int i = 0; i < 6; ++i)
+        if (!head[i]) return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_load: NULL head tensor");
+    DeviceGuard dg(ctx->device);
+    MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    stg_engine_destroy(ctx->stg);
+    ctx->stg = nullptr;
+    StgEngine* e = new (std::nothrow) StgEngine();
+    if (!e) return mpv_fail(ctx, MPV_ENOMEM, "mpv_stg_load: out of host memory");
+    e->d = *d;
+    std::vector<float> host;
+    auto put = [&](const float* p, size_t n) { const size_t at = host.size(); host.insert(host.end(), p, p + n); host.resize((host.size() + 3) & ~size_t(3)); return at; };
+    auto putv = [&](const std::vector<float>& v) { return put(v.data(), v.size()); };
+    std::vector<std::vector<size_t>> offs(n_steps);
+    const int pad = Td / 2;
+    for (int i = 0; i < n_steps; ++i) {
+        const mpv_stg_step& s = steps[i];
+        Step st;
+        st.kind = s.kind; st.c_in = s.c_in; st.c_out = s.c_out; st.T = s.T; st.pop = s.pop; st.push = s.push;
+        if (s.c_in < 1 || s.c_out < 1 || s.T < 2 || ((s.c_out * s.T) & 3) || ((Td * s.c_out) & 3)) { delete e; return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_load: bad step shape"); }
+        std::vector<size_t>& o = offs[i];
+        if (s.kind == 0) {
+            const int ci = s.c_in, co = s.c_out, Ts = s.T, C = Td * co;
+            for (int k : {0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21})
+                if (!s.w[k]) { delete e; return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_load: NULL tensor in a residual block"); }
+            auto mid = [&](const float* w, int o_, int i_) {            // [o][i][3][3] -> middle row [o][i][3]
+                std::vector<float> m((size_t)o_ * i_ * 3);
+                for (int a = 0; a < o_ * i_; ++a)
+                    for (int k = 0; k < 3; ++k) m[(size_t)a * 3 + k] = w[(size_t)a * 9 + 3 + k];
+                return m;
+            };
+            o.push_back(putv(mid(s.w[0], co, ci))); o.push_back(put(s.w[1], co));
+            o.push_back(s.w[2] ? put(s.w[2], (size_t)co * ci) : (size_t)-1); o.push_back(s.w[3] ? put(s.w[3], co) : (size_t)-1);
+            o.push_back(put(s.w[4], (size_t)co * d_h)); o.push_back(put(s.w[5], co));
+            o.push_back(putv(mid(s.w[6], co, co))); o.push_back(put(s.w[7], co));
+            o.push_back(put(s.w[8], co)); o.push_back(put(s.w[9], co));
+            // downsampling Conv2d(co, co, (1, T+1), pad Td/2): row j*co + o, column i*T + t  <-  w[o][i][t - j + pad]
+            std::vector<float> wd((size_t)C * co * Ts, 0.0f), bd(C);
+            for (int j = 0; j < Td; ++j)
+                for (int oc = 0; oc < co; ++oc) {
+                    bd[(size_t)j * co + oc] = s.w[11][oc];
+                    for (int ic = 0; ic < co; ++ic)
+                        for (int t = 0; t < Ts; ++t) {
+                            const int k = t - j + pad;
+                            if (k >= 0 && k <= Ts) wd[((size_t)j * co + oc) * co * Ts + (size_t)ic * Ts + t] = s.w[10][((size_t)oc * co + ic) * (Ts + 1) + k];
+                        }
+                }
+            o.push_back(putv(wd)); o.push_back(putv(bd));
+            std::vector<float> wg((size_t)4 * C * C), bg((size_t)4 * C, 0.0f);
+            for (int part = 0; part < 4; ++part) {
+                std::memcpy(&wg[(size_t)part * C * C], s.w[12 + 2 * part], sizeof(float) * C * C);   // key.w, query.w, value.w at 12, 14, 16; skip.w at 18
+                if (part < 3) std::memcpy(&bg[(size_t)part * C], s.w[13 + 2 * part], sizeof(float) * C);
+            }
+            o.push_back(putv(wg)); o.push_back(putv(bg)); o.push_back(put(s.w[19], C));
+            // upsampling ConvTranspose2d(co, co, (1, T+1), pad Td/2): row o*T + t, column j*co + i  <-  w[i][o][t - j + pad]
+            std::vector<float> wu((size_t)co * Ts * C, 0.0f), bu((size_t)co * Ts);
+            for (int oc = 0; oc < co; ++oc)
+                for (int t = 0; t < Ts; ++t) {
+                    bu[(size_t)oc * Ts + t] = s.w[21][oc];
+                    for (int j = 0; j < Td; ++j) {
+                        const int k = t - j + pad;
+                        if (k < 0 || k > Ts) continue;
+                        for (int ic = 0; ic < co; ++ic) wu[((size_t)oc * Ts + t) * C + (size_t)j * co + ic] = s.w[20][((size_t)ic * co + oc) * (Ts + 1) + k];
+                    }
+                }
+            o.push_back(putv(wu)); o.push_back(putv(bu));
+            o.push_back(s.w[22] ? put(s.w[22], (size_t)co * ci) : (size_t)-1); o.push_back(s.w[23] ? put(s.w[23], co) : (size_t)-1);
+        } else {
+            if (!s.w[0] || !s.w[1] || s.c_in != s.c_out) { delete e; return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_load: bad resampling step"); }
+            o.push_back(put(s.w[0], (size_t)s.c_out * s.c_out * (s.kind == 1 ? 3 : 4)));
+            o.push_back(put(s.w[1], s.c_out));
+        }
+        e->steps.push_back(st);
+    }
+    const size_t o_wx = put(head[0], (size_t)d_h * F), o_bx = put(head[1], d_h), o_wo = put(head[2], (size_t)F * d_h), o_bo = put(head[3], F),
+                 o_wl = put(head[4], (size_t)T * 2 * T), o_bl = put(head[5], T), o_temb = put(temb, (size_t)(d->timesteps + 1) * d_h);
+    if (hipMalloc(&e->blob, host.size() * sizeof(float)) != hipSuccess) { delete e; return mpv_fail(ctx, MPV_ENOMEM, "mpv_stg_load: weight blob"); }
+    if (hipMemcpy(e->blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        stg_engine_destroy(e);
+        return mpv_fail(ctx, MPV_EHIP, "mpv_stg_load: upload failed");
+    }
+    auto P = [&](size_t off) { return off == (size_t)-1 ? (const float*)nullptr : (const float*)(e->blob + off); };
+    for (int i = 0; i < n_steps; ++i) {
+        Step& st = e->steps[i];
+        const std::vector<size_t>& o = offs[i];
+        if (st.kind == 0) {
+            st.r = ResW{P(o[0]), P(o[1]), P(o[2]), P(o[3]), P(o[4]), P(o[5]), P(o[6]), P(o[7]), P(o[8]), P(o[9]), P(o[10]), P(o[11]), P(o[12]), P(o[13]),
+                        P(o[14]), P(o[15]), P(o[16]), P(o[17]), P(o[18])};
+        } else {
+            st.cw = P(o[0]);
+            st.cb = P(o[1]);
+        }
+    }
+    e->wx = P(o_wx); e->bx = P(o_bx); e->wo = P(o_wo); e->bo = P(o_bo); e->wl = P(o_wl); e->bl = P(o_bl); e->temb = P(o_temb);
+    ctx->stg = e;
+    return MPV_OK;
+}
+
+int mpv_stg_set_graph(mpv_ctx* ctx, int32_t n_nodes, int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_stg_set_graph: ctx is NULL");
+    if (!ctx->stg) return mpv_fail(ctx, MPV_ESTATE, "mpv_stg_set_graph: call mpv_stg_load first");
+    if (n_nodes < 1 || n_edges < 0 || (n_edges > 0 && (!edge_src || !edge_dst))) return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_set_graph: bad argument");
+    std::vector<int> row_ptr(n_nodes + 1, 0), col(n_edges);
+    for (int64_t k = 0; k < n_edges; ++k) {
+        if (edge_src[k] < 0 || edge_src[k] >= n_nodes || edge_dst[k] < 0 || edge_dst[k] >= n_nodes) return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_set_graph: node index out of range");
+        ++row_ptr[edge_dst[k] + 1];
+    }
+    for (int v = 0; v < n_nodes; ++v) row_ptr[v + 1] += row_ptr[v];
+    std::vector<int> fill(row_ptr.begin(), row_ptr.end() - 1);
+    for (int64_t k = 0; k < n_edges; ++k) col[fill[edge_dst[k]]++] = (int)edge_src[k];        // edge order kept within a target: the sum order of index_add_
+    StgEngine& e = *ctx->stg;
+    DeviceGuard dg(ctx->device);
+    MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (e.graph) (void)hipFree(e.graph);
+    e.graph = nullptr;
+    if (hipMalloc(&e.graph, sizeof(int) * (size_t)(n_nodes + 1 + std::max<int64_t>(n_edges, 1))) != hipSuccess) return mpv_fail(ctx, MPV_ENOMEM, "mpv_stg_set_graph");
+    MPV_HIP_TRY(ctx, hipMemcpy(e.graph, row_ptr.data(), sizeof(int) * (n_nodes + 1), hipMemcpyHostToDevice));
+    if (n_edges) MPV_HIP_TRY(ctx, hipMemcpy(e.graph + n_nodes + 1, col.data(), sizeof(int) * n_edges, hipMemcpyHostToDevice));
+    e.V = n_nodes;
+    e.E = (int)n_edges;
+    return MPV_OK;
+}
+
+int mpv_stg_forward(mpv_ctx* ctx, const float* xt, const float* x_masked, int64_t n_rows, int32_t t, float* eps_out) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_stg_forward: ctx is NULL");
+    if (!ctx->stg || !ctx->stg->graph) return mpv_fail(ctx, MPV_ESTATE, "mpv_stg_forward: call mpv_stg_load and mpv_stg_set_graph first");
+    StgEngine& e = *ctx->stg;
+    if (!xt || !x_masked || !eps_out || n_rows < 1 || n_rows % e.V != 0 || t < 0 || t > e.d.timesteps)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_forward: need rows = a multiple of the graph's node count and 0 <= t <= diffusion_steps");
+    DeviceGuard dg(ctx->device);
+    STG_TRY(carve(ctx, e, n_rows));
+    STG_TRY(forward(ctx, e, xt, x_masked, n_rows, t));
+    // eps [N][F][T] -> [N][T][F]
+    const int T = e.d.T_h + e.d.T_p, F = e.d.nf;
+    if (F == 1) {
+        MPV_HIP_TRY(ctx, hipMemcpyAsync(eps_out, e.eps, sizeof(float) * n_rows * T, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        MPV_HIP_TRY(ctx, hipMemcpy2DAsync(eps_out, sizeof(float) * F, e.eps, sizeof(float), sizeof(float), 1, hipMemcpyDeviceToDevice, ctx->stream));
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_forward: F > 1 output transposition is not built (the reference's evaluation_step assumes F = 1)");
+    }
+    return MPV_OK;
+}
+
+int mpv_stg_sample(mpv_ctx* ctx, const mpv_stg_sample_shape* s, const float* history, const double* plan, const float* noise, float* samples) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_stg_sample: ctx is NULL");
+    if (!ctx->stg || !ctx->stg->graph) return mpv_fail(ctx, MPV_ESTATE, "mpv_stg_sample: call mpv_stg_load and mpv_stg_set_graph first");
+    if (!s || !history || !plan || !samples) return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_sample: NULL argument");
+    StgEngine& e = *ctx->stg;
+    if (s->n_windows < 1 || s->parallel < 1 || s->sequential < 1 || s->n_steps < 1) return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_sample: need n_windows, parallel, sequential, n_steps >= 1");
+    DeviceGuard dg(ctx->device);
+    const int T = e.d.T_h + e.d.T_p, F = e.d.nf, P = s->parallel, V = e.V;
+    const long long N = (long long)s->n_windows * P * V;
+    STG_TRY(carve(ctx, e, N));
+    hipStream_t st = ctx->stream;
+    const long long n = N * T * F;
+    const unsigned seed_lo = (unsigned)s->seed, seed_hi = (unsigned)(s->seed >> 32);
+    int draws = 1;
+    for (int i = 0; i < s->n_steps; ++i) draws += plan[i * MPV_STG_PLAN_COLS + 1] > 0.0 ? 1 : 0;
+    hipLaunchKernelGGL(stg_build_masked_kernel, g1d(n), dim3(256), 0, st, history, V, P, T, e.d.T_h, F, n, e.xm);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    for (int pass = 0; pass < s->sequential; ++pass) {
+        long long draw = (long long)pass * draws;
+        unsigned stream_id = (unsigned)pass * 4096u;
+        auto next_noise = [&](float* dst) -> int {
+            if (noise) MPV_HIP_TRY(ctx, hipMemcpyAsync(dst, noise + draw * n, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+            else {
+                hipLaunchKernelGGL(stg_philox_kernel, g1d((n + 3) / 4), dim3(256), 0, st, seed_lo, seed_hi, stream_id, n, dst);
+                MPV_HIP_TRY(ctx, hipGetLastError());
+            }
+            ++draw;
+            ++stream_id;
+            return MPV_OK;
+        };
+        STG_TRY(next_noise(e.xt));                                       // x_T = randn_like(x_masked), :253
+        for (int i = 0; i < s->n_steps; ++i) {
+            const double* pr = plan + i * MPV_STG_PLAN_COLS;
+            const int t1 = (int)pr[0];
+            if (t1 < 0 || t1 > e.d.timesteps) return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_sample: plan row with t outside [0, diffusion_steps]");
+            STG_TRY(forward(ctx, e, e.xt, e.xm, N, t1));
+            const int ddpm = pr[1] > 0.0;
+            if (ddpm) STG_TRY(next_noise(e.noise));
+            hipLaunchKernelGGL(stg_posterior_kernel, g1d(n), dim3(256), 0, st, e.eps, e.noise, (float)pr[2], (float)pr[3], (float)pr[4], ddpm, T, F, n, e.xt);
+            MPV_HIP_TRY(ctx, hipGetLastError());
+        }
+        hipLaunchKernelGGL(stg_gather_kernel, g1d(n), dim3(256), 0, st, e.xt, V, P, T, F, P * s->sequential, pass, n, samples);
+        MPV_HIP_TRY(ctx, hipGetLastError());
+    }
+    return MPV_OK;
+}
+
+}  // extern "C"

@@ -16,7 +16,10 @@ def diffusion_models(task_model, net_param, **kwargs):
     if task_model == "DiffusionTS":
         from .Diffusion_model.DiffusionTS.DiffusionTS_model import DiffusionTS_model
         return DiffusionTS_model(net_param=net_param)
-    if task_model in ("DiffSTG", "NsDiff_spatial"):
+    if task_model == "DiffSTG":
+        from .Diffusion_model.DiffSTG.graph_diffusion_model import DiffSTG
+        return DiffSTG(net_param=net_param)
+    if task_model in ("NsDiff_spatial",):
         raise NotImplementedError(
             "task_model {!r} is a later row of the hot-path scope table (SURVEY.md section 8): the NsDiff "
             "pointwise sampler is built first; this model family has no HIP path yet".format(task_model))
