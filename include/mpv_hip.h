@@ -263,6 +263,62 @@ int mpv_dts_sample(mpv_ctx* ctx, const mpv_dts_sample_shape* shape, const float*
                    float* samples);
 
 /* ------------------------------------------------------------------------------------
+ * DiffSTG: graph U-Net epsilon network + DDIM / DDPM sampler
+ * replaces: UGnet.forward and its blocks (DiffSTG/ugnet.py:15-295: TimeEmbedding, TcnBlock, ResidualBlock, Down/Upsample),
+ *           torch_geometric.nn.ResGatedGraphConv as selected by models/layer/gnn_conv.py:18-19 (restated from its published
+ *           definition: the package is absent, that layer's parity is unpinned), gaussian_denoise_step / gaussian_posterior /
+ *           duplicate_edge_index / evaluation_step (DiffSTG/graph_diffusion_model.py:46-101, 193-282).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t T_h, T_p;      /* history / prediction length; T = T_h + T_p (even)                    */
+    int32_t nf;            /* F                                                                    */
+    int32_t d_h;           /* base channels = time-embedding width                                 */
+    int32_t Td_h;          /* taps the k = T+1 convolution reduces the time axis to (even)         */
+    int32_t timesteps;     /* diffusion_steps: rows 0..timesteps of the time-embedding table       */
+} mpv_stg_desc;
+
+/* One step of UGnet.forward's module sequence (down path, middle, up path), host pointers in PyTorch layouts.
+ * kind 0: ResidualBlock(c_in -> c_out) at time length T (c_in includes the concatenated skip when pop = 1); w[] =
+ *    0 tcn1.conv.weight [co][ci][3][3]  1 tcn1.conv.bias  2 tcn1.shortcut.weight [co][ci] | NULL  3 tcn1.shortcut.bias | NULL
+ *    4 t_conv.weight [co][d_h]  5 t_conv.bias  6 tcn2.conv.weight [co][co][3][3]  7 tcn2.conv.bias  8 norm.weight [co]  9 norm.bias
+ *    10 downsampling.weight [co][co][1][T+1]  11 downsampling.bias
+ *    12..17 spatial.gnn.lin_key / lin_query / lin_value .weight [C][C], .bias [C] (C = Td_h co)   18 lin_skip.weight [C][C]   19 gnn bias [C]
+ *    20 upsampling.weight [co][co][1][T+1] (ConvTranspose2d: [in][out])  21 upsampling.bias  22 shortcut.weight [co][ci] | NULL  23 shortcut.bias | NULL
+ * kind 1: Downsample conv (1,3) stride 2 pad 1: w[0] weight [c][c][1][3], w[1] bias.   kind 2: Upsample ConvTranspose (1,4) stride 2 pad 1:
+ *    w[0] weight [c][c][1][4] ([in][out]), w[1] bias.
+ * push: the step's output is appended to the skip stack (down path); pop: the block concatenates the popped skip behind its input. */
+typedef struct {
+    int32_t kind, c_in, c_out, T, pop, push;
+    const float* w[24];
+} mpv_stg_step;
+
+/* head: host { x_proj.weight [d_h][F], x_proj.bias, out.0.weight [F][d_h], out.0.bias, out.1.weight [T][2T], out.1.bias }.
+ * temb: host [timesteps + 1][d_h] = TimeEmbedding(t, d_h) for t = 0..timesteps, evaluated with the reference's fp32 ops (ugnet.py:15-33). */
+int mpv_stg_load(mpv_ctx* ctx, const mpv_stg_desc* desc, const mpv_stg_step* steps, int32_t n_steps, const float* const* head, const float* temb);
+
+/* The graph of ONE window (host int64, torch_geometric convention: edge k goes edge_src[k] -> edge_dst[k], messages are summed at the
+ * target, an undirected edge is listed in both directions).  Stored as CSR by target; every (window, parallel sample) copy reuses it. */
+int mpv_stg_set_graph(mpv_ctx* ctx, int32_t n_nodes, int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst);
+
+/* eps = UGnet(x_t, t, (x_masked, edges)): xt, x_masked, eps_out dev [n_rows][T][F], n_rows a multiple of the graph's node count. */
+int mpv_stg_forward(mpv_ctx* ctx, const float* xt, const float* x_masked, int64_t n_rows, int32_t t, float* eps_out);
+
+#define MPV_STG_PLAN_COLS 6
+typedef struct {
+    int32_t n_windows;     /* W evaluation_step calls batched                                       */
+    int32_t parallel;      /* parallel_sampling P: graph copies per window in one batch             */
+    int32_t sequential;    /* sequential_sampling S: passes                                         */
+    int32_t n_steps;       /* inference_diffusion_steps = rows of plan                              */
+    uint64_t seed;
+} mpv_stg_sample_shape;
+
+/* history: dev [W][V][T_h][F] scaled.  plan: HOST float64 [n_steps][6]: 0 t1, 1 ddpm flag, 2..4 the posterior's Python-float
+ * coefficients (ddim: x' = c1 (x - c2 eps) + c3 eps; ddpm: x' = c1 (x - c2 eps) + c3 z), 5 t2 (informative).
+ * noise: dev or NULL: per sequential pass the draws of the reference in order (x_T, then one z per DDPM step), each [W][P*V][T][F].
+ * samples: dev [W][V][T][F][P*S], sample index s*P + p; window w's slice is the reference's splitted_predict_x0 (F = 1). */
+int mpv_stg_sample(mpv_ctx* ctx, const mpv_stg_sample_shape* shape, const float* history, const double* plan, const float* noise, float* samples);
+
+/* ------------------------------------------------------------------------------------
  * Synthetic input generation on device (the step before the path)
  * replaces: the harvested-biomass network simulator dataset/spdata_sde_biomass_dynamic_gene.py:53-68 (drift f, noise g;
  *           there integrated by torchsde) + normalize_time_series / sample_time_series of the harness

@@ -25,6 +25,7 @@ EXPORTS = (
     "mpv_abi_version", "mpv_ctx_create", "mpv_ctx_destroy", "mpv_ctx_set_stream", "mpv_last_error",
     "mpv_nsdiff_load", "mpv_nsdiff_sample", "mpv_chain_stats", "mpv_nsdiff_philox_normals", "mpv_sigma_load", "mpv_sigma_head",
     "mpv_reduce", "mpv_chain_timing", "mpv_chain_timing_enable", "mpv_tmdm_load", "mpv_tmdm_sample",
+    "mpv_stg_load", "mpv_stg_set_graph", "mpv_stg_forward", "mpv_stg_sample",
     "mpv_biomass_simulate", "mpv_dts_load", "mpv_dts_forward", "mpv_dts_vjp", "mpv_dts_debug_tensor", "mpv_dts_sample",
 )
 
@@ -64,6 +65,22 @@ class DtsSampleShape(C.Structure):
 
 
 DTS_PLAN_COLS = 10
+
+
+class StgDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("T_h", "T_p", "nf", "d_h", "Td_h", "timesteps")]
+
+
+class StgStep(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("c_in", C.c_int32), ("c_out", C.c_int32), ("T", C.c_int32), ("pop", C.c_int32), ("push", C.c_int32),
+                ("w", _F * 24)]
+
+
+class StgSampleShape(C.Structure):
+    _fields_ = [("n_windows", C.c_int32), ("parallel", C.c_int32), ("sequential", C.c_int32), ("n_steps", C.c_int32), ("seed", C.c_uint64)]
+
+
+STG_PLAN_COLS = 6
 
 
 class SigmaDesc(C.Structure):
@@ -113,6 +130,10 @@ def load_library():
         "mpv_sigma_load": (C.c_int, [vp, C.POINTER(SigmaDesc), C.POINTER(SigmaWeights)]),
         "mpv_sigma_head": (C.c_int, [vp, vp, i32, i64, i32, i64, i64, vp, vp, f32, vp]),
         "mpv_reduce": (C.c_int, [vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
+        "mpv_stg_load": (C.c_int, [vp, C.POINTER(StgDesc), C.POINTER(StgStep), i32, C.POINTER(_F), _F]),
+        "mpv_stg_set_graph": (C.c_int, [vp, i32, i64, C.POINTER(i64), C.POINTER(i64)]),
+        "mpv_stg_forward": (C.c_int, [vp, vp, vp, i64, i32, vp]),
+        "mpv_stg_sample": (C.c_int, [vp, C.POINTER(StgSampleShape), vp, C.POINTER(C.c_double), vp, vp]),
         "mpv_dts_load": (C.c_int, [vp, C.POINTER(DtsDesc), C.POINTER(_F), i32, _F, _F, _F]),
         "mpv_dts_forward": (C.c_int, [vp, vp, i32, i32, vp, vp]),
         "mpv_dts_vjp": (C.c_int, [vp, vp, i32, i32, vp, vp]),
@@ -170,6 +191,8 @@ class Context:
         self.tmdm = None       # (steps, nf)
         self.sigma = None      # SigmaDesc fields
         self.dts = None        # DtsDesc fields
+        self.stg = None        # (T_h, T_p, F, graph nodes | None)
+        self._stg_graph = None
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -396,6 +419,121 @@ class Context:
         self._bind_stream()
         self._check(self.lib.mpv_dts_sample(self._h, C.byref(shape), _dev_ptr(history, self.device, "history"), _fptr(plan),
                                             _dev_ptr(noise, self.device, "noise"), _dev_ptr(out, self.device, "samples")), "mpv_dts_sample")
+        return out
+
+    # ---- DiffSTG -----------------------------------------------------------------------
+    def load_stg(self, ugnet):
+        """Upload a UGnet holder (models/Diffusion_model/DiffSTG/ugnet.py): its layout() gives the step sequence."""
+        import math
+        keep = []
+
+        def h(t):
+            if t is None:
+                return None
+            keep.append(_host_f32(t))
+            return _fptr(keep[-1])
+
+        steps = ugnet.layout()
+        arr = (StgStep * len(steps))()
+        for i, st in enumerate(steps):
+            m = st["module"]
+            if st["kind"] == "res":
+                g = m.spatial.gnn
+                tensors = [m.tcn1.conv.weight, m.tcn1.conv.bias,
+                           m.tcn1.shortcut.weight if m.tcn1.shortcut is not None else None, m.tcn1.shortcut.bias if m.tcn1.shortcut is not None else None,
+                           m.t_conv.weight, m.t_conv.bias, m.tcn2.conv.weight, m.tcn2.conv.bias, m.norm.weight, m.norm.bias,
+                           m.downsampling.weight, m.downsampling.bias, g.lin_key.weight, g.lin_key.bias, g.lin_query.weight, g.lin_query.bias,
+                           g.lin_value.weight, g.lin_value.bias,
+                           g.lin_skip.weight if g.lin_skip is not None else torch.zeros_like(g.lin_key.weight),
+                           g.bias if g.bias is not None else torch.zeros_like(g.lin_key.bias),
+                           m.upsampling.weight, m.upsampling.bias]
+                has_sc = not isinstance(m.shortcut, torch.nn.Identity)
+                tensors += [m.shortcut.weight if has_sc else None, m.shortcut.bias if has_sc else None]
+                arr[i].kind, arr[i].c_in, arr[i].c_out, arr[i].T = 0, m.c_in, m.c_out, m.T
+                arr[i].pop, arr[i].push = int(st["pop"]), int(st["push"])
+            else:
+                c = m.conv.weight.shape[0]
+                tensors = [m.conv.weight, m.conv.bias] + [None] * 22
+                arr[i].kind, arr[i].c_in, arr[i].c_out = (1 if st["kind"] == "down" else 2), c, c
+                arr[i].pop, arr[i].push = 0, int(st.get("push", False))
+            for k, t in enumerate(tensors):
+                arr[i].w[k] = h(t)
+        # time lengths of the resampling steps follow from the sequence
+        T_cur = 2 * ugnet.T
+        for i, st in enumerate(steps):
+            if st["kind"] == "res":
+                if arr[i].T != T_cur:
+                    raise MpvError("UGnet layout: block {} expects T = {}, the sequence gives {}".format(i, arr[i].T, T_cur))
+            else:
+                arr[i].T = T_cur
+                T_cur = (T_cur - 1) // 2 + 1 if st["kind"] == "down" else 2 * T_cur
+        T_steps = int(ugnet.net_param["diffusion_steps"])
+        d_h = ugnet.d_h
+        half = d_h // 2                                                            # TimeEmbedding, reference ugnet.py:15-33
+        freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
+        emb = torch.arange(T_steps + 1).float()[:, None] * freq[None, :]
+        temb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
+        if d_h % 2 == 1:
+            temb = torch.nn.functional.pad(temb, (0, 1, 0, 0))
+        temb = _host_f32(temb)
+        head = [_host_f32(t) for t in (ugnet.x_proj.weight, ugnet.x_proj.bias, ugnet.out[0].weight, ugnet.out[0].bias, ugnet.out[1].weight,
+                                        ugnet.out[1].bias)]
+        head_arr = (_F * 6)(*[_fptr(t) for t in head])
+        desc = StgDesc(ugnet.T_h, ugnet.T_p, ugnet.F, d_h, int(ugnet.net_param["Td_h"]), T_steps)
+        self._bind_stream()
+        self._check(self.lib.mpv_stg_load(self._h, C.byref(desc), arr, len(steps), head_arr, _fptr(temb)), "mpv_stg_load")
+        self.stg = (ugnet.T_h, ugnet.T_p, ugnet.F)
+        self._stg_graph = None
+
+    def stg_set_graph(self, edge_index: torch.Tensor, num_nodes: int):
+        if self.stg is None:
+            raise MpvError("DiffSTG weights not loaded")
+        e = torch.as_tensor(edge_index).detach().to("cpu", torch.int64).reshape(2, -1).contiguous()
+        key = (int(num_nodes), e.shape[1], hash(e.numpy().tobytes()))
+        if self._stg_graph == key:
+            return
+        src, dst = e[0].contiguous(), e[1].contiguous()
+        P64 = C.POINTER(C.c_int64)
+        self._check(self.lib.mpv_stg_set_graph(self._h, int(num_nodes), e.shape[1], C.cast(src.data_ptr(), P64), C.cast(dst.data_ptr(), P64)),
+                    "mpv_stg_set_graph")
+        self._stg_graph = key
+
+    def stg_forward(self, xt: torch.Tensor, x_masked: torch.Tensor, t: int) -> torch.Tensor:
+        """eps = UGnet(xt, t, x_masked) over the graph set by stg_set_graph; xt, x_masked [rows, T, F] on device."""
+        if self.stg is None:
+            raise MpvError("DiffSTG weights not loaded")
+        if tuple(xt.shape) != tuple(x_masked.shape) or xt.dim() != 3 or xt.shape[1] != self.stg[0] + self.stg[1] or xt.shape[2] != self.stg[2]:
+            raise MpvError("xt and x_masked must both be [rows, {}, {}]".format(self.stg[0] + self.stg[1], self.stg[2]))
+        out = torch.empty_like(xt)
+        self._bind_stream()
+        self._check(self.lib.mpv_stg_forward(self._h, _dev_ptr(xt, self.device, "xt"), _dev_ptr(x_masked, self.device, "x_masked"), xt.shape[0], int(t),
+                                             _dev_ptr(out, self.device, "eps")), "mpv_stg_forward")
+        return out
+
+    def stg_sample(self, history: torch.Tensor, edge_index: torch.Tensor, plan: torch.Tensor, parallel: int, sequential: int,
+                   noise: Optional[torch.Tensor] = None, seed: int = 0) -> torch.Tensor:
+        """history [W, V, T_h, F] on device -> samples [W, V, T, F, parallel*sequential] on device."""
+        if self.stg is None:
+            raise MpvError("DiffSTG weights not loaded")
+        W, V, T_h, F = history.shape
+        if T_h != self.stg[0] or F != self.stg[2]:
+            raise MpvError("history must be [W, V, {}, {}], got {}".format(self.stg[0], self.stg[2], tuple(history.shape)))
+        self.stg_set_graph(edge_index, V)
+        plan = plan.detach().to("cpu", torch.float64).contiguous()
+        if plan.dim() != 2 or plan.shape[1] != STG_PLAN_COLS:
+            raise MpvError("plan must be [n_steps, {}]".format(STG_PLAN_COLS))
+        T = self.stg[0] + self.stg[1]
+        if noise is not None:
+            draws = 1 + int((plan[:, 1] > 0).sum())
+            need = sequential * draws * W * parallel * V * T * F
+            if noise.numel() != need:
+                raise MpvError("noise has {} elements, the draw order needs {}".format(noise.numel(), need))
+        out = torch.empty((W, V, T, F, parallel * sequential), device=self.device, dtype=torch.float32)
+        shape = StgSampleShape(W, parallel, sequential, plan.shape[0], seed & (2 ** 64 - 1))
+        self._bind_stream()
+        self._check(self.lib.mpv_stg_sample(self._h, C.byref(shape), _dev_ptr(history, self.device, "history"),
+                                            C.cast(plan.data_ptr(), C.POINTER(C.c_double)), _dev_ptr(noise, self.device, "noise"),
+                                            _dev_ptr(out, self.device, "samples")), "mpv_stg_sample")
         return out
 
     # ---- synthetic input generation ---------------------------------------------------

@@ -242,6 +242,7 @@ void mpv_ctx_destroy(mpv_ctx* ctx) {
     if (ctx->summary_acc) (void)hipFree(ctx->summary_acc);
     if (ctx->sample_ws) (void)hipFree(ctx->sample_ws);
     dts_engine_destroy(ctx->dts);
+    stg_engine_destroy(ctx->stg);
     delete ctx;
 }
 

@@ -18,9 +18,6 @@
 #include <cstring>
 
 #include "chain_common.h"
-#include "dts_kernels.h"
-
-using dts::gelu_f;   // (unused; keeps the shared header's helpers referenced)
 
 namespace {
 
