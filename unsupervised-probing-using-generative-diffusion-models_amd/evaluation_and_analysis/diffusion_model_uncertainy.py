@@ -320,9 +320,40 @@ def _skip_host_noise(model, n_windows: int, nodes: int):
         model.host_noise(1, nodes)
 
 
-def _native_shard(model, windows, pred_len, scale, keep_samples=True):
+# sequences (DiffusionTS) / graph-node rows (DiffSTG) per library call of the batched-history model families
+MAX_BATCH_ROWS = int(os.environ.get("MPV_MAX_BATCH_ROWS", 4096))
+
+
+def _native_shard_batched(model, windows, pred_len, scale, graph=None):
+    """DiffusionTS / DiffSTG: their `sample_windows` takes [W, V, history, F] and runs W evaluation_steps in one call."""
+    V = int(windows[0].shape[0])
+    ctx = model.native_context()
+    inv_std = model.scaler_std.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
+    inv_mean = model.scaler_mean.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
+    is_stg = graph is not None
+    hist_len = model.T_h if is_stg else model.windows
+    per_window = V * (int(model.parallel_sampling) if is_stg else min(int(model.parallel_sample), int(model.n_z_samples)))
+    chunk = max(1, MAX_BATCH_ROWS // max(per_window, 1))
+    preds, mpv_parts, mean_parts = [], [], []
+    for start in range(0, len(windows), chunk):
+        part = windows[start: start + chunk]
+        hist = torch.stack([torch.as_tensor(w).float()[:, :hist_len, :] for w in part]).to(ctx.device)         # [w, V, hist, F]
+        if scale:
+            hist = (hist - model.scaler_mean.to(ctx.device)) / model.scaler_std.to(ctx.device)
+        samples = model.sample_windows(hist, graph.edge_index) if is_stg else model.sample_windows(hist)
+        samples = samples[:, :, -pred_len:].contiguous()                                                       # [w, V, pred_len, F, S]
+        mpv, pm, _ = ctx.reduce(samples, inv_std, inv_mean)
+        mpv_parts.append(mpv)
+        mean_parts.append(pm)
+        preds.append(samples if dist_utils.active() else samples.cpu())
+    return torch.cat(preds, dim=0), torch.cat(mpv_parts), torch.cat(mean_parts)
+
+
+def _native_shard(model, windows, pred_len, scale, keep_samples=True, graph=None):
     """This rank's windows on the device: as few launches as memory allows.  keep_samples=False (curve-only runs of a
     stacked model whose horizon is not cut) never materialises the sample tensor: the summary comes out of the sampler."""
+    if getattr(model, "batched_history", False):
+        return _native_shard_batched(model, windows, pred_len, scale, graph=graph)
     V = int(windows[0].shape[0])
     ctx = model.native_context()
     inv_std = model.scaler_std.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
@@ -392,7 +423,7 @@ def _summary_only(model, rows4, scale, noise):
     return None, mpv, pm
 
 
-def _sample_stacked(model, window_list, pred_len, scale: bool, keep_samples: bool = True):
+def _sample_stacked(model, window_list, pred_len, scale: bool, keep_samples: bool = True, graph=None):
     """All windows of a trajectory -> (list of W CPU tensors [V, pred_len, F, S], MPV [W], pred_mean [W]).
 
     With torch.distributed active every rank computes a contiguous block of windows (`distributed.shard_bounds`), then
@@ -407,19 +438,23 @@ def _sample_stacked(model, window_list, pred_len, scale: bool, keep_samples: boo
     if hi > lo:
         if lo > 0:
             _skip_host_noise(model, lo, V)
-        if keep_samples:
+        if graph is not None and SHARD_COMPUTE is None:
+            samples, mpv_local, mean_local = compute(model, list(window_list[lo:hi]), pred_len, scale, graph=graph)
+        elif keep_samples or getattr(model, "batched_history", False):
             samples, mpv_local, mean_local = compute(model, list(window_list[lo:hi]), pred_len, scale)
         else:
             samples, mpv_local, mean_local = compute(model, list(window_list[lo:hi]), pred_len, scale, keep_samples=False)
     else:                                   # more ranks than windows: an empty block still joins the collectives
         cfg = getattr(model, "configs", model)
         S = int(getattr(cfg, "n_z_samples", getattr(model, "n_z_samples", 1)))
+        if graph is not None:
+            S = int(model.parallel_sampling) * int(model.sequential_sampling)
         nccl = dist_utils.active() and torch.distributed.get_backend() == "nccl"
         dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
         samples = torch.zeros((0, V, pred_len, int(window_list[0].shape[-1]), S), device=dev)
         mpv_local = mean_local = torch.zeros(0, device=dev)
     mpv_all, mean_all = dist_utils.gather_curve(n, lo, hi, mpv_local, mean_local)
-    if not keep_samples:
+    if not keep_samples and not getattr(model, "batched_history", False):
         return None, mpv_all, mean_all
     full = dist_utils.gather_windows(n, lo, hi, samples)
     return list(full.unbind(0)), mpv_all, mean_all
@@ -483,6 +518,56 @@ def run_slbp_sensitivity_cache(model, input_datas, cache_path, device, force_rec
     preds = [p.squeeze(0) for p in preds]
     _save_on_primary(preds, cache_path)
     return preds
+
+
+class _Graph:
+    """edge_index [2, E] (both directions of every undirected edge, source row 0 / target row 1) + num_nodes: what the reference gets
+    from torch_geometric.utils.from_networkx (reference :342-351), without torch_geometric."""
+    def __init__(self, edge_index, num_nodes):
+        self.edge_index, self.num_nodes, self.x = edge_index, int(num_nodes), None
+
+    def clone(self):
+        return _Graph(self.edge_index.clone(), self.num_nodes)
+
+
+def load_diffstg_graph(graph_file):
+    import networkx as nx
+    if graph_file is None:
+        raise ValueError("graph_file is required for DiffSTG.")
+    graph_file = _resolve_project_path(graph_file)
+    nx_g = nx.convert_node_labels_to_integers(nx.read_graphml(graph_file))
+    directed = nx_g if nx_g.is_directed() else nx_g.to_directed()
+    edges = list(directed.edges)
+    edge_index = torch.tensor(edges, dtype=torch.long).t().contiguous() if edges else torch.zeros((2, 0), dtype=torch.long)
+    return _Graph(edge_index, nx_g.number_of_nodes())
+
+
+def normalize_diffstg_pred_future_list(pred_future_list):
+    out = []
+    for pred_future in pred_future_list:
+        pred_future = torch.as_tensor(pred_future).detach().cpu()
+        if pred_future.ndim == 3:
+            pred_future = pred_future.unsqueeze(-2)
+        if pred_future.ndim != 4:
+            raise ValueError("DiffSTG pred_future must have shape [Node, pred_len, F, samples] "
+                             "or legacy [Node, pred_len, samples], got {}".format(tuple(pred_future.shape)))
+        out.append(pred_future)
+    return out
+
+
+def run_diffstg_evaluation_cache(model, timeseries_datas, pred_len, graph_data, cache_path, device, force_recompute=False, max_windows=None):
+    """Windows -> list of CPU tensors [V, pred_len, 1, parallel*sequential], cached (reference :369-397): all windows as disjoint
+    copies of the graph in as few library calls as memory allows."""
+    cache_path = Path(cache_path)
+    if cache_path.exists() and not force_recompute:
+        return normalize_diffstg_pred_future_list(_load_tensor_list(cache_path))
+    windows = list(timeseries_datas[:max_windows] if max_windows is not None else timeseries_datas)
+    with torch.no_grad():
+        preds, mpv, pm = _sample_stacked(model, windows, pred_len, scale=_uses_scaler(model), graph=graph_data)
+    out = _DeviceCurve(preds)
+    out.ews, out.pred_mean = mpv, pm
+    _save_on_primary(list(out), cache_path)
+    return out
 
 
 def run_nsdiff_g_cache(model, timeseries_datas, cache_path, device, pred_dim=0, force_recompute=False, max_windows=None):
@@ -982,8 +1067,6 @@ def uncertainty_ews(model_save_file=None, data_file=None, torch_time_series=None
     windows, pred_len = dataset_config.get("windows"), dataset_config.get("pred_len")
     if windows is None or pred_len is None:
         raise ValueError("model_trained.yaml must provide dataset.windows and dataset.pred_len.")
-    if task_model == "DiffSTG":
-        raise NotImplementedError("DiffSTG has no HIP path yet (SURVEY.md section 8, later row)")
 
     cache_path = resolve_cache_path(cache_path, model_save_file, data_file, dynamic_type)
     want_sampling = method in {"sampling", "both"}
@@ -1018,7 +1101,22 @@ def uncertainty_ews(model_save_file=None, data_file=None, torch_time_series=None
         return model
 
     preds, pred_mean_list, ews_list = None, [], []
-    if want_sampling:
+    if want_sampling and task_model == "DiffSTG":                       # reference :1393-1430
+        if dynamic_type not in NETWORK_DYNAMICS:
+            raise ValueError("DiffSTG only supports network dynamics: SIS, neuronal, biomass.")
+        if graph_file is None:
+            raise ValueError("graph_file is required for DiffSTG.")
+        if cached_preds is not None:
+            preds = normalize_diffstg_pred_future_list(cached_preds)
+            if model_save_file is not None and load_model_when_cached:
+                need_model()
+        else:
+            if infer_params is None:
+                infer_params = {"parallel_sampling": 10, "sequential_sampling": 1, "n_z_samples": 10, "diffusion_steps": 20}
+            preds = run_diffstg_evaluation_cache(need_model(), window_views, pred_len, load_diffstg_graph(graph_file), cache_path, device,
+                                                 force_recompute=force_recompute, max_windows=max_windows)
+        pred_mean_list, ews_list = summarize_pred_future_list(preds, model=model)
+    elif want_sampling:
         if cached_preds is not None:
             preds = cached_preds
             if model_save_file is not None and load_model_when_cached:

@@ -42,6 +42,8 @@ class graph_Diffusion_model(nn.Module):
 
 
 class DiffSTG(graph_Diffusion_model):
+    batched_history = True          # the harness hands `sample_windows` all windows of a launch as [W, V, history, F]
+
     def __init__(self, net_param):
         super().__init__(net_param=net_param)
         self.T_p, self.T_h, self.F = net_param["T_p"], net_param["T_h"], net_param["F"]

@@ -26,6 +26,8 @@ from .DiffusionTS import Diffusion_TS
 
 
 class DiffusionTS_model(nn.Module):
+    batched_history = True          # the harness hands `sample_windows` all windows of a launch as [W, V, history, F]
+
     def __init__(self, net_param):
         super().__init__()
         self.device = net_param["device"]
