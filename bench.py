@@ -102,8 +102,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=("c2", "c3"), default="c2",
-                    help="c2 (default, the headline): NsDiff 100-node biomass, N=32, T=50; c3: DiffusionTS 100-node SIS, N=32, T=100")
+    ap.add_argument("--config", choices=("c2", "c3", "c5"), default="c2",
+                    help="c2 (default, the headline): NsDiff 100-node biomass, N=32, T=50; c3: DiffusionTS 100-node SIS, N=32, T=100; "
+                         "c5: DiffSTG 200-node small-world biomass, N=32, 50 inference steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=4, help="windows of the workload timed on the CPU oracle (each ~25 s on 16 threads)")
     ap.add_argument("--gemm", choices=("f16x3", "f32", "f16x2", "f16"), default="f16x3",
@@ -119,6 +120,7 @@ def main():
                     "(the reported metric is then NOT the BASELINE workload and says so)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: rehearse the N>1 launch path on a 1-GPU box")
     ap.add_argument("--dts-windows", type=int, default=1, help="--config c3: rolling windows per step (each 3200 sequences)")
+    ap.add_argument("--stg-windows", type=int, default=4, help="--config c5: rolling windows per step (each 6400 graph-node rows)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -126,6 +128,9 @@ def main():
     if args.config == "c3":
         from mpv_amd.bench_dts import main_c3
         return main_c3(args, log)
+    if args.config == "c5":
+        from mpv_amd.bench_stg import main_c5
+        return main_c5(args, log)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
