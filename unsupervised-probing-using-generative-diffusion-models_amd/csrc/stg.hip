@@ -32,6 +32,7 @@ struct GemmArgs {
     long long rows;
     int K, N, KC;                   // KC: K chunk staged per iteration (multiple of 16)
     int relu;
+    const float* r1;                // optional residual [rows][N] added in the epilogue (a ResidualBlock's shortcut) | null
 };
 constexpr int GEMM_NT = 10;         // 16-wide column tiles per workgroup (N tile = 160)
 
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(256) void stg_gemm_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
                 }
+                if (p.r1) v += *reinterpret_cast<const f32x4*>(p.r1 + tok * p.ldy + n);       // + shortcut(x) of the block input, [rows][N]
                 *reinterpret_cast<f32x4*>(p.Y + tok * p.ldy + n) = v;
             }
         }
@@ -101,69 +103,105 @@ struct TcnArgs {
     const float *lnw, *lnb;         // [co]
     float* out;                     // [N][co][T]
     int co, T, d_h;
+    const float *wsb, *bsb;         // the BLOCK's shortcut 1x1 conv [co][ci], [co] | null (identity)
+    float* sc;                      // [N][co][T] shortcut(x), written when wsb
 };
 
+// A thread owns one time step and ALL output channels (CO accumulators): an input sample is read from LDS once per tap instead of
+// once per output channel, the weights are staged in LDS as [k][c][4] so that one broadcast ds_read_b128 feeds four FMAs, and the
+// LayerNorm over the channels of a time step is register-local.  When the block's shortcut is a 1x1 convolution it is formed here
+// too (the block input is in LDS anyway) and written to `sc` for the epilogue of the up-sampling product.
+template <int CO>
 __global__ __launch_bounds__(256) void stg_tcn_ln_kernel(const TcnArgs p) {
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ci = p.c1 + p.c2, T = p.T, TP = T + 2;
-    float* xs = sm;                           // [ci][T+2], two zeros in front (causal padding)
-    float* h1 = xs + ci * TP;                 // [co][T+2]
-    float* h2 = h1 + p.co * TP;               // [co][T]
-    float* tv = h2 + p.co * T;                // [co]
+    float* W1 = sm;                           // [ci][CO][4] = (w1 tap0, tap1, tap2, tcn1.shortcut)
+    float* W2 = W1 + ci * CO * 4;             // [CO][CO][4] = (w2 tap0, tap1, tap2, 0)
+    float* WB = W2 + CO * CO * 4;             // [ci][CO]     block shortcut (1x1 conv) | unused
+    float* xs = WB + ci * CO;                 // [ci][T+2], two zeros in front (causal padding)
+    float* h1 = xs + ci * TP;                 // [CO][T+2]
     const long long n = blockIdx.x;
+    for (int i = threadIdx.x; i < ci * CO; i += 256) {
+        const int k = i / CO, c = i - k * CO;
+        const float* w = p.w1 + (c * ci + k) * 3;
+        *reinterpret_cast<f32x4*>(W1 + i * 4) = f32x4{w[0], w[1], w[2], p.ws1 ? p.ws1[c * ci + k] : 0.0f};
+        WB[i] = p.wsb ? p.wsb[c * ci + k] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < CO * CO; i += 256) {
+        const int k = i / CO, c = i - k * CO;
+        const float* w = p.w2 + (c * CO + k) * 3;
+        *reinterpret_cast<f32x4*>(W2 + i * 4) = f32x4{w[0], w[1], w[2], 0.0f};
+    }
     for (int i = threadIdx.x; i < ci * TP; i += 256) {
         const int c = i / TP, t = i - c * TP - 2;
         float v = 0.0f;
         if (t >= 0) v = c < p.c1 ? p.src1[(n * p.c1 + c) * T + t] : p.src2[(n * p.c2 + (c - p.c1)) * T + t];
         xs[i] = v;
     }
-    for (int c = threadIdx.x; c < p.co; c += 256) {
+    for (int c = threadIdx.x; c < CO; c += 256) h1[c * TP] = h1[c * TP + 1] = 0.0f;
+    float tv[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
         float a = p.bt[c];
         for (int d = 0; d < p.d_h; ++d) a += p.wt[c * p.d_h + d] * p.temb[d];
         tv[c] = a;
-        h1[c * TP] = h1[c * TP + 1] = 0.0f;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < p.co * T; i += 256) {
-        const int c = i / T, t = i - c * T;
-        float a = p.b1[c];
+    for (int t = threadIdx.x; t < T; t += 256) {
+        float acc[CO], sk[CO], sb[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            acc[c] = p.b1[c];
+            sk[c] = p.ws1 ? p.bs1[c] : xs[c * TP + t + 2];
+            sb[c] = p.wsb ? p.bsb[c] : 0.0f;
+        }
+#pragma nounroll
         for (int k = 0; k < ci; ++k) {
-            const float* w = p.w1 + (c * ci + k) * 3;
-            const float* x = xs + k * TP + t;
-            a += w[0] * x[0] + w[1] * x[1] + w[2] * x[2];
+            const float x0 = xs[k * TP + t], x1 = xs[k * TP + t + 1], x2 = xs[k * TP + t + 2];
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(W1 + (k * CO + c) * 4);
+                acc[c] += w[0] * x0 + w[1] * x1 + w[2] * x2;
+                sk[c] += w[3] * x2;
+                sb[c] += WB[k * CO + c] * x2;
+            }
         }
-        float s;
-        if (p.ws1) {
-            s = p.bs1[c];
-            for (int k = 0; k < ci; ++k) s += p.ws1[c * ci + k] * xs[k * TP + t + 2];
-        } else {
-            s = xs[c * TP + t + 2];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            h1[c * TP + t + 2] = (acc[c] + sk[c]) + tv[c];
+            if (p.wsb) p.sc[(n * CO + c) * T + t] = sb[c];
         }
-        h1[c * TP + t + 2] = (a + s) + tv[c];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < p.co * T; i += 256) {
-        const int c = i / T, t = i - c * T;
-        float a = p.b2[c];
-        for (int k = 0; k < p.co; ++k) {
-            const float* w = p.w2 + (c * p.co + k) * 3;
-            const float* x = h1 + k * TP + t;
-            a += w[0] * x[0] + w[1] * x[1] + w[2] * x[2];
+    for (int t = threadIdx.x; t < T; t += 256) {
+        float acc[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c] = p.b2[c];
+#pragma nounroll
+        for (int k = 0; k < CO; ++k) {
+            const float x0 = h1[k * TP + t], x1 = h1[k * TP + t + 1], x2 = h1[k * TP + t + 2];
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(W2 + (k * CO + c) * 4);
+                acc[c] += w[0] * x0 + w[1] * x1 + w[2] * x2;
+            }
         }
-        h2[i] = a + h1[c * TP + t + 2];
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 256) {                 // LayerNorm([1, co]) over the channels of one time step
         float s = 0.0f;
-        for (int c = 0; c < p.co; ++c) s += h2[c * T + t];
-        const float mean = s / (float)p.co;
-        float q = 0.0f;
-        for (int c = 0; c < p.co; ++c) {
-            const float d = h2[c * T + t] - mean;
-            q += d * d;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            acc[c] += h1[c * TP + t + 2];
+            s += acc[c];
         }
-        const float rstd = 1.0f / sqrtf(q / (float)p.co + 1e-5f);
-        for (int c = 0; c < p.co; ++c) p.out[(n * p.co + c) * T + t] = (h2[c * T + t] - mean) * rstd * p.lnw[c] + p.lnb[c];
+        const float mean = s / (float)CO;                        // LayerNorm([1, co]) over the channels of this time step
+        float q = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            acc[c] -= mean;
+            q += acc[c] * acc[c];
+        }
+        const float rstd = 1.0f / sqrtf(q / (float)CO + 1e-5f);
+#pragma unroll
+        for (int c = 0; c < CO; ++c) p.out[(n * CO + c) * T + t] = acc[c] * rstd * p.lnw[c] + p.lnb[c];
     }
 }
 
@@ -357,10 +395,11 @@ namespace {
         if (int rc_ = (expr)) return rc_; \
     } while (0)
 
-int gemm(mpv_ctx* ctx, const float* X, long long ldx, const float* W, const float* bias, int K, int N, long long rows, float* Y, long long ldy, int relu = 0) {
+int gemm(mpv_ctx* ctx, const float* X, long long ldx, const float* W, const float* bias, int K, int N, long long rows, float* Y, long long ldy, int relu = 0,
+         const float* r1 = nullptr) {
     int KC = 64;
     if (K < 64) KC = (K + 15) & ~15;
-    GemmArgs a{X, ldx, W, bias, Y, ldy, rows, K, N, KC, relu};
+    GemmArgs a{X, ldx, W, bias, Y, ldy, rows, K, N, KC, relu, r1};
     const size_t lds = sizeof(float) * (size_t)(16 * GEMM_NT + 64) * (KC + 4);
     MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(stg_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((N + 16 * GEMM_NT - 1) / (16 * GEMM_NT)));
@@ -433,19 +472,33 @@ int forward(mpv_ctx* ctx, StgEngine& e, const float* xt, const float* xm, long l
             }
             if (cur_c + c2 != s.c_in) return mpv_fail(ctx, MPV_ESTATE, "DiffSTG: block input channels do not match the layout");
             const int co = s.c_out, C = Td * co;
-            TcnArgs a{cur, cur_c, src2, c2, s.r.w1, s.r.b1, s.r.ws1, s.r.bs1, s.r.wt, s.r.bt, temb, s.r.w2, s.r.b2, s.r.lnw, s.r.lnb, e.hn, co, s.T, d_h};
-            const size_t lds = sizeof(float) * ((size_t)s.c_in * (s.T + 2) + (size_t)co * (s.T + 2) + (size_t)co * s.T + co);
+            TcnArgs a{cur, cur_c, src2, c2, s.r.w1, s.r.b1, s.r.ws1, s.r.bs1, s.r.wt, s.r.bt, temb, s.r.w2, s.r.b2, s.r.lnw, s.r.lnb, e.hn, co, s.T, d_h,
+                      s.r.ws, s.r.bs, e.up};
+            const size_t lds = sizeof(float) * ((size_t)s.c_in * (s.T + 2) + (size_t)co * (s.T + 2) + (size_t)s.c_in * co * 5 + (size_t)co * co * 4);
             if (lds > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "DiffSTG: a node row does not fit the LDS (sequence too long)");
-            MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(stg_tcn_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(stg_tcn_ln_kernel, dim3((unsigned)N), dim3(256), lds, st, a);
+#define STG_TCN(CO_)                                                                                                                          \
+    do {                                                                                                                                      \
+        MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(stg_tcn_ln_kernel<CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(stg_tcn_ln_kernel<CO_>, dim3((unsigned)N), dim3(256), lds, st, a);                                                 \
+    } while (0)
+            switch (co) {
+                case 2: STG_TCN(2); break;
+                case 4: STG_TCN(4); break;
+                case 8: STG_TCN(8); break;
+                case 16: STG_TCN(16); break;
+                case 32: STG_TCN(32); break;
+                default: return mpv_fail(ctx, MPV_EINVAL, "DiffSTG: block channel counts must be 2, 4, 8, 16 or 32 (d_h times the channel multipliers)");
+            }
+#undef STG_TCN
             MPV_HIP_TRY(ctx, hipGetLastError());
             STG_TRY(gemm(ctx, e.hn, (long long)co * s.T, s.r.wdown, s.r.bdown, co * s.T, C, N, e.z, C));
             STG_TRY(gemm(ctx, e.z, C, s.r.wg, s.r.bg4, C, 4 * C, N, e.kqvs, 4 * C));
             hipLaunchKernelGGL(stg_gate_kernel, g1d(N * C), dim3(256), 0, st, e.kqvs, s.r.gbias, e.graph, e.graph + e.V + 1, e.V, C, N * C, e.sp);
             MPV_HIP_TRY(ctx, hipGetLastError());
-            STG_TRY(gemm(ctx, e.sp, C, s.r.wup, s.r.bup, C, co * s.T, N, e.up, (long long)co * s.T));
-            hipLaunchKernelGGL(stg_res_out_kernel, g1d(N * co * s.T), dim3(256), 0, st, e.up, cur, cur_c, src2, c2, s.r.ws, s.r.bs, co, s.T,
-                               N * co * s.T, out);
+            // up-sampling product with the block's shortcut added in its epilogue: the block input itself (identity) or the 1x1
+            // convolution the TCN kernel left in e.up
+            if (!s.r.ws && cur_c != co) return mpv_fail(ctx, MPV_ESTATE, "DiffSTG: identity shortcut with differing channel counts");
+            STG_TRY(gemm(ctx, e.sp, C, s.r.wup, s.r.bup, C, co * s.T, N, out, (long long)co * s.T, 0, s.r.ws ? e.up : cur));
         }
         MPV_HIP_TRY(ctx, hipGetLastError());
         cur = out;
