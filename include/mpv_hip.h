@@ -337,6 +337,21 @@ typedef struct mpv_biomass_desc {
 int mpv_biomass_simulate(mpv_ctx* ctx, const mpv_biomass_desc* desc, const int32_t* row_ptr, const int32_t* col_idx,
                          const float* x0, float* series_out);
 
+/* The same generator for all three network dynamics of the paper.  model: MPV_SDE_BIOMASS (p0 = r, p1 = k, p2 = d: the call above),
+ * MPV_SDE_SIS (p2 = d: dx = [-d x + eps(t) (1 - x) A x] dt + eta dW, dataset/spdata_sde_SIS_dynamic_gene.py:44-52),
+ * MPV_SDE_NEURONAL (p0 = tau, p1 = mu: dx = [-x + (1 - eps(t)) A sigmoid(tau (x - mu))] dt + eta dW, Wilson-Cowan,
+ * dataset/spdata_sde_neuronal_dynamic_gene.py:50-63).  Same graph / Philox / sub-sampling conventions. */
+#define MPV_SDE_BIOMASS 0
+#define MPV_SDE_SIS 1
+#define MPV_SDE_NEURONAL 2
+typedef struct mpv_sde_desc {
+    int32_t model, n_trajectories, nodes, ticks, burn_ticks, stride;
+    float p0, p1, p2, eta, dt, eps_start, eps_end;
+    uint64_t seed;
+} mpv_sde_desc;
+int mpv_network_sde_simulate(mpv_ctx* ctx, const mpv_sde_desc* desc, const int32_t* row_ptr, const int32_t* col_idx, const float* x0,
+                             float* series_out);
+
 /* Debug/validation helper: write the Philox normals mpv_nsdiff_sample would consume, in the
  * dense layout [n_chains][T][F] (chain-major), so a CPU checker can replay them. */
 int mpv_nsdiff_philox_normals(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out_dev);

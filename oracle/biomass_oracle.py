@@ -49,3 +49,42 @@ def simulate(adj: np.ndarray, x0: np.ndarray, ticks: int, burn_ticks: int, strid
         if i >= 0 and i % stride == 0:
             out[:, i // stride] = x
     return out
+
+
+def simulate_model(model: str, adj: np.ndarray, x0: np.ndarray, ticks: int, burn_ticks: int, stride: int, p0, p1, p2, eta, dt, eps_start, eps_end,
+                   seed: int) -> np.ndarray:
+    """mpv_network_sde_simulate, trajectory 0, operation by operation in float32: 'SIS' (p2 = d; reference
+    dataset/spdata_sde_SIS_dynamic_gene.py:44-52) and 'neuronal' (p0 = tau, p1 = mu; dataset/spdata_sde_neuronal_dynamic_gene.py:50-63).
+    UNPINNED against the reference simulators (torchsde absent), like `simulate`."""
+    if model == "biomass":
+        return simulate(adj, x0, ticks, burn_ticks, stride, p0, p1, p2, eta, dt, eps_start, eps_end, seed)
+    f = np.float32
+    V = adj.shape[0]
+    row_ptr, col = csr(adj)
+    total = burn_ticks + ticks
+    z = PH.normals(seed, 0, V, total, 1)[:, :, 0]
+    x = x0.astype(f).copy()
+    sig = lambda v: (f(1) / (f(1) + np.exp(-f(p0) * (v - f(p1)), dtype=f))).astype(f)
+    share = sig(x) if model == "neuronal" else x.copy()
+    out = np.empty((V, (ticks + stride - 1) // stride), dtype=f)
+    eps_step = f((f(eps_end) - f(eps_start)) / f(ticks - 1)) if ticks > 1 else f(0)
+    noise_scale = f(f(eta) * np.sqrt(f(dt)))
+    d, dt = f(p2), f(dt)
+    for t in range(total):
+        i = t - burn_ticks
+        eps = f(eps_start) if i < 0 else f(f(eps_start) + f(f(i) * eps_step))
+        ax = np.zeros(V, dtype=f)
+        for n in range(V):
+            s = f(0)
+            for j in range(row_ptr[n], row_ptr[n + 1]):
+                s = f(s + share[col[j]])
+            ax[n] = s
+        if model == "SIS":
+            drift = f(-d) * x + (eps * (f(1) - x)) * ax
+        else:
+            drift = -x + (f(1) - eps) * ax
+        x = (x + drift * dt) + noise_scale * z[:, t]
+        share = sig(x) if model == "neuronal" else x.copy()
+        if i >= 0 and i % stride == 0:
+            out[:, i // stride] = x
+    return out

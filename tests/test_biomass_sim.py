@@ -57,3 +57,28 @@ def test_full_size_trajectory_is_usable_by_the_path():
     with pytest.raises(MpvError):
         ctx.biomass_simulate(torch.zeros(3, dtype=torch.int32).cuda(), torch.zeros(1, dtype=torch.int32).cuda(),
                              torch.zeros(1, 5).cuda(), 10, 0, 1, 0.7, 10.0, 0.5, 0.005, 0.1, 0.0, 1.0, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,par", [("SIS", dict(p0=0.0, p1=0.0, p2=0.5, eta=1e-4, eps_start=0.2, eps_end=0.0)),
+                                       ("neuronal", dict(p0=2.0, p1=1.5, p2=0.0, eta=0.01, eps_start=0.0, eps_end=0.9))])
+def test_sis_and_wilson_cowan_generators_match_float32_restatement(model, par):
+    """mpv_network_sde_simulate for the other two dynamics of the paper (BASELINE configs[2] / [3] inputs), tick by tick."""
+    from mpv_amd import _native, synthetic
+    ctx = _native.Context(torch.device("cuda", 0))
+    nodes, ticks, burn, stride = 40, 500, 30, 3
+    adj = synthetic.ba_graph(nodes, m=3, seed=5) if model == "SIS" else synthetic.er_graph(nodes, p=0.1, seed=5)
+    rp, ci = synthetic.adjacency_csr(adj)
+    rng = np.random.default_rng(5)
+    x0 = (rng.uniform(0.2, 0.8, nodes) if model == "SIS" else rng.uniform(2.0, 6.0, nodes)).astype(np.float32)
+    got = ctx.network_sde_simulate(model, torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(x0).cuda()[None],
+                                   ticks, burn, stride, dt=0.1, seed=31, **par)
+    want = BO.simulate_model(model, adj, x0, ticks, burn, stride, dt=0.1, seed=31, **par)
+    err = np.abs(got[0, :, :, 0].cpu().numpy() - want).max() / np.abs(want).max()
+    print("%s sim: max rel err %.3e, final mean %.4f" % (model, err, float(want[:, -1].mean())))
+    assert tuple(got.shape) == (1, nodes, (ticks + stride - 1) // stride, 1) and err < 1e-4
+    bio = ctx.network_sde_simulate("biomass", torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(x0).cuda()[None],
+                                   64, 0, 1, 0.7, 10.0, 0.5, 0.005, 0.1, 0.0, 1.0, 9)
+    old = ctx.biomass_simulate(torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(x0).cuda()[None], 64, 0, 1,
+                               0.7, 10.0, 0.5, 0.005, 0.1, 0.0, 1.0, 9)
+    assert torch.equal(bio, old)

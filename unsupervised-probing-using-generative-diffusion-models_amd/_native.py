@@ -26,7 +26,7 @@ EXPORTS = (
     "mpv_nsdiff_load", "mpv_nsdiff_sample", "mpv_chain_stats", "mpv_nsdiff_philox_normals", "mpv_sigma_load", "mpv_sigma_head",
     "mpv_reduce", "mpv_chain_timing", "mpv_chain_timing_enable", "mpv_tmdm_load", "mpv_tmdm_sample",
     "mpv_stg_load", "mpv_stg_set_graph", "mpv_stg_forward", "mpv_stg_sample",
-    "mpv_biomass_simulate", "mpv_dts_load", "mpv_dts_forward", "mpv_dts_vjp", "mpv_dts_debug_tensor", "mpv_dts_sample",
+    "mpv_biomass_simulate", "mpv_network_sde_simulate", "mpv_dts_load", "mpv_dts_forward", "mpv_dts_vjp", "mpv_dts_debug_tensor", "mpv_dts_sample",
 )
 
 
@@ -98,6 +98,13 @@ class BiomassDesc(C.Structure):
                 ("dt", C.c_float), ("eps_start", C.c_float), ("eps_end", C.c_float), ("seed", C.c_uint64)]
 
 
+class SdeDesc(C.Structure):
+    _fields_ = [("model", C.c_int32), ("n_trajectories", C.c_int32), ("nodes", C.c_int32), ("ticks", C.c_int32), ("burn_ticks", C.c_int32),
+                ("stride", C.c_int32), ("p0", C.c_float), ("p1", C.c_float), ("p2", C.c_float), ("eta", C.c_float), ("dt", C.c_float),
+                ("eps_start", C.c_float), ("eps_end", C.c_float), ("seed", C.c_uint64)]
+
+
+SDE_MODELS = {"biomass": 0, "SIS": 1, "neuronal": 2}
 _lib = None
 
 
@@ -125,6 +132,7 @@ def load_library():
         "mpv_tmdm_load": (C.c_int, [vp, C.POINTER(NsdiffDesc), C.POINTER(NsdiffWeights), _F]),
         "mpv_tmdm_sample": (C.c_int, [vp, C.POINTER(SampleShape), vp, vp, C.POINTER(SampleOut)]),
         "mpv_biomass_simulate": (C.c_int, [vp, C.POINTER(BiomassDesc), vp, vp, vp, vp]),
+        "mpv_network_sde_simulate": (C.c_int, [vp, C.POINTER(SdeDesc), vp, vp, vp, vp]),
         "mpv_nsdiff_philox_normals": (C.c_int, [vp, u64, u64, i64, vp]),
         "mpv_chain_stats": (C.c_int, [vp, C.POINTER(u64), C.POINTER(u64), C.c_int]),
         "mpv_sigma_load": (C.c_int, [vp, C.POINTER(SigmaDesc), C.POINTER(SigmaWeights)]),
@@ -554,6 +562,27 @@ class Context:
         self._check(self.lib.mpv_biomass_simulate(self._h, C.byref(desc), C.c_void_p(row_ptr.data_ptr()),
                                                   C.c_void_p(col_idx.data_ptr()), _dev_ptr(x0, self.device, "x0"),
                                                   _dev_ptr(out, self.device, "series_out")), "mpv_biomass_simulate")
+        return out
+
+    def network_sde_simulate(self, model: str, row_ptr: torch.Tensor, col_idx: torch.Tensor, x0: torch.Tensor, ticks: int, burn_ticks: int,
+                             stride: int, p0: float, p1: float, p2: float, eta: float, dt: float, eps_start: float, eps_end: float,
+                             seed: int) -> torch.Tensor:
+        """Euler-Maruyama of the 'biomass' (p0 = r, p1 = k, p2 = d), 'SIS' (p2 = d) or 'neuronal' (p0 = tau, p1 = mu) network dynamics:
+        CSR graph (int32, on device), x0 [n_traj, V] -> sub-sampled trajectories [n_traj, V, ceil(ticks/stride), 1]."""
+        if model not in SDE_MODELS:
+            raise MpvError("model must be one of {}".format(sorted(SDE_MODELS)))
+        for name, t in (("row_ptr", row_ptr), ("col_idx", col_idx)):
+            if t.device != self.device or t.dtype != torch.int32 or not t.is_contiguous():
+                raise MpvError("{} must be a contiguous int32 tensor on {}".format(name, self.device))
+        n_traj, V = x0.shape
+        if row_ptr.numel() != V + 1:
+            raise MpvError("row_ptr has {} entries, expected nodes + 1 = {}".format(row_ptr.numel(), V + 1))
+        out = torch.empty((n_traj, V, (ticks + stride - 1) // stride, 1), device=self.device, dtype=torch.float32)
+        desc = SdeDesc(SDE_MODELS[model], n_traj, V, ticks, burn_ticks, stride, p0, p1, p2, eta, dt, eps_start, eps_end, seed & (2 ** 64 - 1))
+        self._bind_stream()
+        self._check(self.lib.mpv_network_sde_simulate(self._h, C.byref(desc), C.c_void_p(row_ptr.data_ptr()), C.c_void_p(col_idx.data_ptr()),
+                                                      _dev_ptr(x0, self.device, "x0"), _dev_ptr(out, self.device, "series_out")),
+                    "mpv_network_sde_simulate")
         return out
 
     def chain_stats(self, reset: bool = False):

@@ -42,10 +42,12 @@ def main_c3(args, log):
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
     cfg = C3
-    log("c3: generating the SIS trajectory (host Euler-Maruyama)")
-    rec = synthetic.sis_trajectory(cfg["nodes"], cfg["ticks"], seed=2000)
-    full = H.normalize_time_series(rec["ys_dynamic"], dynamic_type="SIS")
-    sampled, _ = H.sample_time_series(full, rec["ts_dynamic"], cfg["sampling_t"])
+    from mpv_amd import _native
+    gen = _native.Context(device)
+    sampled, _ = synthetic.sis_trajectory_device(gen, cfg["nodes"], cfg["ticks"], seed=2000, sampling_stride=H.sampling_interval_from_t(cfg["sampling_t"]))
+    sampled = sampled.cpu()
+    gen.close()
+    log("c3: SIS trajectory generated on device: %s" % (tuple(sampled.shape),))
     n_total = H.sliding_window_count(sampled.shape[1], cfg["windows"], cfg["window_step"])
     wps = max(1, int(getattr(args, "dts_windows", 1)))
     net = dict(device=device, scaler_type="StandardScaler", task_model="DiffusionTS", dataset_nf=cfg["nf"], windows=cfg["windows"],

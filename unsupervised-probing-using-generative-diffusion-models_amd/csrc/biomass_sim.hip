@@ -1,8 +1,11 @@
-// Harvested-biomass network SDE, Euler-Maruyama on device, for gfx950 (the step before the path).
+// Network SDEs of the paper's three dynamics, Euler-Maruyama on device, for gfx950 (the step before the path).
 //
-//   dx_i = [ r x_i (1 - x_i/k) - eps(t) x_i^2/(x_i^2+1) + d sum_j A_ij (x_j - x_i) ] dt + eta dW_i ,  x clamped at 0
-//   (reference dataset/spdata_sde_biomass_dynamic_gene.py:53-68: drift f(), noise g(); parameters as in
-//   paper_figures/common.py:41), eps(t) a linear ramp over the recorded ticks after a burn-in at eps_start.
+//   biomass  dx_i = [ r x_i (1 - x_i/k) - eps(t) x_i^2/(x_i^2+1) + d sum_j A_ij (x_j - x_i) ] dt + eta dW_i ,  x clamped at 0
+//            (reference dataset/spdata_sde_biomass_dynamic_gene.py:53-68; parameters as in paper_figures/common.py:41)
+//   SIS      dx_i = [ -d x_i + eps(t) (1 - x_i) sum_j A_ij x_j ] dt + eta dW_i      (dataset/spdata_sde_SIS_dynamic_gene.py:44-52)
+//   neuronal dx_i = [ -x_i + (1 - eps(t)) sum_j A_ij sigmoid(tau (x_j - mu)) ] dt + eta dW_i   (Wilson-Cowan,
+//            dataset/spdata_sde_neuronal_dynamic_gene.py:50-63)
+//   eps(t) a linear ramp over the recorded ticks after a burn-in at eps_start.
 //
 // Time is inherently serial, the network is small (V <= 1024): ONE workgroup per trajectory keeps the state in
 // LDS (double buffered, one barrier per tick), a thread owns up to 4 nodes, the graph is CSR.  Normals are the
@@ -23,10 +26,12 @@ struct SimArgs {
     const float* x0;        // [n_traj][V]
     float* out;             // [n_traj][V][L]
     int V, ticks, burn, stride, L;
-    float r, k, d, dt, eps0, eps_step, noise_scale;
+    float r, k, d, dt, eps0, eps_step, noise_scale;     // SIS: d; neuronal: r = tau, k = mu
     unsigned seed_lo, seed_hi;
 };
 
+// MODEL 0 biomass, 1 SIS, 2 neuronal (Wilson-Cowan)
+template <int MODEL>
 __global__ __launch_bounds__(SIM_THREADS) void biomass_em_kernel(const SimArgs p) {
     extern __shared__ float xs[];                             // [2][V]
     const int traj = blockIdx.x;
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(SIM_THREADS) void biomass_em_kernel(const SimArgs p
         beg[q] = live ? p.row_ptr[node[q]] : 0;
         end[q] = live ? p.row_ptr[node[q] + 1] : 0;
         x[q] = live ? p.x0[(long long)traj * p.V + node[q]] : 0.0f;
-        if (live) xs[node[q]] = fmaxf(x[q], 0.0f);
+        if (live) xs[node[q]] = MODEL == 0 ? fmaxf(x[q], 0.0f) : (MODEL == 2 ? 1.0f / (1.0f + expf(-p.r * (x[q] - p.k))) : x[q]);
     }
     __syncthreads();
     const int total = p.burn + p.ticks;
@@ -55,16 +60,24 @@ __global__ __launch_bounds__(SIM_THREADS) void biomass_em_kernel(const SimArgs p
                     chain::philox_normals((unsigned long long)traj * p.V + node[q], (unsigned)(t >> 2), p.seed_lo, p.seed_hi, 0u, zc[q]);
                 const int e = t & 3;
                 const float z = e == 0 ? zc[q][0] : (e == 1 ? zc[q][1] : (e == 2 ? zc[q][2] : zc[q][3]));
-                const float xc = cur[node[q]];                // already clamped at 0
+                // cur[] holds what the neighbours contribute: the clamped state (biomass), the state (SIS) or its sigmoid (neuronal)
+                const float xc = cur[node[q]];
                 float ax = 0.0f;
                 for (int j = beg[q]; j < end[q]; ++j) ax += cur[p.col_idx[j]];
                 {
 #pragma clang fp contract(off)
-                    const float deg = (float)(end[q] - beg[q]);
-                    const float drift = p.r * xc * (1.0f - xc / p.k) - eps * xc * xc / (xc * xc + 1.0f) + p.d * (ax - deg * xc);
+                    float drift;
+                    if (MODEL == 0) {
+                        const float deg = (float)(end[q] - beg[q]);
+                        drift = p.r * xc * (1.0f - xc / p.k) - eps * xc * xc / (xc * xc + 1.0f) + p.d * (ax - deg * xc);
+                    } else if (MODEL == 1) {
+                        drift = -p.d * x[q] + eps * (1.0f - x[q]) * ax;
+                    } else {
+                        drift = -x[q] + (1.0f - eps) * ax;
+                    }
                     x[q] = x[q] + drift * p.dt + p.noise_scale * z;
                 }
-                nxt[node[q]] = fmaxf(x[q], 0.0f);
+                nxt[node[q]] = MODEL == 0 ? fmaxf(x[q], 0.0f) : (MODEL == 2 ? 1.0f / (1.0f + expf(-p.r * (x[q] - p.k))) : x[q]);
                 if (i >= 0 && (i % p.stride) == 0) p.out[((long long)traj * p.V + node[q]) * p.L + i / p.stride] = x[q];
             }
         }
@@ -84,7 +97,28 @@ int launch_biomass_sim(mpv_ctx* ctx, const mpv_biomass_desc& d, const int32_t* r
     a.eps_step = d.ticks > 1 ? (d.eps_end - d.eps_start) / (float)(d.ticks - 1) : 0.0f;
     a.noise_scale = d.eta * sqrtf(d.dt);
     a.seed_lo = (unsigned)d.seed; a.seed_hi = (unsigned)(d.seed >> 32);
-    hipLaunchKernelGGL(biomass_em_kernel, dim3(d.n_trajectories), dim3(SIM_THREADS), 2 * sizeof(float) * d.nodes, ctx->stream, a);
+    hipLaunchKernelGGL(biomass_em_kernel<0>, dim3(d.n_trajectories), dim3(SIM_THREADS), 2 * sizeof(float) * d.nodes, ctx->stream, a);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+int launch_network_sde(mpv_ctx* ctx, const mpv_sde_desc& d, const int32_t* row_ptr, const int32_t* col_idx, const float* x0, float* series_out) {
+    SimArgs a{};
+    a.row_ptr = row_ptr; a.col_idx = col_idx; a.x0 = x0; a.out = series_out;
+    a.V = d.nodes; a.ticks = d.ticks; a.burn = d.burn_ticks; a.stride = d.stride;
+    a.L = (d.ticks + d.stride - 1) / d.stride;
+    a.r = d.p0; a.k = d.p1; a.d = d.p2; a.dt = d.dt; a.eps0 = d.eps_start;
+    a.eps_step = d.ticks > 1 ? (d.eps_end - d.eps_start) / (float)(d.ticks - 1) : 0.0f;
+    a.noise_scale = d.eta * sqrtf(d.dt);
+    a.seed_lo = (unsigned)d.seed; a.seed_hi = (unsigned)(d.seed >> 32);
+    const dim3 grid(d.n_trajectories), block(SIM_THREADS);
+    const size_t lds = 2 * sizeof(float) * d.nodes;
+    switch (d.model) {
+        case MPV_SDE_BIOMASS: hipLaunchKernelGGL(biomass_em_kernel<0>, grid, block, lds, ctx->stream, a); break;
+        case MPV_SDE_SIS: hipLaunchKernelGGL(biomass_em_kernel<1>, grid, block, lds, ctx->stream, a); break;
+        case MPV_SDE_NEURONAL: hipLaunchKernelGGL(biomass_em_kernel<2>, grid, block, lds, ctx->stream, a); break;
+        default: return mpv_fail(ctx, MPV_EINVAL, "mpv_network_sde_simulate: unknown model");
+    }
     MPV_HIP_TRY(ctx, hipGetLastError());
     return MPV_OK;
 }

@@ -343,6 +343,16 @@ int mpv_biomass_simulate(mpv_ctx* ctx, const mpv_biomass_desc* d, const int32_t*
     return launch_biomass_sim(ctx, *d, row_ptr, col_idx, x0, series_out);
 }
 
+int mpv_network_sde_simulate(mpv_ctx* ctx, const mpv_sde_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const float* x0, float* series_out) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_network_sde_simulate: ctx is NULL");
+    if (!d || !row_ptr || !x0 || !series_out) return mpv_fail(ctx, MPV_EINVAL, "mpv_network_sde_simulate: NULL argument");
+    if (d->n_trajectories < 1 || d->nodes < 1 || d->nodes > 1024 || d->ticks < 1 || d->burn_ticks < 0 || d->stride < 1 || !(d->dt > 0.0f))
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_network_sde_simulate: need n_trajectories >= 1, 1 <= nodes <= 1024, ticks >= 1, burn_ticks >= 0, stride >= 1, dt > 0");
+    if (d->model == MPV_SDE_BIOMASS && !(d->p1 != 0.0f)) return mpv_fail(ctx, MPV_EINVAL, "mpv_network_sde_simulate: biomass needs k != 0");
+    DeviceGuard g(ctx->device);
+    return launch_network_sde(ctx, *d, row_ptr, col_idx, x0, series_out);
+}
+
 int mpv_chain_stats(mpv_ctx* ctx, uint64_t* tile_steps, uint64_t* safe_steps, int reset) {
     if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_chain_stats: ctx is NULL");
     DeviceGuard g(ctx->device);

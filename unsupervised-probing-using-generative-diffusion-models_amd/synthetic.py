@@ -162,3 +162,25 @@ def neuronal_trajectory(nodes: int = 500, ticks: int = 100_000, seed: int = 0, t
                                eps_start, eps_end, rng)
     return {"ys_dynamic": torch.from_numpy(ys), "ts_dynamic": torch.arange(ticks, dtype=torch.float32) * dt,
             "tp_values": torch.from_numpy(ramp.astype(np.float32))}
+
+
+def sis_trajectory_device(ctx, nodes: int = 100, ticks: int = 10_000, seed: int = 0, sampling_stride: int = 1, d: float = 0.5, eta: float = 1e-4,
+                          dt: float = 0.1, burn_ticks: int = 500, eps_start: float = 0.2, eps_end: float = 0.0, m: int = 3):
+    """`sis_trajectory` integrated by the HIP kernel (csrc/biomass_sim.hip, model SIS) -> (series [V, L, 1] on ctx.device, time stamps)."""
+    row_ptr, col_idx = adjacency_csr(ba_graph(nodes, m=m, seed=seed))
+    x0 = np.random.default_rng(seed).uniform(0.2, 0.8, nodes).astype(np.float32)
+    series = ctx.network_sde_simulate("SIS", torch.from_numpy(row_ptr).to(ctx.device), torch.from_numpy(col_idx).to(ctx.device),
+                                      torch.from_numpy(x0).to(ctx.device).unsqueeze(0), ticks, burn_ticks, sampling_stride, 0.0, 0.0, d, eta, dt,
+                                      eps_start, eps_end, seed)
+    return series[0], (np.arange(ticks, dtype=np.float32) * np.float32(dt))[::sampling_stride]
+
+
+def neuronal_trajectory_device(ctx, nodes: int = 500, ticks: int = 100_000, seed: int = 0, sampling_stride: int = 1, tau: float = 2.0, mu: float = 1.5,
+                               eta: float = 0.01, dt: float = 0.1, burn_ticks: int = 500, eps_start: float = 0.0, eps_end: float = 0.9, p: float = 0.02):
+    """`neuronal_trajectory` (Wilson-Cowan on an Erdos-Renyi graph) integrated by the HIP kernel."""
+    row_ptr, col_idx = adjacency_csr(er_graph(nodes, p=p, seed=seed))
+    x0 = np.random.default_rng(seed).uniform(2.0, 6.0, nodes).astype(np.float32)
+    series = ctx.network_sde_simulate("neuronal", torch.from_numpy(row_ptr).to(ctx.device), torch.from_numpy(col_idx).to(ctx.device),
+                                      torch.from_numpy(x0).to(ctx.device).unsqueeze(0), ticks, burn_ticks, sampling_stride, tau, mu, 0.0, eta, dt,
+                                      eps_start, eps_end, seed)
+    return series[0], (np.arange(ticks, dtype=np.float32) * np.float32(dt))[::sampling_stride]
