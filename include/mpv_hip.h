@@ -248,6 +248,7 @@ typedef struct {
     int32_t chunk;         /* par = min(parallel_sample, n_z_samples); S % par == 0                           */
     int32_t n_pairs;       /* rows of `plan` = sampling_timesteps                                             */
     float infill_coef;     /* model_kwargs["coef"] (:87)                                                      */
+    int32_t rows_per_pass; /* sequences run through the network together (0 = library default, 4096): results do not depend on it */
     uint64_t seed;         /* Philox key when noise == NULL                                                   */
 } mpv_dts_sample_shape;
 

@@ -144,6 +144,14 @@ def test_evaluation_step_torch_cpu_stream_and_philox_mode():
     b, _ = m.evaluation_step(T(z["batch_small"]))
     c, _ = m.evaluation_step(T(z["batch_small"]))
     assert torch.equal(a, b) and not torch.equal(a, c) and bool(torch.isfinite(a).all())
+    import os
+    os.environ["MPV_DTS_ROWS"] = "2"                           # the batch in row blocks of 2 sequences: same numbers (Philox by position)
+    try:
+        torch.manual_seed(5)
+        d, _ = m.evaluation_step(T(z["batch_small"]))
+    finally:
+        del os.environ["MPV_DTS_ROWS"]
+    assert torch.equal(a, d)
     hist = torch.stack([T(z["batch_small"]), T(z["batch_small"]) * 0.5 + 0.1]).to(dev())           # [W=2, V, windows, F]
     m2, _ = build("small", noise_source="torch_cpu")
     torch.manual_seed(9)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Where do the VGPR spills of the split-f16 chain kernel live?  Compiles csrc/nsdiff_chain_f16.hip with -save-temps, finds the
+largest basic block of every nsdiff_chain_f16_kernel instantiation (the reverse-step body) and counts scratch_* instructions in it
+and in the whole kernel.  Exit code 1 if any instantiation has a scratch access inside its step body.
+
+    python tools/check_spills.py
+"""
+import re
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+PKG = ROOT / "unsupervised-probing-using-generative-diffusion-models_amd"
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-I", str(ROOT / "include"),
+               "-I", str(PKG / "csrc"), "-c", str(PKG / "csrc" / "nsdiff_chain_f16.hip"), "-o", tmp + "/f16.o", "-save-temps"]
+        subprocess.run(cmd, cwd=tmp, check=True, capture_output=True)
+        asm = next(Path(tmp).glob("*gfx950.s")).read_text()
+    bad = 0
+    for m in re.finditer(r"^(_ZN\S*nsdiff_chain_f16_kernel\S*):", asm, re.M):
+        name = m.group(1)
+        body = asm[m.end(): asm.index(".Lfunc_end", m.end())].split("\n")
+        blocks, cur = {}, None
+        for ln in body:
+            lab = re.match(r"^(\.LBB\d+_\d+):", ln)
+            if lab:
+                cur = lab.group(1)
+                blocks[cur] = [0, 0]
+            elif cur and ln.startswith("\t") and not ln.startswith(("\t.", "\t;")):
+                blocks[cur][0] += 1
+                blocks[cur][1] += "scratch_" in ln
+        hot = max(blocks, key=lambda k: blocks[k][0])
+        total = sum(v[1] for v in blocks.values())
+        tmpl = re.search(r"kernelILi(\d)ELb([01])ELi(\d)ELb([01])E", name)
+        demangled = "nsdiff_chain_f16_kernel<F=%s, philox=%s, products=%s, NORM=%s>" % tmpl.groups() if tmpl else name
+        print("%-70s step body %5d instructions, %2d scratch accesses; whole kernel %3d" % (demangled[-70:], blocks[hot][0], blocks[hot][1], total))
+        bad += blocks[hot][1] > 0 and "<F=1," in demangled
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

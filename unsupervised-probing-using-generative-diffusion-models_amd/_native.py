@@ -61,7 +61,7 @@ class DtsDesc(C.Structure):
 
 class DtsSampleShape(C.Structure):
     _fields_ = [("n_windows", C.c_int32), ("nodes", C.c_int32), ("windows", C.c_int32), ("n_samples", C.c_int32), ("chunk", C.c_int32),
-                ("n_pairs", C.c_int32), ("infill_coef", C.c_float), ("seed", C.c_uint64)]
+                ("n_pairs", C.c_int32), ("infill_coef", C.c_float), ("rows_per_pass", C.c_int32), ("seed", C.c_uint64)]
 
 
 DTS_PLAN_COLS = 10
@@ -406,7 +406,7 @@ class Context:
         return out
 
     def dts_sample(self, history: torch.Tensor, plan: torch.Tensor, n_samples: int, chunk: int, infill_coef: float,
-                   noise: Optional[torch.Tensor] = None, seed: int = 0) -> torch.Tensor:
+                   noise: Optional[torch.Tensor] = None, seed: int = 0, rows_per_pass: int = 0) -> torch.Tensor:
         """history [W, V, windows, F] on device, plan [n_pairs, 10] (host) -> samples [W, V, pred_len, F, S] on device."""
         if self.dts is None:
             raise MpvError("DiffusionTS weights not loaded")
@@ -423,7 +423,7 @@ class Context:
             if noise.numel() != need:
                 raise MpvError("noise has {} elements, the draw order needs {}".format(noise.numel(), need))
         out = torch.empty((W, V, L - windows, F, n_samples), device=self.device, dtype=torch.float32)
-        shape = DtsSampleShape(W, V, windows, n_samples, chunk, plan.shape[0], float(infill_coef), seed & (2 ** 64 - 1))
+        shape = DtsSampleShape(W, V, windows, n_samples, chunk, plan.shape[0], float(infill_coef), int(rows_per_pass), seed & (2 ** 64 - 1))
         self._bind_stream()
         self._check(self.lib.mpv_dts_sample(self._h, C.byref(shape), _dev_ptr(history, self.device, "history"), _fptr(plan),
                                             _dev_ptr(noise, self.device, "noise"), _dev_ptr(out, self.device, "samples")), "mpv_dts_sample")

@@ -54,7 +54,8 @@ struct ChainArgs {
     double* acc;                 // global [W][F][2] fp64: sum over rows of var_row, sum over rows of mean_row (zeroed by the launcher)
     const float *inv_std, *inv_mean;   // [F] inverse scaling inside the summary, or NULL
     int seg;                     // lanes of a tile that share a (b,o,f) row: min(S, 32), a power of two
-    int sub;                     // consecutive tiles that make up one row: max(1, S / 32); a claim covers `sub` tiles
+    int sub;                     // consecutive tiles that make up one row: max(1, S / 32)
+    int claim;                   // tiles per work-queue claim: a multiple of `sub` (8 by default)
     int acc_windows;             // windows of this launch (rows of the LDS accumulator table)
     long long chain_base;        // added to the chain index in the Philox key (launches over window groups)
     unsigned long long* stats;   // [0] += steps re-run through chain_step_safe

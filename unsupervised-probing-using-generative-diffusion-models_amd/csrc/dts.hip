@@ -3,6 +3,7 @@
 // mpv_dts_* entry points of include/mpv_hip.h.  The kernels are in dts_kernels.h (MFMA) and dts_small.h (VALU).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "dts_small.h"
@@ -576,10 +577,17 @@ int mpv_dts_sample(mpv_ctx* ctx, const mpv_dts_sample_shape* s, const float* his
     const int par = s->chunk, V = s->nodes, W = s->n_windows;
     const long long rows = (long long)W * par * V;                       // sequences per chunk pass
     if (rows > 0x7fffffffLL / std::max(L, 1)) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_sample: batch too large for one call");
-    const int B = (int)rows;
-    DTS_TRY(carve(ctx, e, B));
+    // Sequences are independent, so a batch larger than the workspace budget runs in blocks of rows (results do not depend on the
+    // block size: Philox is keyed by position).  Measured on BASELINE configs[2] (3200 sequences): blocks of 3200 / 1600 / 800 /
+    // 400 / 200 rows take 14.9 / 15.3 / 16.6 / 20.4 / 28.9 s per window -- smaller blocks do NOT buy Infinity-Cache residency of the
+    // per-layer activations, they only add launches, so the default keeps a whole evaluation_step chunk together (35 KB per token).
+    long long blk = s->rows_per_pass > 0 ? s->rows_per_pass : 4096;
+    if (const char* env = std::getenv("MPV_DTS_ROWS")) blk = std::max(1, std::atoi(env));
+    if ((L * F) % 4) blk = (blk + 3) & ~3LL;                             // Philox blocks of four elements must not straddle row blocks
+    blk = std::min(blk, rows);
+    DTS_TRY(carve(ctx, e, (int)blk));
     hipStream_t st = ctx->stream;
-    const long long n = rows * L * F;
+    const long long n_full = rows * L * F;
     const int Bw = par * V;                                              // batch of ONE evaluation_step chunk: the loss normalisers
     const float inv_nmask = 1.0f / (float)((long long)Bw * s->windows * F);
     const float coef_over_b = s->infill_coef / (float)Bw;
@@ -589,53 +597,57 @@ int mpv_dts_sample(mpv_ctx* ctx, const mpv_dts_sample_shape* s, const float* his
     long long draws_per_chunk = 1;
     for (int pi = 0; pi < s->n_pairs; ++pi)
         if (plan[pi * MPV_DTS_PLAN_COLS + 1] >= 0.0f) draws_per_chunk += 2 + (long long)plan[pi * MPV_DTS_PLAN_COLS + 6];
-    hipLaunchKernelGGL(dts_build_target_kernel, g1d(n), dim3(256), 0, st, history, V, par, L, F, s->windows, n, e.target);
-    MPV_HIP_TRY(ctx, hipGetLastError());
-    for (int c = 0; c < s->n_samples / par; ++c) {
-        long long draw = (long long)c * draws_per_chunk;
-        unsigned stream_id = (unsigned)c * 65536u;
-        auto next_noise = [&](bool used, float* dst) -> int {            // consume one draw of the reference's stream
-            if (noise) {
-                if (used) MPV_HIP_TRY(ctx, hipMemcpyAsync(dst, noise + draw * n, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
-            } else if (used) {
-                hipLaunchKernelGGL(dts_philox_kernel, g1d((n + 3) / 4), dim3(256), 0, st, seed_lo, seed_hi, stream_id, n, dst);
+    for (long long r0 = 0; r0 < rows; r0 += blk) {
+        const int B = (int)std::min(blk, rows - r0);
+        const long long n = (long long)B * L * F, e0 = r0 * L * F;
+        hipLaunchKernelGGL(dts_build_target_kernel, g1d(n), dim3(256), 0, st, history, V, par, L, F, s->windows, r0, n, e.target);
+        MPV_HIP_TRY(ctx, hipGetLastError());
+        for (int c = 0; c < s->n_samples / par; ++c) {
+            long long draw = (long long)c * draws_per_chunk;
+            unsigned stream_id = (unsigned)c * 65536u;
+            auto next_noise = [&](bool used, float* dst) -> int {        // consume one draw of the reference's stream
+                if (noise) {
+                    if (used) MPV_HIP_TRY(ctx, hipMemcpyAsync(dst, noise + draw * n_full + e0, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+                } else if (used) {
+                    hipLaunchKernelGGL(dts_philox_kernel, g1d((n + 3) / 4), dim3(256), 0, st, seed_lo, seed_hi, stream_id, e0 / 4, n, dst);
+                    MPV_HIP_TRY(ctx, hipGetLastError());
+                }
+                ++draw;
+                ++stream_id;
+                return MPV_OK;
+            };
+            DTS_TRY(next_noise(true, e.img));                            // img = randn(shape), :285
+            for (int pi = 0; pi < s->n_pairs; ++pi) {
+                const float* pr = plan + pi * MPV_DTS_PLAN_COLS;
+                const int time = (int)pr[0];
+                const bool last = pr[1] < 0.0f;
+                const PairCoef kc{pr[2], pr[3], pr[4], pr[5], pr[8], pr[9]};
+                if (time < 0 || time >= e.d.timesteps) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_sample: plan row with a time outside [0, timesteps)");
+                DTS_TRY(forward(ctx, e, e.img, B, time, false));
+                hipLaunchKernelGGL(dts_predict_kernel, g1d(n), dim3(256), 0, st, e.img, e.trend, e.season, kc, last ? 1 : 0, n, e.xstart, e.pmean);
+                MPV_HIP_TRY(ctx, hipGetLastError());
+                if (last) break;
+                DTS_TRY(next_noise(false, nullptr));                     // `noise` of :300, multiplied by sigma = 0
+                // img = pred_mean; Langevin refinement of the whole tensor (:359-407)
+                MPV_HIP_TRY(ctx, hipMemcpyAsync(e.img, e.pmean, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+                const int K = (int)pr[6];
+                for (int it = 0; it < K; ++it) {
+                    DTS_TRY(forward(ctx, e, e.img, B, time, true));
+                    hipLaunchKernelGGL(dts_infill_grad_kernel, g1d(n), dim3(256), 0, st, e.trend, e.season, e.target, L, F, s->windows, inv_nmask, n, e.gout);
+                    MPV_HIP_TRY(ctx, hipGetLastError());
+                    DTS_TRY(backward(ctx, e, e.gout, e.gx, B, time));
+                    hipLaunchKernelGGL(dts_langevin_step_kernel, g1d(n), dim3(256), 0, st, e.gx, e.pmean, coef_over_b, pr[7], n, e.img);
+                    MPV_HIP_TRY(ctx, hipGetLastError());
+                    DTS_TRY(next_noise(false, nullptr));                 // epsilon of :403, multiplied by coef_ = 0
+                }
+                DTS_TRY(next_noise(true, e.noise));                      // q_sample's noise, :305
+                hipLaunchKernelGGL(dts_overwrite_kernel, g1d(n), dim3(256), 0, st, e.img, e.target, e.noise, kc, L, F, s->windows, n, e.img);
                 MPV_HIP_TRY(ctx, hipGetLastError());
             }
-            ++draw;
-            ++stream_id;
-            return MPV_OK;
-        };
-        DTS_TRY(next_noise(true, e.img));                                // img = randn(shape), :285
-        for (int pi = 0; pi < s->n_pairs; ++pi) {
-            const float* pr = plan + pi * MPV_DTS_PLAN_COLS;
-            const int time = (int)pr[0];
-            const bool last = pr[1] < 0.0f;
-            const PairCoef kc{pr[2], pr[3], pr[4], pr[5], pr[8], pr[9]};
-            if (time < 0 || time >= e.d.timesteps) return mpv_fail(ctx, MPV_EINVAL, "mpv_dts_sample: plan row with a time outside [0, timesteps)");
-            DTS_TRY(forward(ctx, e, e.img, B, time, false));
-            hipLaunchKernelGGL(dts_predict_kernel, g1d(n), dim3(256), 0, st, e.img, e.trend, e.season, kc, last ? 1 : 0, n, e.xstart, e.pmean);
-            MPV_HIP_TRY(ctx, hipGetLastError());
-            if (last) break;
-            DTS_TRY(next_noise(false, nullptr));                         // `noise` of :300, multiplied by sigma = 0
-            // img = pred_mean; Langevin refinement of the whole tensor (:359-407)
-            MPV_HIP_TRY(ctx, hipMemcpyAsync(e.img, e.pmean, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
-            const int K = (int)pr[6];
-            for (int it = 0; it < K; ++it) {
-                DTS_TRY(forward(ctx, e, e.img, B, time, true));
-                hipLaunchKernelGGL(dts_infill_grad_kernel, g1d(n), dim3(256), 0, st, e.trend, e.season, e.target, L, F, s->windows, inv_nmask, n, e.gout);
-                MPV_HIP_TRY(ctx, hipGetLastError());
-                DTS_TRY(backward(ctx, e, e.gout, e.gx, B, time));
-                hipLaunchKernelGGL(dts_langevin_step_kernel, g1d(n), dim3(256), 0, st, e.gx, e.pmean, coef_over_b, pr[7], n, e.img);
-                MPV_HIP_TRY(ctx, hipGetLastError());
-                DTS_TRY(next_noise(false, nullptr));                     // epsilon of :403, multiplied by coef_ = 0
-            }
-            DTS_TRY(next_noise(true, e.noise));                          // q_sample's noise, :305
-            hipLaunchKernelGGL(dts_overwrite_kernel, g1d(n), dim3(256), 0, st, e.img, e.target, e.noise, kc, L, F, s->windows, n, e.img);
+            const long long no = (long long)B * (L - s->windows) * F;
+            hipLaunchKernelGGL(dts_gather_kernel, g1d(no), dim3(256), 0, st, e.xstart, V, par, L, F, s->windows, s->n_samples, c, r0, no, samples);
             MPV_HIP_TRY(ctx, hipGetLastError());
         }
-        const long long no = rows * (L - s->windows) * F;
-        hipLaunchKernelGGL(dts_gather_kernel, g1d(no), dim3(256), 0, st, e.xstart, V, par, L, F, s->windows, s->n_samples, c, no, samples);
-        MPV_HIP_TRY(ctx, hipGetLastError());
     }
     return MPV_OK;
 }

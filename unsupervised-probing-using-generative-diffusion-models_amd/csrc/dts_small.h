@@ -418,13 +418,13 @@ __global__ void dts_overwrite_kernel(const float* __restrict__ param, const floa
 
 // rows of the batch: target[r][l][f] = l < windows ? history[w][v][l][f] : 0, with r = (w*par + s)*V + v (sample-major tiling of
 // DiffusionTS_model.py:92); n = rows * L * F
-__global__ void dts_build_target_kernel(const float* __restrict__ hist /*[W][V][windows][F]*/, int V, int par, int L, int F, int windows, long long n,
-                                        float* target) {
+__global__ void dts_build_target_kernel(const float* __restrict__ hist /*[W][V][windows][F]*/, int V, int par, int L, int F, int windows, long long row0,
+                                        long long n, float* target) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int f = (int)(i % F);
     const int l = (int)((i / F) % L);
-    const long long r = i / ((long long)F * L);
+    const long long r = row0 + i / ((long long)F * L);
     const int v = (int)(r % V);
     const long long w = r / ((long long)V * par);
     target[i] = l < windows ? hist[((w * V + v) * windows + l) * F + f] : 0.0f;
@@ -433,26 +433,27 @@ __global__ void dts_build_target_kernel(const float* __restrict__ hist /*[W][V][
 // final img (observed part = target) -> samples[w][v'][o][f][chunk*par + p'] with the reference's un-tiling quirk
 // (DiffusionTS_model.py:102-104): batch row r of a window is read as (v', p') = (r / par, r % par) although it was tiled
 // sample-major (r = s*V + v).
-__global__ void dts_gather_kernel(const float* __restrict__ x_start, int V, int par, int L, int F, int windows, int S, int chunk, long long n,
-                                  float* samples /*[W][V][O][F][S]*/) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // ((w*V*par + r)*O + o)*F + f
+__global__ void dts_gather_kernel(const float* __restrict__ x_start, int V, int par, int L, int F, int windows, int S, int chunk, long long row0,
+                                  long long n, float* samples /*[W][V][O][F][S]*/) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // ((row - row0)*O + o)*F + f, row = w*V*par + r
     if (i >= n) return;
     const int O = L - windows;
     const int f = (int)(i % F);
     const int o = (int)((i / F) % O);
-    const long long wr = i / ((long long)F * O);
+    const long long lr = i / ((long long)F * O);
+    const long long wr = row0 + lr;
     const int r = (int)(wr % ((long long)V * par));
     const long long w = wr / ((long long)V * par);
     const int vq = r / par, pq = r - vq * par;
-    samples[((((w * V + vq) * O + o) * F + f) * (long long)S) + chunk * par + pq] = x_start[((wr * L) + windows + o) * F + f];
+    samples[((((w * V + vq) * O + o) * F + f) * (long long)S) + chunk * par + pq] = x_start[((lr * L) + windows + o) * F + f];
 }
 
 // Philox normals for a [n] tensor: element i uses normal (i & 3) of block i >> 2, stream `stream`
-__global__ void dts_philox_kernel(unsigned seed_lo, unsigned seed_hi, unsigned stream, long long n, float* out) {
-    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // block of 4
+__global__ void dts_philox_kernel(unsigned seed_lo, unsigned seed_hi, unsigned stream, long long q0, long long n, float* out) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // block of 4 (q0 + q: position in the whole tensor)
     if (4 * q >= n) return;
     float z[4];
-    chain::philox_normals((unsigned long long)q, stream, seed_lo, seed_hi, 0x44545300u, z);
+    chain::philox_normals((unsigned long long)(q0 + q), stream, seed_lo, seed_hi, 0x44545300u, z);
     for (int e = 0; e < 4 && 4 * q + e < n; ++e) out[4 * q + e] = z[e];
 }
 

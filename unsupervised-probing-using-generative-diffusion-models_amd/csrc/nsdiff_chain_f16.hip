@@ -758,8 +758,13 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+struct SummaryArgs {                  // by value: a reference to the kernel-argument struct would force it into scratch
+    const float *inv_std, *inv_mean;
+    int S, O, B, seg, sub;
+};
+
 template <int F>
-__device__ __noinline__ void summary_epilogue(const ChainArgs& p, const Vec<F>& y, bool valid, long long n, int lane, bool row_done,
+__device__ __noinline__ void summary_epilogue(const SummaryArgs p, const Vec<F> y, bool valid, long long n, int lane, bool row_done,
                                               double* row_slot, double* acc_tab) {
     const long long row = n / p.S;
     const int w = (int)(row / ((long long)p.O * p.B));
@@ -858,12 +863,15 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
 
     double* const acc_tab = reinterpret_cast<double*>(smem + LD::TAB);
     double* const row_slot = reinterpret_cast<double*>(smem + LD::SLOT) + wave * (F * 2);
-    const int n_sub = p.sub;                                  // 1 unless the fused summary needs S/32 tiles per row
+    // A claim covers `p.claim` consecutive tiles (a multiple of the p.sub tiles that make up one (b,o,f) row of S samples): one
+    // returning atomic per 8 tiles instead of one per tile (each is a 64-byte request at the memory side).
+    const int n_sub = p.claim;
     for (;;) {
         const long long claim = claim_tile(p.tile_counter, lane);
         if (claim * n_sub >= p.n_tiles) break;
       for (int sub = 0; sub < n_sub; ++sub) {
         const long long tile = claim * n_sub + sub;
+        if (tile >= p.n_tiles) break;
         const long long n_raw = tile * TILE + r_lane;
         const bool valid = n_raw < p.n_chains;
         const long long n = valid ? n_raw : p.n_chains - 1;
@@ -960,7 +968,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
 #pragma unroll
             for (int f = 0; f < F; ++f) p.samples[(row * F + f) * p.S + s] = y.v[f];
         }
-        if (p.acc) summary_epilogue<F>(p, y, valid, n, lane, sub == n_sub - 1, row_slot, acc_tab);
+        if (p.acc) summary_epilogue<F>(SummaryArgs{p.inv_std, p.inv_mean, p.S, p.O, p.B, p.seg, p.sub}, y, valid, n, lane, (sub + 1) % p.sub == 0, row_slot, acc_tab);
       }
     }
     if (p.acc) {                                              // one flush per workgroup: W*F*2 fp64 atomics
