@@ -353,6 +353,45 @@ typedef struct mpv_sde_desc {
 int mpv_network_sde_simulate(mpv_ctx* ctx, const mpv_sde_desc* desc, const int32_t* row_ptr, const int32_t* col_idx, const float* x0,
                              float* series_out);
 
+/* ------------------------------------------------------------------------------------
+ * f(x): the mean backbone of NsDiff, and TMDM's prior
+ * replaces: ns_Transformer.Model.forward (NsDiff/mu_backbone.py:150-183, Projector :12-41), called at NsDiff_model.py:222 /
+ *           :442-446 once per window, and TMDM's prior (TMDM/tmdm_ns_transformer.py:136-172, called at tmdm_adapter.py:123)
+ *           in eval mode; with scaler_transform and build_sliding_windows folded into the load like mpv_sigma_head.
+ * The encoder / decoder / attention / embedding layers are torch-timeseries==0.1.10 classes the reference only imports;
+ * they are restated from the published Non-stationary Transformer (oracle/ns_transformer_oracle.py): PARITY UNPINNED.
+ *
+ * tensors (host, fp32, state_dict order of the `cond_pred_model.` sub-module):
+ *   enc_embedding.value_embedding.tokenConv.weight [D][F][3], enc_embedding.position_embedding.pe [pe_rows][D], the same two of
+ *   dec_embedding; per encoder layer: attention.{query,key,value,out}_projection.{weight,bias} (8), conv1.{weight [d_ff][D],bias},
+ *   conv2.{weight [D][d_ff],bias}, norm1.{weight,bias}, norm2.{weight,bias}; encoder.norm.{weight,bias}; per decoder layer:
+ *   self_attention (8), cross_attention (8), conv1, conv2 (4), norm1..3 (6); decoder.norm (2); decoder.projection.{weight,bias};
+ *   tau_learner: series_conv.weight [seq_len][3], then backbone.{0,2,..}.{weight,bias} for the hidden layers and the bias-free
+ *   output weight; delta_learner likewise; with latent: z_mean.0, z_mean.2, z_out.0, z_out.2 {weight,bias}.
+ * ---------------------------------------------------------------------------------- */
+typedef struct mpv_nst_desc {
+    int32_t enc_in, c_out;            /* F (c_out must equal enc_in: the output is de-normalised with the input statistics) */
+    int32_t seq_len, label_len, pred_len;
+    int32_t d_model, n_heads, d_ff, e_layers, d_layers;
+    int32_t activation;               /* 0 relu, 1 gelu (erf) */
+    int32_t p_layers;                 /* p_hidden_layers, 1..4 */
+    int32_t p_hidden[4];              /* p_hidden_dims */
+    int32_t latent;                   /* 1: TMDM prior (encoder output -> z_mean -> z_out -> decoder) */
+    int32_t pe_rows;                  /* rows of the two position tables passed */
+} mpv_nst_desc;
+int mpv_nst_load(mpv_ctx* ctx, const mpv_nst_desc* desc, const float* const* tensors, int32_t n_tensors);
+
+/* series: dev [nodes][series_len][F]; window w covers [first + w*step, +seq_len) of every node; mean/std: dev [F] scaler fused into
+ * the load or both NULL.  y0hat: dev [n_windows*nodes][pred_len][F] (full = 0: the reference's first return value) or
+ * [n_windows*nodes][label_len+pred_len][F] (full = 1: its second).  rows_per_pass: window rows per pass over the layers
+ * (0 = sized to a 6 GB workspace). */
+int mpv_nst_forward(mpv_ctx* ctx, const float* series, int32_t nodes, int64_t series_len, int32_t n_windows, int64_t first, int64_t step,
+                    const float* mean, const float* std, int32_t full, int64_t rows_per_pass, float* y0hat);
+
+/* Validation helper: intermediate of the LAST pass of the last mpv_nst_forward call.  which: 0 normalised window [B][S][F],
+ * 1 statistics [B][2][F] (mean, std), 2 tau [B], 3 delta [B][S], 4 encoder output [B][S][D]. */
+int mpv_nst_debug_tensor(mpv_ctx* ctx, int32_t which, float* out_dev, int64_t capacity);
+
 /* Debug/validation helper: write the Philox normals mpv_nsdiff_sample would consume, in the
  * dense layout [n_chains][T][F] (chain-major), so a CPU checker can replay them. */
 int mpv_nsdiff_philox_normals(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out_dev);

@@ -96,10 +96,13 @@ def _model(golden_tmdm, tag, nf, steps, device="cpu", **kw):
     m = diffusion_models("TMDM", param)
     sd = state(golden_tmdm, tag)
     sd["scaler_mean"], sd["scaler_std"] = torch.zeros(nf), torch.ones(nf)
-    # a reference checkpoint also carries the prior network and the unused data embedding
-    sd["cond_pred_model.enc_embedding.value_embedding.tokenConv.weight"] = torch.zeros(4, nf, 3)
+    # a reference checkpoint also carries the prior network (loaded into the holder) and the unused data embedding (dropped)
+    torch.manual_seed(5)
+    for k, v in m.cond_pred_model.state_dict().items():
+        sd["cond_pred_model." + k] = v.clone() if k.endswith(".pe") else torch.randn_like(v) * 0.1
     sd["model.enc_embedding.position_embedding.pe"] = torch.zeros(1, 8, 4)
     m.load_state_dict(sd)
+    assert torch.equal(m.cond_pred_model.z_out[2].weight, sd["cond_pred_model.z_out.2.weight"])
     return m.to(device)
 
 
@@ -110,9 +113,13 @@ def test_host_model_mirrors_reference_interface(golden_tmdm):
     x = torch.arange(3 * 8 * 2, dtype=torch.float32).reshape(3, 8, 2)
     assert torch.equal(m.scaler_inverse_transform(m.scaler_transform(x)), x)
     assert m._decoder_input(x).shape == (3, 4 + 8, 2)
-    with pytest.raises(NotImplementedError):
-        m.evaluation_step(x)                                                          # no prior attached
     from mpv_amd import _native
+    with pytest.raises(_native.MpvError):
+        m.evaluation_step(x)                                                          # CPU: the prior is native too, no fallback
+    prior, m.cond_pred_model = m.cond_pred_model, None
+    with pytest.raises(NotImplementedError):
+        m.evaluation_step(x)                                                          # prior removed and no y_0_hat
+    m.cond_pred_model = prior
     with pytest.raises(_native.MpvError):
         m.evaluation_step(x, y_0_hat=torch.zeros(3, 12, 2))                           # CPU: no fallback
     m.n_z_samples, m.parallel_sample = 7, 3

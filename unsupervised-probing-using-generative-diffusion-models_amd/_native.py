@@ -27,6 +27,7 @@ EXPORTS = (
     "mpv_reduce", "mpv_chain_timing", "mpv_chain_timing_enable", "mpv_tmdm_load", "mpv_tmdm_sample",
     "mpv_stg_load", "mpv_stg_set_graph", "mpv_stg_forward", "mpv_stg_sample",
     "mpv_biomass_simulate", "mpv_network_sde_simulate", "mpv_dts_load", "mpv_dts_forward", "mpv_dts_vjp", "mpv_dts_debug_tensor", "mpv_dts_sample",
+    "mpv_nst_load", "mpv_nst_forward", "mpv_nst_debug_tensor",
 )
 
 
@@ -81,6 +82,11 @@ class StgSampleShape(C.Structure):
 
 
 STG_PLAN_COLS = 6
+
+
+class NstDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("enc_in", "c_out", "seq_len", "label_len", "pred_len", "d_model", "n_heads", "d_ff", "e_layers", "d_layers",
+                                          "activation", "p_layers")] + [("p_hidden", C.c_int32 * 4), ("latent", C.c_int32), ("pe_rows", C.c_int32)]
 
 
 class SigmaDesc(C.Structure):
@@ -147,6 +153,9 @@ def load_library():
         "mpv_dts_vjp": (C.c_int, [vp, vp, i32, i32, vp, vp]),
         "mpv_dts_debug_tensor": (C.c_int, [vp, C.c_char_p, i32, vp, i64]),
         "mpv_dts_sample": (C.c_int, [vp, C.POINTER(DtsSampleShape), vp, _F, vp, vp]),
+        "mpv_nst_load": (C.c_int, [vp, C.POINTER(NstDesc), C.POINTER(_F), i32]),
+        "mpv_nst_forward": (C.c_int, [vp, vp, i32, i64, i32, i64, i64, vp, vp, i32, i64, vp]),
+        "mpv_nst_debug_tensor": (C.c_int, [vp, i32, vp, i64]),
         "mpv_chain_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i64)]),
         "mpv_chain_timing_enable": (C.c_int, [vp, C.c_int]),
     }
@@ -198,6 +207,7 @@ class Context:
         self.nsdiff = None     # (steps, nf)
         self.tmdm = None       # (steps, nf)
         self.sigma = None      # SigmaDesc fields
+        self.nst = None        # NstDesc of the loaded f(x) backbone
         self.dts = None        # DtsDesc fields
         self.stg = None        # (T_h, T_p, F, graph nodes | None)
         self._stg_graph = None
@@ -430,6 +440,52 @@ class Context:
         return out
 
     # ---- DiffSTG -----------------------------------------------------------------------
+    # ---- f(x): ns-Transformer mean backbone ---------------------------------------------------------------
+    def load_nst(self, backbone):
+        """Upload an ns-Transformer holder (models/Diffusion_model/NsDiff/mu_backbone.py::Model or TMDM's): its
+        native_weight_list() gives (NstDesc fields, tensors in the ABI's order)."""
+        fields, tensors = backbone.native_weight_list()
+        d = NstDesc()
+        for k, v in fields.items():
+            if k == "p_hidden":
+                for i, h in enumerate(v):
+                    d.p_hidden[i] = int(h)
+            else:
+                setattr(d, k, int(v))
+        keep = [_host_f32(t) for t in tensors]
+        arr = (_F * len(keep))(*[_fptr(t) for t in keep])
+        self._check(self.lib.mpv_nst_load(self._h, C.byref(d), arr, len(keep)), "mpv_nst_load")
+        self.nst = d
+
+    def nst_forward(self, series: torch.Tensor, n_windows: int, first: int = 0, step: int = 1, mean: Optional[torch.Tensor] = None,
+                    std: Optional[torch.Tensor] = None, full: bool = False, rows_per_pass: int = 0) -> torch.Tensor:
+        """series [V, L, F] on device -> y_0_hat [n_windows, V, pred_len (or label_len + pred_len when full), F]."""
+        if self.nst is None:
+            raise MpvError("f(x) weights not loaded")
+        if series.dim() != 3 or series.shape[2] != self.nst.enc_in:
+            raise MpvError("series must be [V, L, {}], got {}".format(self.nst.enc_in, tuple(series.shape)))
+        V, L, F = series.shape
+        keep = self.nst.label_len + self.nst.pred_len if full else self.nst.pred_len
+        out = torch.empty((n_windows, V, keep, F), device=self.device, dtype=torch.float32)
+        m = None if mean is None else mean.to(self.device, torch.float32).contiguous()
+        sd = None if std is None else std.to(self.device, torch.float32).contiguous()
+        self._bind_stream()
+        self._check(self.lib.mpv_nst_forward(self._h, _dev_ptr(series, self.device, "series"), V, L, int(n_windows), int(first), int(step),
+                                             _dev_ptr(m, self.device, "mean"), _dev_ptr(sd, self.device, "std"), int(bool(full)), int(rows_per_pass),
+                                             _dev_ptr(out, self.device, "y0hat")), "mpv_nst_forward")
+        return out
+
+    def nst_debug(self, which: str, rows: int) -> torch.Tensor:
+        """Intermediate of the last pass (validation): 'x_norm', 'stats', 'tau', 'delta', 'enc_out'; rows = window rows of that pass."""
+        d = self.nst
+        ids = {"x_norm": (0, (rows, d.seq_len, d.enc_in)), "stats": (1, (rows, 2, d.enc_in)), "tau": (2, (rows,)), "delta": (3, (rows, d.seq_len)),
+               "enc_out": (4, (rows, d.seq_len, d.d_model))}
+        idx, shape = ids[which]
+        out = torch.empty(shape, device=self.device, dtype=torch.float32)
+        self._bind_stream()
+        self._check(self.lib.mpv_nst_debug_tensor(self._h, idx, _dev_ptr(out, self.device, "out"), out.numel()), "mpv_nst_debug_tensor")
+        return out
+
     def load_stg(self, ugnet):
         """Upload a UGnet holder (models/Diffusion_model/DiffSTG/ugnet.py): its layout() gives the step sequence."""
         import math

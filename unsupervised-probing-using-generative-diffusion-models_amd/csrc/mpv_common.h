@@ -34,6 +34,9 @@ void dts_engine_destroy(DtsEngine* e);
 struct StgEngine;                      // DiffSTG weights + workspace (stg.hip)
 void stg_engine_destroy(StgEngine* e);
 
+struct NstEngine;                      // ns-Transformer f(x) weights + workspace (nst.hip)
+void nst_engine_destroy(NstEngine* e);
+
 struct DeviceGuard {     // run on ctx->device without disturbing the caller's current device
     int prev = -1;
     explicit DeviceGuard(int dev) {
@@ -55,6 +58,7 @@ struct mpv_ctx {
     SigmaModel sg;
     DtsEngine* dts = nullptr;
     StgEngine* stg = nullptr;
+    NstEngine* nst = nullptr;
     double* reduce_ws = nullptr;   // partial sums of mpv_reduce
     unsigned long long* tile_counter = nullptr;   // work queue head of the split-f16 chain kernel (zeroed per launch)
     unsigned long long* chain_stats = nullptr;    // [0] steps re-run through the exact routine (device counter)

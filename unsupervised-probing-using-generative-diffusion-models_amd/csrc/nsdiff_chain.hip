@@ -25,6 +25,7 @@
 // Algorithmic work per chain-step: 2*128*(128+128) + 2*128*3F + 2*2*128*F = 256*(256+5F) flop
 // (SURVEY.md section 8d), ~98% of it in the two MFMA layers -> roofline: fp32 MFMA peak.
 #include <algorithm>
+#include <cstdlib>
 
 #include "chain_common.h"
 
@@ -352,7 +353,9 @@ static int run_chain(mpv_ctx* ctx, const NsdiffModel& m, bool tmdm, const mpv_sa
             a.sub = S <= 32 ? 1 : S / 32;
             a.acc_windows = wn;
         }
-        a.claim = f16 ? a.sub * std::max(1, 8 / a.sub) : 1;             // (the exact-fp32 kernel claims tile by tile)
+        int per_claim = 8;                                               // tiles per work-queue atomic (tuning knob: MPV_CHAIN_CLAIM)
+        if (const char* env = getenv("MPV_CHAIN_CLAIM")) per_claim = std::max(1, atoi(env));
+        a.claim = f16 ? a.sub * std::max(1, per_claim / a.sub) : 1;     // (the exact-fp32 kernel claims tile by tile)
         const long long wg_needed = ((a.n_tiles + a.claim - 1) / a.claim + WAVES - 1) / WAVES;
         const int grid = (int)(wg_needed < ctx->cu_count ? wg_needed : ctx->cu_count);   // 1 workgroup per CU (LDS-bound)
         int rc;

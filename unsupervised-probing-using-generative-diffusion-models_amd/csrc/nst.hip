@@ -1,0 +1,847 @@
+// f(x): the non-stationary-transformer mean backbone of NsDiff, and TMDM's prior (the same network with a latent bottleneck),
+// for gfx950.  One forward per window row, no gradient.
+//
+// Wiring follows reference models/Diffusion_model/NsDiff/mu_backbone.py:12-183 (Projector :12-41, Model.forward :150-183) and
+// TMDM/tmdm_ns_transformer.py:136-172; the encoder / decoder / attention / embedding layers are torch-timeseries==0.1.10
+// classes that the reference only imports (source absent): they are restated from the published Non-stationary Transformer
+// definition, see oracle/ns_transformer_oracle.py -- PARITY UNPINNED for those layers.
+//
+// Activations are fp32 [rows][d_model], row = (window row b, position l).  Kernels:
+//   nst_prepare_kernel   per b: gather the window from the resident series (scaler fused), series statistics, normalised window,
+//                        both Projector MLPs (tau = exp(.), delta[seq_len])                                    HBM, tiny
+//   nst_embed_kernel     circular k=3 token convolution + position table; the decoder input [x_norm[-label:], 0] is formed on the fly
+//   nst_gemm_kernel      Y = act(X W^T + b) (+ R): 128x128x32 LDS tiles, double buffered, exact-fp32 v_mfma_f32_32x32x2_f32   MFMA
+//   nst_attn_kernel      de-stationary attention softmax(scale (q.k tau + delta)) v, causal option; online softmax (base 2) over
+//                        128-key chunks, S^T accumulators reused as the B operand of the P.V product; v_mfma_f32_16x16x4_f32   MFMA
+//   nst_ln_kernel        LayerNorm of a row (the residual is added in the producing GEMM's epilogue)           HBM
+//   nst_head_kernel      decoder.norm + Linear(d_model, c_out) + de-normalisation, only the rows that are returned
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "mpv_common.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr float LOG2E = 1.44269504088896341f;
+
+__device__ __forceinline__ float nst_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// window gather + statistics + the two Projector MLPs                       (mu_backbone.py:12-41, :154-163)
+// ---------------------------------------------------------------------------------------------------------------------
+struct ProjW {
+    const float* conv;        // [S][3]
+    const float* w[5];        // hidden layers then the bias-free output layer
+    const float* b[4];
+};
+
+struct PrepArgs {
+    const float* series;      // [V][L][F]
+    const float* mean;        // scaler [F] | null
+    const float* std;
+    long long L, first, step;
+    int V, S, F, n_out_delta;
+    int p_layers, p_dim[4];
+    ProjW tau, delta;
+    float* xn;                // [B][S][F]
+    float* stats;             // [B][2][F]  (mean, std)
+    float* tau_out;           // [B]
+    float* delta_out;         // [B][S]
+    long long b0;             // first window row of this pass
+};
+
+__device__ void projector_mlp(const PrepArgs& p, const ProjW& w, const float* conv_out, const float* stat, float* h0, float* h1, int n_out, float* out,
+                              bool exp_out) {
+    const int tid = threadIdx.x, nt = blockDim.x, F = p.F;
+    // input [conv_out (F) | stat (F)]
+    for (int i = tid; i < 2 * F; i += nt) h0[i] = i < F ? conv_out[i] : stat[i - F];
+    __syncthreads();
+    int n_in = 2 * F;
+    float* src = h0;
+    float* dst = h1;
+    for (int l = 0; l < p.p_layers; ++l) {
+        const int n = p.p_dim[l];
+        for (int o = tid; o < n; o += nt) {
+            float acc = w.b[l][o];
+            const float* row = w.w[l] + (size_t)o * n_in;
+            for (int i = 0; i < n_in; ++i) acc += row[i] * src[i];
+            dst[o] = fmaxf(acc, 0.0f);
+        }
+        __syncthreads();
+        float* t = src; src = dst; dst = t;
+        n_in = n;
+    }
+    for (int o = tid; o < n_out; o += nt) {
+        float acc = 0.0f;
+        const float* row = w.w[p.p_layers] + (size_t)o * n_in;
+        for (int i = 0; i < n_in; ++i) acc += row[i] * src[i];
+        out[o] = exp_out ? expf(acc) : acc;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(128) void nst_prepare_kernel(const PrepArgs p) {
+    extern __shared__ float sm[];
+    const int S = p.S, F = p.F, tid = threadIdx.x, nt = blockDim.x;
+    float* win = sm;                    // [S][F] scaled window (x_raw)
+    float* red = win + S * F;           // [2][F] mean, std
+    float* conv = red + 2 * F;          // [F]
+    float* h0 = conv + F;               // [256]
+    float* h1 = h0 + 256;               // [256]
+    const long long b = p.b0 + blockIdx.x;
+    const long long w = b / p.V;
+    const int v = (int)(b % p.V);
+    const float* src = p.series + ((size_t)v * p.L + p.first + w * p.step) * F;
+    for (int i = tid; i < S * F; i += nt) {
+        float x = src[i];
+        if (p.mean) x = (x - p.mean[i % F]) / p.std[i % F];
+        win[i] = x;
+    }
+    __syncthreads();
+    // per-feature mean and population std over the window: one wave per feature, round-robin
+    const int lane = tid & 63, wave = tid >> 6, n_waves = nt >> 6;
+    for (int f = wave; f < F; f += n_waves) {
+        float s = 0.0f;
+        for (int t = lane; t < S; t += 64) s += win[t * F + f];
+        const float m = wave_sum(s) / (float)S;
+        float q = 0.0f;
+        for (int t = lane; t < S; t += 64) { const float d = win[t * F + f] - m; q += d * d; }
+        const float sd = sqrtf(wave_sum(q) / (float)S + 1e-5f);
+        if (lane == 0) { red[f] = m; red[F + f] = sd; }
+    }
+    __syncthreads();
+    float* xn = p.xn + (size_t)blockIdx.x * S * F;
+    for (int i = tid; i < S * F; i += nt) xn[i] = (win[i] - red[i % F]) / red[F + i % F];
+    if (tid < 2 * F) p.stats[(size_t)blockIdx.x * 2 * F + tid] = red[tid];
+    // tau: conv over features (circular, k=3) with the time axis as input channels; stats row = std
+    for (int pass = 0; pass < 2; ++pass) {
+        const ProjW& pw = pass == 0 ? p.tau : p.delta;
+        for (int e = wave; e < F; e += n_waves) {
+            float s = 0.0f;
+            const int em = (e + F - 1) % F, ep = (e + 1) % F;
+            for (int t = lane; t < S; t += 64)
+                s += pw.conv[t * 3 + 0] * win[t * F + em] + pw.conv[t * 3 + 1] * win[t * F + e] + pw.conv[t * 3 + 2] * win[t * F + ep];
+            s = wave_sum(s);
+            if (lane == 0) conv[e] = s;
+        }
+        __syncthreads();
+        if (pass == 0) projector_mlp(p, pw, conv, red + F, h0, h1, 1, p.tau_out + blockIdx.x, true);
+        else projector_mlp(p, pw, conv, red, h0, h1, p.n_out_delta, p.delta_out + (size_t)blockIdx.x * p.n_out_delta, false);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// DataEmbedding: circular k=3 token convolution + position table
+// ---------------------------------------------------------------------------------------------------------------------
+struct EmbedArgs {
+    const float* xn;          // [B][S][F]
+    const float* wt;          // [F][3][D]  (transposed at load)
+    const float* pe;          // [rows][D]
+    float* out;               // [B][Lx][D]
+    int S, F, D, Lx, label;   // label < 0: encoder (Lx == S); else decoder input [xn[S-label:], zeros]
+    long long n_rows;         // B * Lx
+};
+
+__global__ __launch_bounds__(256) void nst_embed_kernel(const EmbedArgs p) {
+    const int dq = p.D >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.n_rows * dq) return;
+    const long long row = idx / dq;
+    const int c = (int)(idx % dq) * 4;
+    const long long b = row / p.Lx;
+    const int l = (int)(row % p.Lx);
+    v4f acc = *reinterpret_cast<const v4f*>(p.pe + (size_t)l * p.D + c);
+    v4f val = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+        int pos = l + tap - 1;
+        pos = pos < 0 ? pos + p.Lx : (pos >= p.Lx ? pos - p.Lx : pos);
+        int src = pos;
+        if (p.label >= 0) { if (pos >= p.label) continue; src = p.S - p.label + pos; }
+        for (int f = 0; f < p.F; ++f) {
+            const float x = p.xn[((size_t)b * p.S + src) * p.F + f];
+            const v4f w = *reinterpret_cast<const v4f*>(p.wt + ((size_t)f * 3 + tap) * p.D + c);
+            val += w * x;
+        }
+    }
+    *reinterpret_cast<v4f*>(p.out + (size_t)row * p.D + c) = val + acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GEMM  Y[M][N] = act(X[M][K] W[N][K]^T + bias) + R
+// ---------------------------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const float* X; long long ldx;
+    const float* W;           // [N][K]
+    const float* bias;        // [N] | null
+    const float* R; long long ldr;     // residual | null
+    float* Y; long long ldy;
+    long long M;
+    int N, K;
+    int act;                  // 0 none, 1 relu, 2 gelu
+};
+
+constexpr int G_BM = 128, G_BN = 128, G_BK = 32, G_LD = G_BK + 4;
+
+__global__ __launch_bounds__(256, 2) void nst_gemm_kernel(const GemmArgs p) {
+    extern __shared__ float sm[];
+    float* As = sm;                               // [2][G_BM][G_LD]
+    float* Bs = sm + 2 * G_BM * G_LD;             // [2][G_BN][G_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long m0 = (long long)blockIdx.x * G_BM;
+    const int n0 = blockIdx.y * G_BN;
+    // global -> register staging: thread covers rows (tid>>3) + 32 j, j = 0..3, k quad (tid & 7)
+    const int lr = tid >> 3, lk = (tid & 7) * 4;
+    const float* xa[4];
+    const float* wb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        long long r = m0 + lr + 32 * j;
+        if (r >= p.M) r = p.M - 1;
+        xa[j] = p.X + (size_t)r * p.ldx + lk;
+        int n = n0 + lr + 32 * j;
+        if (n >= p.N) n = p.N - 1;
+        wb[j] = p.W + (size_t)n * p.K + lk;
+    }
+    v4f ra[4], rb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ra[j] = *reinterpret_cast<const v4f*>(xa[j]); rb[j] = *reinterpret_cast<const v4f*>(wb[j]); }
+    v16f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<v4f*>(As + (size_t)(lr + 32 * j) * G_LD + lk) = ra[j];
+        *reinterpret_cast<v4f*>(Bs + (size_t)(lr + 32 * j) * G_LD + lk) = rb[j];
+    }
+    __syncthreads();
+    const int nk = p.K / G_BK;
+    const int li = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ra[j] = *reinterpret_cast<const v4f*>(xa[j] + (size_t)(kt + 1) * G_BK);
+                rb[j] = *reinterpret_cast<const v4f*>(wb[j] + (size_t)(kt + 1) * G_BK);
+            }
+        }
+        const float* a_base = As + (size_t)cur * G_BM * G_LD + (size_t)(wm * 64 + li) * G_LD + 4 * lh;
+        const float* b_base = Bs + (size_t)cur * G_BN * G_LD + (size_t)(wn * 64 + li) * G_LD + 4 * lh;
+#pragma unroll
+        for (int k8 = 0; k8 < G_BK / 8; ++k8) {
+            v4f a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const v4f*>(a_base + (size_t)i * 32 * G_LD + 8 * k8);
+                b[i] = *reinterpret_cast<const v4f*>(b_base + (size_t)i * 32 * G_LD + 8 * k8);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            float* an = As + (size_t)(cur ^ 1) * G_BM * G_LD;
+            float* bn = Bs + (size_t)(cur ^ 1) * G_BN * G_LD;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<v4f*>(an + (size_t)(lr + 32 * j) * G_LD + lk) = ra[j];
+                *reinterpret_cast<v4f*>(bn + (size_t)(lr + 32 * j) * G_LD + lk) = rb[j];
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue: accumulator (i, j) register r holds row wm*64 + i*32 + (r&3) + 8 (r>>2) + 4 lh, column wn*64 + j*32 + li
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + li;
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float y = acc[i][j][r] + bias;
+                if (p.act == 1) y = fmaxf(y, 0.0f);
+                else if (p.act == 2) y = nst_gelu(y);
+                if (p.R) y += p.R[(size_t)m * p.ldr + n];
+                p.Y[(size_t)m * p.ldy + n] = y;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// de-stationary attention
+// ---------------------------------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const float* Q; long long ldq;      // [B][L][ldq], head h at column h*E
+    const float* K; long long ldk;      // [B][S][ldk]
+    const float* V; long long ldv;
+    const float* tau;                   // [B] | null
+    const float* delta;                 // [B][S] | null
+    float* O; long long ldo;
+    int L, S, causal;
+    float scale;
+};
+
+constexpr int A_KC = 128;               // keys per chunk
+constexpr int A_QT = 64;                // queries per workgroup (16 per wave)
+
+template <int E>
+__global__ __launch_bounds__(256) void nst_attn_kernel(const AttnArgs p) {
+    constexpr int KLD = E + 4, VLD = A_KC + 4, ES = E / 16;
+    __shared__ float Ks[A_KC * KLD];
+    __shared__ float Vt[E * VLD];
+    __shared__ float Dl[A_KC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y;
+    const long long b = blockIdx.z;
+    const int q0 = blockIdx.x * A_QT;
+    const float qs = p.scale * LOG2E * (p.tau ? p.tau[b] : 1.0f);
+    const float ds = p.scale * LOG2E;
+    // Q fragments: lane (query lq, g) holds Q[query][16 s + 4 g + i], pre-scaled
+    int qrow = q0 + wave * 16 + lq;
+    const int qclamp = qrow < p.L ? qrow : p.L - 1;
+    v4f qf[ES];
+    {
+        const float* qp = p.Q + ((size_t)b * p.L + qclamp) * p.ldq + (size_t)h * E + 4 * g;
+#pragma unroll
+        for (int s = 0; s < ES; ++s) qf[s] = *reinterpret_cast<const v4f*>(qp + 16 * s) * qs;
+    }
+    v4f o[ES];                          // O^T tiles: d = 16 dt + 4 g + r, column = query
+#pragma unroll
+    for (int dt = 0; dt < ES; ++dt) o[dt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    float m_run = -INFINITY, l_run = 0.0f;
+    const int s_end = p.causal ? min(p.S, q0 + A_QT) : p.S;
+    for (int k0 = 0; k0 < s_end; k0 += A_KC) {
+        __syncthreads();                // previous chunk fully consumed
+        // stage K chunk [key][E] and V chunk transposed [e][key]
+        for (int i = tid; i < A_KC * (E / 4); i += 256) {
+            const int key = i / (E / 4), e4 = (i % (E / 4)) * 4;
+            const int src = k0 + key < p.S ? k0 + key : p.S - 1;
+            const v4f kv = *reinterpret_cast<const v4f*>(p.K + ((size_t)b * p.S + src) * p.ldk + (size_t)h * E + e4);
+            *reinterpret_cast<v4f*>(Ks + key * KLD + e4) = kv;
+            const v4f vv = *reinterpret_cast<const v4f*>(p.V + ((size_t)b * p.S + src) * p.ldv + (size_t)h * E + e4);
+            Vt[(e4 + 0) * VLD + key] = vv[0];
+            Vt[(e4 + 1) * VLD + key] = vv[1];
+            Vt[(e4 + 2) * VLD + key] = vv[2];
+            Vt[(e4 + 3) * VLD + key] = vv[3];
+        }
+        if (tid < A_KC) Dl[tid] = (p.delta && k0 + tid < p.S) ? p.delta[(size_t)b * p.S + k0 + tid] * ds : 0.0f;
+        __syncthreads();
+        // S^T tiles: rows = keys (16 kt + 4 g + r), column = query
+        v4f sc[A_KC / 16];
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < A_KC / 16; ++kt) {
+            v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            const float* kp = Ks + (kt * 16 + lq) * KLD + 4 * g;
+#pragma unroll
+            for (int s = 0; s < ES; ++s) {
+                const v4f kf = *reinterpret_cast<const v4f*>(kp + 16 * s);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[i], qf[s][i], acc, 0, 0, 0);
+            }
+            const v4f dl = *reinterpret_cast<const v4f*>(Dl + kt * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + kt * 16 + 4 * g + r;
+                float v = acc[r] + dl[r];
+                if (key >= p.S || (p.causal && key > qrow)) v = -INFINITY;
+                acc[r] = v;
+                cmax = fmaxf(cmax, v);
+            }
+            sc[kt] = acc;
+        }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+        const float m_new = fmaxf(m_run, cmax);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < A_KC / 16; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = exp2f(sc[kt][r] - m_new);
+                sc[kt][r] = e;
+                psum += e;
+            }
+        psum += __shfl_xor(psum, 16);
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < ES; ++dt) o[dt] *= alpha;
+        // O^T[d][query] += V^T[d][key] P^T[key][query]
+#pragma unroll
+        for (int kt = 0; kt < A_KC / 16; ++kt)
+#pragma unroll
+            for (int dt = 0; dt < ES; ++dt) {
+                const v4f vf = *reinterpret_cast<const v4f*>(Vt + (dt * 16 + lq) * VLD + kt * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], sc[kt][r], o[dt], 0, 0, 0);
+            }
+    }
+    if (qrow < p.L) {
+        const float inv = 1.0f / l_run;
+        float* op = p.O + ((size_t)b * p.L + qrow) * p.ldo + (size_t)h * E + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < ES; ++dt) *reinterpret_cast<v4f*>(op + 16 * dt) = o[dt] * inv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm over d_model (one wave per row), and the output head
+// ---------------------------------------------------------------------------------------------------------------------
+struct LnArgs {
+    const float* X; float* Y;
+    const float* w; const float* b;
+    long long rows;
+    int D;
+};
+
+constexpr int LN_MAXQ = 4;               // float4 per lane: d_model <= 1024
+
+__device__ __forceinline__ void ln_row(const float* x, int D, const float* w, const float* bia, int lane, v4f (&v)[LN_MAXQ]) {
+    const int nq = D >> 2;
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXQ; ++j) {
+        const int q = lane + 64 * j;
+        v[j] = q < nq ? *reinterpret_cast<const v4f*>(x + 4 * q) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float qd = 0.0f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXQ; ++j) {
+        const int q = lane + 64 * j;
+        if (q < nq) {
+            v[j] -= mean;
+            qd += v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3];
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(qd) / (float)D + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < LN_MAXQ; ++j) {
+        const int q = lane + 64 * j;
+        if (q < nq) v[j] = v[j] * rstd * *reinterpret_cast<const v4f*>(w + 4 * q) + *reinterpret_cast<const v4f*>(bia + 4 * q);
+    }
+}
+
+__global__ __launch_bounds__(256) void nst_ln_kernel(const LnArgs p) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int lane = threadIdx.x & 63;
+    v4f v[LN_MAXQ];
+    ln_row(p.X + (size_t)row * p.D, p.D, p.w, p.b, lane, v);
+#pragma unroll
+    for (int j = 0; j < LN_MAXQ; ++j) {
+        const int q = lane + 64 * j;
+        if (q < (p.D >> 2)) *reinterpret_cast<v4f*>(p.Y + (size_t)row * p.D + 4 * q) = v[j];
+    }
+}
+
+struct HeadArgs {
+    const float* X;           // decoder output [B][Ld][D]
+    const float* nw; const float* nb;     // decoder.norm
+    const float* pw; const float* pb;     // projection [C][D], [C]
+    const float* stats;       // [B][2][F]
+    float* out;               // [B][n_keep][C]
+    int D, C, Ld, n_keep, F;
+    long long rows;           // B * n_keep
+};
+
+__global__ __launch_bounds__(256) void nst_head_kernel(const HeadArgs p) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int lane = threadIdx.x & 63;
+    const long long b = row / p.n_keep;
+    const int l = p.Ld - p.n_keep + (int)(row % p.n_keep);
+    v4f v[LN_MAXQ];
+    ln_row(p.X + ((size_t)b * p.Ld + l) * p.D, p.D, p.nw, p.nb, lane, v);
+    for (int c = 0; c < p.C; ++c) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXQ; ++j) {
+            const int q = lane + 64 * j;
+            if (q < (p.D >> 2)) {
+                const v4f w = *reinterpret_cast<const v4f*>(p.pw + (size_t)c * p.D + 4 * q);
+                s += v[j][0] * w[0] + v[j][1] * w[1] + v[j][2] * w[2] + v[j][3] * w[3];
+            }
+        }
+        s = wave_sum(s) + p.pb[c];
+        if (lane == 0) p.out[(size_t)row * p.C + c] = s * p.stats[(size_t)b * 2 * p.F + p.F + c] + p.stats[(size_t)b * 2 * p.F + c];
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------------------------------------------------
+struct AttnW { const float *wqkv, *bqkv, *wo, *bo; };       // wqkv rows: q (D), k (D), v (D)
+struct FfnW { const float *w1, *b1, *w2, *b2; };
+struct NormW { const float *w, *b; };
+struct EncLayer { AttnW att; FfnW ffn; NormW n1, n2; };
+struct DecLayer { AttnW self, cross; FfnW ffn; NormW n1, n2, n3; };
+
+struct NstEngine {
+    mpv_nst_desc d{};
+    float* blob = nullptr;
+    const float *enc_tok = nullptr, *enc_pe = nullptr, *dec_tok = nullptr, *dec_pe = nullptr;
+    std::vector<EncLayer> enc;
+    std::vector<DecLayer> dec;
+    NormW enc_norm{}, dec_norm{};
+    const float *proj_w = nullptr, *proj_b = nullptr;
+    ProjW tau{}, delta{};
+    const float* z[8] = {};
+    float* ws = nullptr;
+    size_t ws_floats = 0;
+    long long cap_b = 0;
+    // workspace (per pass of cap_b window rows)
+    float *xn = nullptr, *stats = nullptr, *tau_v = nullptr, *delta_v = nullptr, *ex = nullptr, *ey = nullptr, *dx = nullptr, *dy = nullptr, *qkv = nullptr,
+          *att = nullptr, *hid = nullptr;
+    long long last_b = 0;
+};
+
+void nst_engine_destroy(NstEngine* e) {
+    if (!e) return;
+    if (e->blob) (void)hipFree(e->blob);
+    if (e->ws) (void)hipFree(e->ws);
+    delete e;
+}
+
+namespace {
+
+#define NST_TRY(expr)                     \
+    do {                                  \
+        if (int rc_ = (expr)) return rc_; \
+    } while (0)
+
+size_t per_row_floats(const mpv_nst_desc& d) {
+    const size_t S = d.seq_len, Ld = d.label_len + d.pred_len, D = d.d_model, F = d.enc_in;
+    const size_t Lm = std::max(S, Ld);
+    return S * F + 2 * F + 1 + S          // xn, stats, tau, delta
+           + 2 * S * D + 2 * Ld * D       // ex, ey, dx, dy
+           + Lm * 3 * D + S * 2 * D       // qkv (self) ; cross kv shares the tail of the same buffer
+           + Lm * D + Lm * std::max<size_t>(d.d_ff, D) + 64;
+}
+
+int carve(mpv_ctx* ctx, NstEngine& e, long long B) {
+    if (B <= e.cap_b) return MPV_OK;
+    const mpv_nst_desc& d = e.d;
+    const size_t S = d.seq_len, Ld = d.label_len + d.pred_len, D = d.d_model, F = d.enc_in, Lm = std::max(S, Ld);
+    size_t total = 0;
+    auto take = [&](size_t n) { const size_t at = total; total += (n + 3) & ~size_t(3); return at; };
+    const size_t o_xn = take(B * S * F), o_st = take(B * 2 * F), o_tau = take(B), o_del = take(B * S), o_ex = take(B * S * D), o_ey = take(B * S * D),
+                 o_dx = take(B * Ld * D), o_dy = take(B * Ld * D), o_qkv = take(B * (Lm * 3 * D + S * 2 * D)), o_att = take(B * Lm * D),
+                 o_hid = take(B * Lm * std::max<size_t>(d.d_ff, D));
+    if (total > e.ws_floats) {
+        MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (e.ws) (void)hipFree(e.ws);
+        e.ws = nullptr;
+        e.ws_floats = 0;
+        e.cap_b = 0;
+        if (hipMalloc(&e.ws, total * sizeof(float)) != hipSuccess) return mpv_fail(ctx, MPV_ENOMEM, "mpv_nst_forward: workspace allocation failed");
+        e.ws_floats = total;
+    }
+    e.xn = e.ws + o_xn; e.stats = e.ws + o_st; e.tau_v = e.ws + o_tau; e.delta_v = e.ws + o_del; e.ex = e.ws + o_ex; e.ey = e.ws + o_ey;
+    e.dx = e.ws + o_dx; e.dy = e.ws + o_dy; e.qkv = e.ws + o_qkv; e.att = e.ws + o_att; e.hid = e.ws + o_hid;
+    e.cap_b = B;
+    return MPV_OK;
+}
+
+int gemm(mpv_ctx* ctx, const float* X, long long ldx, const float* W, const float* bias, const float* R, long long ldr, float* Y, long long ldy, long long M, int N,
+         int K, int act) {
+    GemmArgs a{X, ldx, W, bias, R, ldr, Y, ldy, M, N, K, act};
+    const size_t lds = sizeof(float) * 2 * (G_BM + G_BN) * G_LD;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(nst_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)((M + G_BM - 1) / G_BM), (unsigned)((N + G_BN - 1) / G_BN));
+    hipLaunchKernelGGL(nst_gemm_kernel, grid, dim3(256), lds, ctx->stream, a);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+int layer_norm(mpv_ctx* ctx, const float* X, float* Y, const NormW& n, long long rows, int D) {
+    LnArgs a{X, Y, n.w, n.b, rows, D};
+    hipLaunchKernelGGL(nst_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, a);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+int attention(mpv_ctx* ctx, const NstEngine& e, const float* Q, long long ldq, const float* K, long long ldk, const float* V, long long ldv, const float* delta,
+              float* O, long long B, int L, int S, int causal) {
+    const int H = e.d.n_heads, E = e.d.d_model / H;
+    AttnArgs a{Q, ldq, K, ldk, V, ldv, e.tau_v, delta, O, (long long)e.d.d_model, L, S, causal, 1.0f / sqrtf((float)E)};
+    const dim3 grid((unsigned)((L + A_QT - 1) / A_QT), (unsigned)H, (unsigned)B);
+    if (E == 64) hipLaunchKernelGGL(nst_attn_kernel<64>, grid, dim3(256), 0, ctx->stream, a);
+    else if (E == 32) hipLaunchKernelGGL(nst_attn_kernel<32>, grid, dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(nst_attn_kernel<16>, grid, dim3(256), 0, ctx->stream, a);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+int ffn(mpv_ctx* ctx, NstEngine& e, const FfnW& f, const float* x, float* y, long long rows) {
+    const int D = e.d.d_model, dff = e.d.d_ff, act = e.d.activation ? 2 : 1;
+    NST_TRY(gemm(ctx, x, D, f.w1, f.b1, nullptr, 0, e.hid, dff, rows, dff, D, act));
+    return gemm(ctx, e.hid, dff, f.w2, f.b2, x, D, y, D, rows, D, dff, 0);           // + residual
+}
+
+// one pass over B window rows starting at global row b0
+int forward_pass(mpv_ctx* ctx, NstEngine& e, const float* series, int V, long long L, long long first, long long step, const float* mean, const float* std,
+                 long long b0, long long B, int full, float* out) {
+    const mpv_nst_desc& d = e.d;
+    const int S = d.seq_len, Ld = d.label_len + d.pred_len, D = d.d_model, F = d.enc_in;
+    PrepArgs pa{};
+    pa.series = series; pa.mean = mean; pa.std = std; pa.L = L; pa.first = first; pa.step = step; pa.V = V; pa.S = S; pa.F = F; pa.n_out_delta = S;
+    pa.p_layers = d.p_layers;
+    for (int i = 0; i < 4; ++i) pa.p_dim[i] = d.p_hidden[i];
+    pa.tau = e.tau; pa.delta = e.delta; pa.xn = e.xn; pa.stats = e.stats; pa.tau_out = e.tau_v; pa.delta_out = e.delta_v; pa.b0 = b0;
+    const size_t prep_lds = sizeof(float) * ((size_t)S * F + 3 * F + 512);
+    hipLaunchKernelGGL(nst_prepare_kernel, dim3((unsigned)B), dim3(128), prep_lds, ctx->stream, pa);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    // encoder
+    {
+        EmbedArgs ea{e.xn, e.enc_tok, e.enc_pe, e.ex, S, F, D, S, -1, B * S};
+        hipLaunchKernelGGL(nst_embed_kernel, dim3((unsigned)((B * S * (D / 4) + 255) / 256)), dim3(256), 0, ctx->stream, ea);
+        MPV_HIP_TRY(ctx, hipGetLastError());
+    }
+    const long long Me = B * S, Md = B * Ld;
+    for (const EncLayer& l : e.enc) {
+        NST_TRY(gemm(ctx, e.ex, D, l.att.wqkv, l.att.bqkv, nullptr, 0, e.qkv, 3 * D, Me, 3 * D, D, 0));
+        NST_TRY(attention(ctx, e, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, e.delta_v, e.att, B, S, S, 0));
+        NST_TRY(gemm(ctx, e.att, D, l.att.wo, l.att.bo, e.ex, D, e.ey, D, Me, D, D, 0));
+        NST_TRY(layer_norm(ctx, e.ey, e.ex, l.n1, Me, D));
+        NST_TRY(ffn(ctx, e, l.ffn, e.ex, e.ey, Me));
+        NST_TRY(layer_norm(ctx, e.ey, e.ex, l.n2, Me, D));
+    }
+    NST_TRY(layer_norm(ctx, e.ex, e.ey, e.enc_norm, Me, D));
+    float* enc_out = e.ey;
+    if (d.latent) {                       // tmdm_ns_transformer.py:155-162, eval mode: z = z_mean(enc); enc = z_out(z)
+        NST_TRY(gemm(ctx, e.ey, D, e.z[0], e.z[1], nullptr, 0, e.ex, D, Me, D, D, 1));
+        NST_TRY(gemm(ctx, e.ex, D, e.z[2], e.z[3], nullptr, 0, e.ey, D, Me, D, D, 0));
+        NST_TRY(gemm(ctx, e.ey, D, e.z[4], e.z[5], nullptr, 0, e.ex, D, Me, D, D, 1));
+        NST_TRY(gemm(ctx, e.ex, D, e.z[6], e.z[7], nullptr, 0, e.ey, D, Me, D, D, 0));
+    }
+    // decoder
+    {
+        EmbedArgs ea{e.xn, e.dec_tok, e.dec_pe, e.dx, S, F, D, Ld, d.label_len, B * Ld};
+        hipLaunchKernelGGL(nst_embed_kernel, dim3((unsigned)((B * Ld * (D / 4) + 255) / 256)), dim3(256), 0, ctx->stream, ea);
+        MPV_HIP_TRY(ctx, hipGetLastError());
+    }
+    float* ckv = e.qkv + (size_t)B * std::max(S, Ld) * 3 * D;       // cross K | V  [B*S][2D]
+    for (const DecLayer& l : e.dec) {
+        NST_TRY(gemm(ctx, e.dx, D, l.self.wqkv, l.self.bqkv, nullptr, 0, e.qkv, 3 * D, Md, 3 * D, D, 0));
+        NST_TRY(attention(ctx, e, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, nullptr, e.att, B, Ld, Ld, 1));
+        NST_TRY(gemm(ctx, e.att, D, l.self.wo, l.self.bo, e.dx, D, e.dy, D, Md, D, D, 0));
+        NST_TRY(layer_norm(ctx, e.dy, e.dx, l.n1, Md, D));
+        NST_TRY(gemm(ctx, e.dx, D, l.cross.wqkv, l.cross.bqkv, nullptr, 0, e.qkv, D, Md, D, D, 0));                                   // q
+        NST_TRY(gemm(ctx, enc_out, D, l.cross.wqkv + (size_t)D * D, l.cross.bqkv + D, nullptr, 0, ckv, 2 * D, Me, 2 * D, D, 0));        // k | v
+        NST_TRY(attention(ctx, e, e.qkv, D, ckv, 2 * D, ckv + D, 2 * D, e.delta_v, e.att, B, Ld, S, 0));
+        NST_TRY(gemm(ctx, e.att, D, l.cross.wo, l.cross.bo, e.dx, D, e.dy, D, Md, D, D, 0));
+        NST_TRY(layer_norm(ctx, e.dy, e.dx, l.n2, Md, D));
+        NST_TRY(ffn(ctx, e, l.ffn, e.dx, e.dy, Md));
+        NST_TRY(layer_norm(ctx, e.dy, e.dx, l.n3, Md, D));
+    }
+    const int n_keep = full ? Ld : d.pred_len;
+    HeadArgs ha{e.dx, e.dec_norm.w, e.dec_norm.b, e.proj_w, e.proj_b, e.stats, out, D, d.c_out, Ld, n_keep, F, B * n_keep};
+    hipLaunchKernelGGL(nst_head_kernel, dim3((unsigned)((B * n_keep + 3) / 4)), dim3(256), 0, ctx->stream, ha);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    e.last_b = B;
+    return MPV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mpv_nst_load(mpv_ctx* ctx, const mpv_nst_desc* d, const float* const* t, int32_t n_tensors) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nst_load: ctx is NULL");
+    if (!d || !t) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: NULL argument");
+    const int D = d->d_model, F = d->enc_in, S = d->seq_len, H = d->n_heads, dff = d->d_ff, Ld = d->label_len + d->pred_len;
+    if (F < 1 || F > 64 || d->c_out != F || S < 2 || d->label_len < 0 || d->label_len > S || d->pred_len < 1 || H < 1 || D % H != 0 || d->e_layers < 0 ||
+        d->d_layers < 1 || d->p_layers < 1 || d->p_layers > 4)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: bad shape (need c_out == enc_in <= 64, label_len <= seq_len, 1 <= p_hidden_layers <= 4)");
+    const int E = D / H;
+    if ((E != 16 && E != 32 && E != 64) || D % 32 != 0 || D > 1024 || dff % 32 != 0)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: head width d_model / n_heads must be 16, 32 or 64, d_model and d_ff multiples of 32, d_model <= 1024");
+    for (int i = 0; i < d->p_layers; ++i)
+        if (d->p_hidden[i] < 1 || d->p_hidden[i] > 256) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: projector hidden widths must be in [1, 256]");
+    if (2 * F > 256) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: too many features");
+    if (d->pe_rows < std::max(S, Ld)) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: position table shorter than the sequences");
+    const int n_proj = 2 + 2 * d->p_layers;
+    const int expect = 4 + 16 * d->e_layers + 2 + 26 * d->d_layers + 4 + 2 * n_proj + (d->latent ? 8 : 0);
+    if (n_tensors != expect) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: expected " + std::to_string(expect) + " tensors, got " + std::to_string(n_tensors));
+    for (int i = 0; i < n_tensors; ++i)
+        if (!t[i]) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: tensor " + std::to_string(i) + " is NULL");
+    DeviceGuard dg(ctx->device);
+    MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    nst_engine_destroy(ctx->nst);
+    ctx->nst = nullptr;
+    NstEngine* e = new (std::nothrow) NstEngine();
+    if (!e) return mpv_fail(ctx, MPV_ENOMEM, "mpv_nst_load: out of host memory");
+    e->d = *d;
+    std::vector<float> host;
+    auto put = [&](const float* p, size_t n) { const size_t at = host.size(); host.insert(host.end(), p, p + n); host.resize((host.size() + 3) & ~size_t(3)); return at; };
+    int k = 0;
+    auto tok = [&](const float* w) {       // [D][F][3] -> [F][3][D]
+        std::vector<float> o((size_t)F * 3 * D);
+        for (int c = 0; c < D; ++c)
+            for (int f = 0; f < F; ++f)
+                for (int tap = 0; tap < 3; ++tap) o[((size_t)f * 3 + tap) * D + c] = w[((size_t)c * F + f) * 3 + tap];
+        return put(o.data(), o.size());
+    };
+    struct AttnO { size_t wqkv, bqkv, wo, bo; };
+    struct FfnO { size_t w1, b1, w2, b2; };
+    struct NormO { size_t w, b; };
+    auto attn = [&]() {
+        AttnO o;
+        std::vector<float> w((size_t)3 * D * D), b((size_t)3 * D);
+        for (int part = 0; part < 3; ++part) {
+            std::memcpy(&w[(size_t)part * D * D], t[k + 2 * part], sizeof(float) * D * D);
+            std::memcpy(&b[(size_t)part * D], t[k + 2 * part + 1], sizeof(float) * D);
+        }
+        o.wqkv = put(w.data(), w.size());
+        o.bqkv = put(b.data(), b.size());
+        o.wo = put(t[k + 6], (size_t)D * D);
+        o.bo = put(t[k + 7], D);
+        k += 8;
+        return o;
+    };
+    auto ffn_o = [&]() {
+        FfnO o{put(t[k], (size_t)dff * D), put(t[k + 1], dff), put(t[k + 2], (size_t)D * dff), put(t[k + 3], D)};
+        k += 4;
+        return o;
+    };
+    auto norm = [&]() {
+        NormO o{put(t[k], D), put(t[k + 1], D)};
+        k += 2;
+        return o;
+    };
+    const size_t o_etok = tok(t[0]), o_epe = put(t[1], (size_t)d->pe_rows * D), o_dtok = tok(t[2]), o_dpe = put(t[3], (size_t)d->pe_rows * D);
+    k = 4;
+    struct EncO { AttnO a; FfnO f; NormO n1, n2; };
+    struct DecO { AttnO s, c; FfnO f; NormO n1, n2, n3; };
+    std::vector<EncO> eo(d->e_layers);
+    for (EncO& o : eo) { o.a = attn(); o.f = ffn_o(); o.n1 = norm(); o.n2 = norm(); }
+    const NormO o_en = norm();
+    std::vector<DecO> dofs(d->d_layers);
+    for (DecO& o : dofs) { o.s = attn(); o.c = attn(); o.f = ffn_o(); o.n1 = norm(); o.n2 = norm(); o.n3 = norm(); }
+    const NormO o_dn = norm();
+    const size_t o_pw = put(t[k], (size_t)d->c_out * D), o_pb = put(t[k + 1], d->c_out);
+    k += 2;
+    struct ProjO { size_t conv, w[5], b[4]; };
+    auto proj = [&](int n_out) {
+        ProjO o{};
+        o.conv = put(t[k++], (size_t)S * 3);
+        int n_in = 2 * F;
+        for (int i = 0; i < d->p_layers; ++i) {
+            o.w[i] = put(t[k++], (size_t)d->p_hidden[i] * n_in);
+            o.b[i] = put(t[k++], d->p_hidden[i]);
+            n_in = d->p_hidden[i];
+        }
+        o.w[d->p_layers] = put(t[k++], (size_t)n_out * n_in);
+        return o;
+    };
+    const ProjO o_tau = proj(1), o_delta = proj(S);
+    size_t o_z[8] = {};
+    if (d->latent)
+        for (int i = 0; i < 8; ++i) o_z[i] = put(t[k + i], (i & 1) ? (size_t)D : (size_t)D * D);
+    if (hipMalloc(&e->blob, host.size() * sizeof(float)) != hipSuccess) { delete e; return mpv_fail(ctx, MPV_ENOMEM, "mpv_nst_load: weight blob"); }
+    if (hipMemcpy(e->blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        nst_engine_destroy(e);
+        return mpv_fail(ctx, MPV_EHIP, "mpv_nst_load: upload failed");
+    }
+    auto P = [&](size_t off) { return (const float*)(e->blob + off); };
+    auto A = [&](const AttnO& o) { return AttnW{P(o.wqkv), P(o.bqkv), P(o.wo), P(o.bo)}; };
+    auto Fw = [&](const FfnO& o) { return FfnW{P(o.w1), P(o.b1), P(o.w2), P(o.b2)}; };
+    auto N = [&](const NormO& o) { return NormW{P(o.w), P(o.b)}; };
+    e->enc_tok = P(o_etok); e->enc_pe = P(o_epe); e->dec_tok = P(o_dtok); e->dec_pe = P(o_dpe);
+    for (const EncO& o : eo) e->enc.push_back(EncLayer{A(o.a), Fw(o.f), N(o.n1), N(o.n2)});
+    for (const DecO& o : dofs) e->dec.push_back(DecLayer{A(o.s), A(o.c), Fw(o.f), N(o.n1), N(o.n2), N(o.n3)});
+    e->enc_norm = N(o_en); e->dec_norm = N(o_dn);
+    e->proj_w = P(o_pw); e->proj_b = P(o_pb);
+    auto PW = [&](const ProjO& o) {
+        ProjW w{};
+        w.conv = P(o.conv);
+        for (int i = 0; i <= d->p_layers; ++i) w.w[i] = P(o.w[i]);
+        for (int i = 0; i < d->p_layers; ++i) w.b[i] = P(o.b[i]);
+        return w;
+    };
+    e->tau = PW(o_tau); e->delta = PW(o_delta);
+    if (d->latent)
+        for (int i = 0; i < 8; ++i) e->z[i] = P(o_z[i]);
+    ctx->nst = e;
+    return MPV_OK;
+}
+
+int mpv_nst_forward(mpv_ctx* ctx, const float* series, int32_t nodes, int64_t series_len, int32_t n_windows, int64_t first, int64_t step, const float* mean,
+                    const float* std, int32_t full, int64_t rows_per_pass, float* y0hat) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nst_forward: ctx is NULL");
+    if (!ctx->nst) return mpv_fail(ctx, MPV_ESTATE, "mpv_nst_forward: call mpv_nst_load first");
+    NstEngine& e = *ctx->nst;
+    if (!series || !y0hat || nodes < 1 || n_windows < 1 || first < 0 || step < 0 || (mean == nullptr) != (std == nullptr))
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_forward: bad argument");
+    if (first + (int64_t)(n_windows - 1) * step + e.d.seq_len > series_len)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_forward: the last window runs past the end of the series");
+    DeviceGuard dg(ctx->device);
+    const long long B = (long long)n_windows * nodes;
+    long long pass = rows_per_pass > 0 ? rows_per_pass : std::max<long long>(1, (long long)((6.0 * (1ull << 30) / sizeof(float)) / (double)per_row_floats(e.d)));
+    pass = std::min(pass, B);
+    NST_TRY(carve(ctx, e, pass));
+    const int n_keep = full ? e.d.label_len + e.d.pred_len : e.d.pred_len;
+    for (long long b0 = 0; b0 < B; b0 += pass) {
+        const long long nb = std::min(pass, B - b0);
+        NST_TRY(forward_pass(ctx, e, series, nodes, series_len, first, step, mean, std, b0, nb, full, y0hat + (size_t)b0 * n_keep * e.d.c_out));
+    }
+    return MPV_OK;
+}
+
+int mpv_nst_debug_tensor(mpv_ctx* ctx, int32_t which, float* out, int64_t capacity) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nst_debug_tensor: ctx is NULL");
+    if (!ctx->nst || ctx->nst->last_b < 1) return mpv_fail(ctx, MPV_ESTATE, "mpv_nst_debug_tensor: run mpv_nst_forward first");
+    NstEngine& e = *ctx->nst;
+    const long long B = e.last_b, S = e.d.seq_len, F = e.d.enc_in, D = e.d.d_model;
+    const float* src = nullptr;
+    long long n = 0;
+    switch (which) {
+        case 0: src = e.xn; n = B * S * F; break;
+        case 1: src = e.stats; n = B * 2 * F; break;
+        case 2: src = e.tau_v; n = B; break;
+        case 3: src = e.delta_v; n = B * S; break;
+        case 4: src = e.ey; n = B * S * D; break;          // encoder output (after the latent bottleneck when present)
+        default: return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_debug_tensor: unknown tensor id");
+    }
+    if (!out || capacity < n) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_debug_tensor: output too small (need " + std::to_string(n) + " floats)");
+    DeviceGuard dg(ctx->device);
+    MPV_HIP_TRY(ctx, hipMemcpyAsync(out, src, sizeof(float) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    return (int)0;
+}
+
+}  // extern "C"

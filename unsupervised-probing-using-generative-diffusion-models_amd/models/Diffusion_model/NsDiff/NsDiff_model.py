@@ -27,15 +27,15 @@ import torch
 import torch.nn as nn
 
 from . import g_backbone as G
+from . import mu_backbone as ns_Transformer
 from .NsDiff_net import NsDiff_net
 from .native_handle import NativeHandle
 
 _F_BACKBONE_MSG = (
-    "train_model_select={!r} needs the non-stationary-transformer mean backbone f(x) "
-    "(reference NsDiff/mu_backbone.py, built on the absent torch_timeseries package); that row of the scope "
-    "table (SURVEY.md 8f.1) has no HIP implementation.  Either pass a precomputed y_0_hat (`y0hat=`) or attach "
-    "your own backbone module with the reference's call signature `(batch_x, dec_inp) -> (y_0_hat, _)` via "
-    "`attach_backbone(module)`; everything after f(x) -- sigma head, sampler, reduction -- runs natively.")
+    "train_model_select={!r} needs the non-stationary-transformer mean backbone f(x) (reference NsDiff/mu_backbone.py), and "
+    "net_param lacks its hyper-parameters (" + ", ".join(ns_Transformer.CONFIG_KEYS) + "), so none was built.  Add them, or "
+    "pass a precomputed y_0_hat (`y0hat=`), or attach your own module with the reference's call signature "
+    "`(batch_x, dec_inp) -> (y_0_hat, _)` via `attach_backbone(module)`.")
 
 
 def _draw_seed() -> int:
@@ -67,8 +67,17 @@ class _NsDiffBase(nn.Module):
         object.__setattr__(self, "_native", NativeHandle())
         self._native.bind(self)
 
-    # ---- f(x): a user-supplied torch module (the backbone itself is not part of this library) -----------
+    # ---- f(x): the native ns-Transformer (mu_backbone.Model -> csrc/nst.hip) when net_param carries its hyper-parameters,
+    #      otherwise a user-supplied torch module ------------------------------------------------------------------
     needs_backbone = False
+
+    def _build_backbone(self, net_param):
+        if all(k in net_param for k in ns_Transformer.CONFIG_KEYS):
+            return ns_Transformer.Model(self.configs, native=self._native)
+        return None
+
+    def _native_backbone(self) -> bool:
+        return isinstance(getattr(self, "cond_pred_model", None), ns_Transformer.Model)
 
     def attach_backbone(self, module: nn.Module):
         """Install f(x) as `cond_pred_model` (same attribute name as the reference, so its checkpoint entries
@@ -82,9 +91,11 @@ class _NsDiffBase(nn.Module):
         return torch.cat([batch_x[:, -self.label_len:, :], zeros], dim=1)                  # reference :195-199
 
     def _backbone_mean(self, batch_x):
-        """y_0_hat of already scaled windows [B, windows, F] through the attached backbone (torch, caller's module)."""
+        """y_0_hat of already scaled windows [B, windows, F] through the backbone (native, or the caller's attached module)."""
         if getattr(self, "cond_pred_model", None) is None:
             raise NotImplementedError(_F_BACKBONE_MSG.format(getattr(self, "train_model_select", None)))
+        if self._native_backbone():
+            return self.cond_pred_model(batch_x)[0]
         dev = next(self.cond_pred_model.parameters(), torch.zeros(0, device=self.scaler_mean.device)).device
         with torch.no_grad():
             y0hat, _ = self.cond_pred_model(batch_x.to(dev), self._decoder_input(batch_x.to(dev)))
@@ -130,6 +141,8 @@ class _NsDiffBase(nn.Module):
         g = getattr(self, "cond_pred_model_g", None)
         if g is not None:
             ctx.load_sigma(g.seq_len, g.kernel_size, g.pred_len, g.enc_in, g.hidden_size, g.native_weights())
+        if self._native_backbone():
+            ctx.load_nst(self.cond_pred_model)
 
     def native_context(self):
         return self._native.context()
@@ -182,7 +195,10 @@ class _NsDiffBase(nn.Module):
         ctx = self._native.context()
         series = series.to(device=ctx.device, dtype=torch.float32).contiguous()
         gx = self._prior_variance(ctx, series, n_windows, first, step, scale_input)
-        if y0hat is None and self.needs_backbone:
+        if y0hat is None and self.needs_backbone and self._native_backbone():        # windows gathered by the kernel, scaler fused
+            y0hat = ctx.nst_forward(series, n_windows, first, step, self.scaler_mean if scale_input else None,
+                                    self.scaler_std if scale_input else None)
+        elif y0hat is None and self.needs_backbone:
             idx = first + step * torch.arange(n_windows, device=series.device).view(-1, 1) + torch.arange(self.windows, device=series.device)
             wins = series[:, idx, :].permute(1, 0, 2, 3).reshape(n_windows * series.shape[0], self.windows, -1)
             if scale_input:
@@ -236,7 +252,7 @@ class NsDiff_model_variants(_NsDiffBase):
             raise ValueError("train_model_select should be in Guassian/cond_mean/cond_var")
         self.needs_backbone = train_model_select in ("cond_mean", "wo_UANS")      # f(x): attach_backbone() or y0hat=
         self.model = NsDiff_net(self.configs, self.device)
-        self.cond_pred_model = None
+        self.cond_pred_model = self._build_backbone(net_param) if self.needs_backbone else None      # reference :299-311
         self.cond_pred_model_g = None
         if train_model_select in ("cond_var", "wo_UANS"):
             self.cond_pred_model_g = G.SigmaEstimation(self.windows, self.pred_len, self.dataset_nf, 512,
@@ -256,9 +272,8 @@ class NsDiff_model_variants(_NsDiffBase):
 
 
 class NsDiff_model(_NsDiffBase):
-    """Plain NsDiff (:17-268).  The g-only configuration ('pretrain_g', the shipped
-    ews_results/NsDiff_preg checkpoint) is native.  The full model needs f(x); until that
-    backbone is built, `evaluation_step(batch, y0hat=...)` samples around a supplied mean."""
+    """Plain NsDiff (:17-268): f(x) (csrc/nst.hip), g(x), sampler and reduction all native.  'pretrain_g' is the g-only
+    configuration of the shipped ews_results/NsDiff_preg checkpoint, 'pretrain_f' the f-only one."""
 
     def __init__(self, net_param, train_model_select, pretrain_f_path="results/pre_model_F",
                  pretrain_g_path="results/pre_model_G"):
@@ -271,13 +286,17 @@ class NsDiff_model(_NsDiffBase):
         if train_model_select == "pretrain_g":
             self.cond_pred_model_g = G.SigmaEstimation(self.windows, self.pred_len, self.dataset_nf, 512,
                                                        self.rolling_length, native=self._native)
-        elif train_model_select == "NsDiff_model":                 # f(x) attached by the caller, g(x) and sampler native
+        elif train_model_select == "NsDiff_model":
             self.needs_backbone = True
             self.model = NsDiff_net(self.configs, self.device)
+            self.cond_pred_model = self._build_backbone(net_param)
             self.cond_pred_model_g = G.SigmaEstimation(self.windows, self.pred_len, self.dataset_nf, 512,
                                                        self.rolling_length, native=self._native)
-        elif train_model_select == "pretrain_f":
-            raise NotImplementedError(_F_BACKBONE_MSG.format(train_model_select))
+        elif train_model_select == "pretrain_f":                   # f(x) alone (reference :88-91): no sampler to run
+            self.needs_backbone = True
+            self.cond_pred_model = self._build_backbone(net_param)
+            if self.cond_pred_model is None:
+                raise NotImplementedError(_F_BACKBONE_MSG.format(train_model_select))
         else:
             raise ValueError("train_model_select should be in ['NsDiff_model', 'pretrain_f', 'pretrain_g']")
 

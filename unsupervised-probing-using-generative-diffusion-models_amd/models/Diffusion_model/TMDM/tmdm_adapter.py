@@ -5,10 +5,10 @@ Same constructor (`TMDM_model(net_param)`), attribute names (`scaler`, `scaler_m
 `evaluation_step(batch) -> (outs [B, pred_len, F, n_z_samples] on CPU, batch_y | None)`.
 
 The sampler (epsilon MLP + CARD reverse loop + tile/un-tile, :122-155) runs in the fused HIP chain kernel.
-The prior `y_0_hat` (:122-123) is the mean head of the reference's ns-Transformer VAE, built on the
-third-party `torch_timeseries` layers that are absent here (parity unpinned).  It is
-therefore an INPUT: pass `y_0_hat=` to `evaluation_step`, or attach any module as `cond_pred_model` with the
-reference's call signature `(batch_x, None, dec_inp, None) -> (_, y_0_hat, _, _)`.
+The prior `y_0_hat` (:122-123) is the mean head of the reference's ns-Transformer VAE: `cond_pred_model` is the holder of
+tmdm_ns_transformer.py, run by csrc/nst.hip (its third-party `torch_timeseries` layers are restated -- SURVEY.md section 8c: parity
+unpinned).  `y_0_hat=` on `evaluation_step` overrides it, and any module with the reference's call signature
+`(batch_x, None, dec_inp, None) -> (_, y_0_hat, _, _)` may be assigned to `cond_pred_model` instead.
 
 Because the sampler is pointwise along the sequence, only the last `pred_len` of the `label_len + pred_len`
 positions (the ones the reference keeps, :152) are sampled.
@@ -23,11 +23,11 @@ import torch.nn as nn
 
 from ..NsDiff.native_handle import NativeHandle
 from ..NsDiff.NsDiff_model import _draw_seed
+from . import tmdm_ns_transformer as ns_Transformer
 from .TMDM import TMDM
 
-_PRIOR_MSG = ("TMDM's prior y_0_hat comes from the ns-Transformer VAE (reference TMDM/tmdm_ns_transformer.py on "
-              "the absent torch_timeseries package); it is not built.  Pass y_0_hat=[B, label_len+pred_len, F] "
-              "(or [B, pred_len, F]) to evaluation_step, or attach a module as `cond_pred_model`.")
+_PRIOR_MSG = ("TMDM's prior network was removed from this model (cond_pred_model is None).  Pass y_0_hat=[B, label_len+pred_len, F] "
+              "(or [B, pred_len, F]) to evaluation_step, or assign a module to `cond_pred_model`.")
 
 
 class TMDM_model(nn.Module):
@@ -50,13 +50,17 @@ class TMDM_model(nn.Module):
             raise ValueError("noise_source must be 'philox' or 'torch_cpu'")
         net_param.setdefault("enc_in", self.dataset_nf)
         net_param.setdefault("timesteps", self.diffusion_steps)
+        for key, default in (("dec_in", self.dataset_nf), ("c_out", self.dataset_nf), ("output_attention", False), ("d_model", 64), ("n_heads", 4),
+                             ("d_ff", 128), ("activation", "gelu"), ("e_layers", 2), ("d_layers", 1), ("p_hidden_dims", [64, 64]),
+                             ("p_hidden_layers", 2)):                          # the prior's defaults, reference :38-55
+            net_param.setdefault(key, default)
         self.configs = SimpleNamespace(**net_param)
         self.register_buffer("scaler_mean", torch.zeros(self.dataset_nf))
         self.register_buffer("scaler_std", torch.ones(self.dataset_nf))
         self.model = TMDM(self.configs, self.device)
-        self.cond_pred_model = None
         object.__setattr__(self, "_native", NativeHandle())
         self._native.bind(self)
+        self.cond_pred_model = ns_Transformer.Model(self.configs, native=self._native)        # reference :70
 
     # ---- scaler (:73-83) ------------------------------------------------------------
     def scaler_fit(self, data):
@@ -97,6 +101,8 @@ class TMDM_model(nn.Module):
         w = self.model.native_weights()
         ctx.load_tmdm(self.model.num_timesteps, self.dataset_nf, w["lin_w"], w["lin_b"], w["embed"], w["eps_w"],
                       w["eps_b"], w["coef"])
+        if isinstance(self.cond_pred_model, ns_Transformer.Model):
+            ctx.load_nst(self.cond_pred_model)
 
     def native_context(self):
         return self._native.context()
