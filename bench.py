@@ -277,6 +277,8 @@ def main():
                                      "value": n_windows * 3 / dt, "unit": "windows/s", "kernel_avg_ms": kms}
         log("other summary path: %.1f windows/s" % out["other_summary_path"]["value"])
         out["trained_checkpoints"] = trained_checkpoint_records(device)
+        out["full_nsdiff"] = full_nsdiff_record(device, sampled, n_windows)
+        log("full NsDiff (f + g + sampler): %.1f windows/s" % out["full_nsdiff"]["value"])
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         parity = cpu_baseline_and_parity(model, sampled, args.cpu_windows, [args.gemm] + others)
@@ -290,6 +292,49 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def full_nsdiff_record(device, sampled, n_windows):
+    """Secondary record: the same workload with `task_model: NsDiff` / `NsDiff_model`, i.e. with the mean backbone f(x) in front of
+    the sampler (the shipped NsDiff YAMLs' ns-Transformer: d_model 512, 8 heads, d_ff 256, 4 + 2 layers; seeded default init).  One
+    launch sequence per trajectory: f(x) over all windows (csrc/nst.hip), g(x), fused sampler + summary."""
+    from mpv_amd import synthetic
+    from mpv_amd.models.models import diffusion_models
+    net_param = dict(device=device, scaler_type="StandardScaler", task_model="NsDiff", rolling_length=CFG["rolling"], diffusion_schedule="linear",
+                     diffusion_steps=CFG["steps"], beta_start=1e-4, beta_end=0.02, n_z_samples=CFG["n_z"], parallel_sample=CFG["parallel_sample"],
+                     windows=CFG["windows"], pred_len=CFG["pred_len"], dataset_nf=CFG["nf"], load_pretrain=False, d_model=512, n_heads=8, d_ff=256,
+                     e_layers=4, d_layers=2, activation="gelu", p_hidden_dims=[64, 64], p_hidden_layers=2, output_attention=False)
+    model = diffusion_models("NsDiff", net_param, train_model_select="NsDiff_model").to(device).eval()
+    synthetic.seeded_nsdiff_state(model, sampled, seed=321)
+    series = sampled.to(device)
+    ctx = model.native_context()
+
+    def step(seed):
+        _, _, mpv, pm = model.sample_windows(series, n_windows, 0, CFG["window_step"], scale_input=True, seed=seed, summary=True, want_samples=False)
+        return torch.stack([mpv, pm]).cpu()
+
+    step(1)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(3):
+        curve = step(10 + i)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / 3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        ctx.nst_forward(series, n_windows, 0, CFG["window_step"], model.scaler_mean, model.scaler_std, gemm=model.cond_pred_model.gemm_mode)
+    e1.record()
+    torch.cuda.synchronize(device)
+    fx_ms = e0.elapsed_time(e1) / 3
+    S, Ld, D, dff = CFG["windows"], CFG["windows"] // 2 + CFG["pred_len"], 512, 256
+    enc = 2 * S * D * 3 * D + 4 * S * S * D + 2 * S * D * D + 4 * S * D * dff
+    dec = (2 * Ld * D * 3 * D + 2 * Ld * Ld * D + 2 * Ld * D * D) + (2 * Ld * D * D + 2 * S * D * 2 * D + 4 * Ld * S * D + 2 * Ld * D * D) + 4 * Ld * D * dff
+    flop = (4 * enc + 2 * dec) * CFG["nodes"] * n_windows
+    return {"value": n_windows / dt, "unit": "windows/s", "ms_per_step": dt * 1e3, "finite": bool(torch.isfinite(curve).all()),
+            "fx_ms_per_step": fx_ms, "fx_gflop_per_node": (4 * enc + 2 * dec) / 1e9, "fx_tflops_fp32_equivalent": flop / fx_ms / 1e9,
+            "fx_gemm": model.cond_pred_model.gemm_mode, "fx_frac_of_fp32_matrix_peak": flop / fx_ms / 1e9 / FP32_MATRIX_PEAK_TFLOPS,
+            "parity": "f(x) layers restated from the published ns-Transformer (torch-timeseries absent): parity unpinned"}
 
 
 def trained_checkpoint_records(device):

@@ -383,10 +383,12 @@ int mpv_nst_load(mpv_ctx* ctx, const mpv_nst_desc* desc, const float* const* ten
 
 /* series: dev [nodes][series_len][F]; window w covers [first + w*step, +seq_len) of every node; mean/std: dev [F] scaler fused into
  * the load or both NULL.  y0hat: dev [n_windows*nodes][pred_len][F] (full = 0: the reference's first return value) or
- * [n_windows*nodes][label_len+pred_len][F] (full = 1: its second).  rows_per_pass: window rows per pass over the layers
- * (0 = sized to a 6 GB workspace). */
+ * [n_windows*nodes][label_len+pred_len][F] (full = 1: its second).  gemm: MPV_GEMM_F16X3 (two-term f16 split of weights and
+ * activations, fp32-equivalent, 3 f16 MFMAs per product) or MPV_GEMM_F32 (exact fp32 pipe) for the Linear layers; attention,
+ * LayerNorm and everything else are fp32 either way.  rows_per_pass: window rows per pass over the layers (0 = sized to a 6 GB
+ * workspace). */
 int mpv_nst_forward(mpv_ctx* ctx, const float* series, int32_t nodes, int64_t series_len, int32_t n_windows, int64_t first, int64_t step,
-                    const float* mean, const float* std, int32_t full, int64_t rows_per_pass, float* y0hat);
+                    const float* mean, const float* std, int32_t full, int32_t gemm, int64_t rows_per_pass, float* y0hat);
 
 /* Validation helper: intermediate of the LAST pass of the last mpv_nst_forward call.  which: 0 normalised window [B][S][F],
  * 1 statistics [B][2][F] (mean, std), 2 tau [B], 3 delta [B][S], 4 encoder output [B][S][D]. */

@@ -49,18 +49,21 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("gemm", ["f16x3", "f32"])
 @pytest.mark.parametrize("tag", list(CASES))
-def test_forward_matches_the_restatement(tag):
+def test_forward_matches_the_restatement(tag, gemm):
     O = oracle()
     kw, B, latent = CASES[tag]
     cfg = O.config(**kw)
     sd = O.random_state(cfg, seed=len(tag), latent=latent)
     m, f = holder(cfg, sd, latent)
+    f.gemm_mode = gemm
     torch.manual_seed(3)
     x = torch.randn(B, cfg.seq_len, cfg.dataset_nf).cumsum(1) * 0.3 + torch.randn(B, 1, cfg.dataset_nf)
     want_pred, want_full = O.forward(sd, cfg, x, latent=latent)
     out = f(x.to(dev()), None, None, None) if latent else f(x.to(dev()), None)
     assert tuple(out[0].shape) == tuple(want_pred.shape) and tuple(out[1].shape) == tuple(want_full.shape)
+    print(tag, gemm, "rel_err", rel_err(out[1], want_full))
     assert rel_err(out[1], want_full) < RTOL, rel_err(out[1], want_full)
     assert rel_err(out[0], want_pred) < RTOL
     if not latent:

@@ -1,0 +1,44 @@
+// Stand-alone timing of the f(x) Linear-layer kernels (csrc/nst_gemm.h) on the shapes of one 2168-row pass of BASELINE configs[1]:
+// where does the time of a 128x128 output tile go -- main loop, global loads, epilogue?
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -I <pkg>/csrc tools/ubench/gemm_h3.hip -o /tmp/gemm_h3 && /tmp/gemm_h3
+#include <cstdio>
+#include <vector>
+#include "nst_gemm.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+template <int PROBE>
+float run(const GemmHArgs& a, int reps) {
+    const long long tiles = ((a.M + G_BM - 1) / G_BM) * ((a.N + G_BN - 1) / G_BN);
+    const dim3 grid((unsigned)(8 * ((tiles + 7) / 8)));
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(nst_gemm_h3_kernel<PROBE>, grid, dim3(256), 0, 0, a);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(nst_gemm_h3_kernel<PROBE>, grid, dim3(256), 0, 0, a);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+
+int main() {
+    const long long M = 216800;
+    struct Shape { int N, K; int act; bool res; const char* name; } shapes[] = {
+        {1536, 512, 0, false, "qkv"}, {512, 512, 0, true, "out+res"}, {256, 512, 2, false, "ffn1 gelu"}, {512, 256, 0, true, "ffn2+res"}};
+    float *X, *Y, *R, *bias;
+    _Float16 *Wh, *Wl;
+    CK(hipMalloc(&X, M * 1536 * 4)); CK(hipMalloc(&Y, M * 1536 * 4)); CK(hipMalloc(&R, M * 512 * 4)); CK(hipMalloc(&bias, 1536 * 4));
+    CK(hipMalloc(&Wh, 1536 * 512 * 2)); CK(hipMalloc(&Wl, 1536 * 512 * 2));
+    CK(hipMemset(X, 0, M * 1536 * 4)); CK(hipMemset(R, 0, M * 512 * 4)); CK(hipMemset(bias, 0, 1536 * 4)); CK(hipMemset(Wh, 0, 1536 * 512 * 2));
+    CK(hipMemset(Wl, 0, 1536 * 512 * 2));
+    for (const Shape& s : shapes) {
+        GemmHArgs a{X, s.K, Wh, Wl, 1.0f, bias, s.res ? R : nullptr, 512, Y, s.N, M, s.N, s.K, s.act};
+        const double gf = 2.0 * M * s.N * s.K / 1e9;
+        const float full = run<0>(a, 5), nostore = run<1>(a, 5), onek = run<2>(a, 5), noload = run<4>(a, 5), loop_only = run<5>(a, 5);
+        printf("%-10s N=%4d K=%3d: full %.3f ms (%.0f TF/s) | no stores %.3f | one k-tile %.3f | no loads in loop %.3f | no loads, no stores %.3f\n", s.name, s.N, s.K,
+               full, gf / full, nostore, onek, noload, loop_only);
+    }
+    return 0;
+}

@@ -154,7 +154,7 @@ def load_library():
         "mpv_dts_debug_tensor": (C.c_int, [vp, C.c_char_p, i32, vp, i64]),
         "mpv_dts_sample": (C.c_int, [vp, C.POINTER(DtsSampleShape), vp, _F, vp, vp]),
         "mpv_nst_load": (C.c_int, [vp, C.POINTER(NstDesc), C.POINTER(_F), i32]),
-        "mpv_nst_forward": (C.c_int, [vp, vp, i32, i64, i32, i64, i64, vp, vp, i32, i64, vp]),
+        "mpv_nst_forward": (C.c_int, [vp, vp, i32, i64, i32, i64, i64, vp, vp, i32, i32, i64, vp]),
         "mpv_nst_debug_tensor": (C.c_int, [vp, i32, vp, i64]),
         "mpv_chain_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i64)]),
         "mpv_chain_timing_enable": (C.c_int, [vp, C.c_int]),
@@ -458,10 +458,12 @@ class Context:
         self.nst = d
 
     def nst_forward(self, series: torch.Tensor, n_windows: int, first: int = 0, step: int = 1, mean: Optional[torch.Tensor] = None,
-                    std: Optional[torch.Tensor] = None, full: bool = False, rows_per_pass: int = 0) -> torch.Tensor:
+                    std: Optional[torch.Tensor] = None, full: bool = False, rows_per_pass: int = 0, gemm: str = "f16x3") -> torch.Tensor:
         """series [V, L, F] on device -> y_0_hat [n_windows, V, pred_len (or label_len + pred_len when full), F]."""
         if self.nst is None:
             raise MpvError("f(x) weights not loaded")
+        if gemm not in ("f16x3", "f32"):
+            raise MpvError("f(x) supports gemm 'f16x3' and 'f32'")
         if series.dim() != 3 or series.shape[2] != self.nst.enc_in:
             raise MpvError("series must be [V, L, {}], got {}".format(self.nst.enc_in, tuple(series.shape)))
         V, L, F = series.shape
@@ -471,7 +473,7 @@ class Context:
         sd = None if std is None else std.to(self.device, torch.float32).contiguous()
         self._bind_stream()
         self._check(self.lib.mpv_nst_forward(self._h, _dev_ptr(series, self.device, "series"), V, L, int(n_windows), int(first), int(step),
-                                             _dev_ptr(m, self.device, "mean"), _dev_ptr(sd, self.device, "std"), int(bool(full)), int(rows_per_pass),
+                                             _dev_ptr(m, self.device, "mean"), _dev_ptr(sd, self.device, "std"), int(bool(full)), GEMM_MODES[gemm], int(rows_per_pass),
                                              _dev_ptr(out, self.device, "y0hat")), "mpv_nst_forward")
         return out
 

@@ -10,25 +10,25 @@
 //   nst_prepare_kernel   per b: gather the window from the resident series (scaler fused), series statistics, normalised window,
 //                        both Projector MLPs (tau = exp(.), delta[seq_len])                                    HBM, tiny
 //   nst_embed_kernel     circular k=3 token convolution + position table; the decoder input [x_norm[-label:], 0] is formed on the fly
-//   nst_gemm_kernel      Y = act(X W^T + b) (+ R): 128x128x32 LDS tiles, double buffered, exact-fp32 v_mfma_f32_32x32x2_f32   MFMA
+//   nst_gemm_h3_kernel   Y = act(X W^T + b) (+ R): 128x128x32 LDS tiles; two-term f16 split of both operands, three
+//                        v_mfma_f32_32x32x16_f16 per k-step, fp32 accumulate (fp32-equivalent, the default)       MFMA
+//   nst_gemm_kernel      the same contraction on the exact-fp32 pipe (v_mfma_f32_32x32x2_f32), gemm = MPV_GEMM_F32  MFMA
 //   nst_attn_kernel      de-stationary attention softmax(scale (q.k tau + delta)) v, causal option; online softmax (base 2) over
 //                        128-key chunks, S^T accumulators reused as the B operand of the P.V product; v_mfma_f32_16x16x4_f32   MFMA
 //   nst_ln_kernel        LayerNorm of a row (the residual is added in the producing GEMM's epilogue)           HBM
 //   nst_head_kernel      decoder.norm + Linear(d_model, c_out) + de-normalisation, only the rows that are returned
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <new>
 
 #include "mpv_common.h"
 
+#include "nst_gemm.h"
+
 namespace {
 
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef float v16f __attribute__((ext_vector_type(16)));
-
 constexpr float LOG2E = 1.44269504088896341f;
-
-__device__ __forceinline__ float nst_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -175,119 +175,6 @@ __global__ __launch_bounds__(256) void nst_embed_kernel(const EmbedArgs p) {
         }
     }
     *reinterpret_cast<v4f*>(p.out + (size_t)row * p.D + c) = val + acc;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// GEMM  Y[M][N] = act(X[M][K] W[N][K]^T + bias) + R
-// ---------------------------------------------------------------------------------------------------------------------
-struct GemmArgs {
-    const float* X; long long ldx;
-    const float* W;           // [N][K]
-    const float* bias;        // [N] | null
-    const float* R; long long ldr;     // residual | null
-    float* Y; long long ldy;
-    long long M;
-    int N, K;
-    int act;                  // 0 none, 1 relu, 2 gelu
-};
-
-constexpr int G_BM = 128, G_BN = 128, G_BK = 32, G_LD = G_BK + 4;
-
-__global__ __launch_bounds__(256, 2) void nst_gemm_kernel(const GemmArgs p) {
-    extern __shared__ float sm[];
-    float* As = sm;                               // [2][G_BM][G_LD]
-    float* Bs = sm + 2 * G_BM * G_LD;             // [2][G_BN][G_LD]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const long long m0 = (long long)blockIdx.x * G_BM;
-    const int n0 = blockIdx.y * G_BN;
-    // global -> register staging: thread covers rows (tid>>3) + 32 j, j = 0..3, k quad (tid & 7)
-    const int lr = tid >> 3, lk = (tid & 7) * 4;
-    const float* xa[4];
-    const float* wb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        long long r = m0 + lr + 32 * j;
-        if (r >= p.M) r = p.M - 1;
-        xa[j] = p.X + (size_t)r * p.ldx + lk;
-        int n = n0 + lr + 32 * j;
-        if (n >= p.N) n = p.N - 1;
-        wb[j] = p.W + (size_t)n * p.K + lk;
-    }
-    v4f ra[4], rb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { ra[j] = *reinterpret_cast<const v4f*>(xa[j]); rb[j] = *reinterpret_cast<const v4f*>(wb[j]); }
-    v16f acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<v4f*>(As + (size_t)(lr + 32 * j) * G_LD + lk) = ra[j];
-        *reinterpret_cast<v4f*>(Bs + (size_t)(lr + 32 * j) * G_LD + lk) = rb[j];
-    }
-    __syncthreads();
-    const int nk = p.K / G_BK;
-    const int li = lane & 31, lh = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ra[j] = *reinterpret_cast<const v4f*>(xa[j] + (size_t)(kt + 1) * G_BK);
-                rb[j] = *reinterpret_cast<const v4f*>(wb[j] + (size_t)(kt + 1) * G_BK);
-            }
-        }
-        const float* a_base = As + (size_t)cur * G_BM * G_LD + (size_t)(wm * 64 + li) * G_LD + 4 * lh;
-        const float* b_base = Bs + (size_t)cur * G_BN * G_LD + (size_t)(wn * 64 + li) * G_LD + 4 * lh;
-#pragma unroll
-        for (int k8 = 0; k8 < G_BK / 8; ++k8) {
-            v4f a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const v4f*>(a_base + (size_t)i * 32 * G_LD + 8 * k8);
-                b[i] = *reinterpret_cast<const v4f*>(b_base + (size_t)i * 32 * G_LD + 8 * k8);
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            float* an = As + (size_t)(cur ^ 1) * G_BM * G_LD;
-            float* bn = Bs + (size_t)(cur ^ 1) * G_BN * G_LD;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *reinterpret_cast<v4f*>(an + (size_t)(lr + 32 * j) * G_LD + lk) = ra[j];
-                *reinterpret_cast<v4f*>(bn + (size_t)(lr + 32 * j) * G_LD + lk) = rb[j];
-            }
-        }
-        __syncthreads();
-    }
-    // epilogue: accumulator (i, j) register r holds row wm*64 + i*32 + (r&3) + 8 (r>>2) + 4 lh, column wn*64 + j*32 + li
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + li;
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-                float y = acc[i][j][r] + bias;
-                if (p.act == 1) y = fmaxf(y, 0.0f);
-                else if (p.act == 2) y = nst_gelu(y);
-                if (p.R) y += p.R[(size_t)m * p.ldr + n];
-                p.Y[(size_t)m * p.ldy + n] = y;
-            }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -501,8 +388,15 @@ __global__ __launch_bounds__(256) void nst_head_kernel(const HeadArgs p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // engine
 // ---------------------------------------------------------------------------------------------------------------------
-struct AttnW { const float *wqkv, *bqkv, *wo, *bo; };       // wqkv rows: q (D), k (D), v (D)
-struct FfnW { const float *w1, *b1, *w2, *b2; };
+struct Mat {                                                 // one Linear weight [N][K]: fp32, and its scaled two-term f16 split
+    const float* w = nullptr;
+    const _Float16* h = nullptr;
+    const _Float16* l = nullptr;
+    float inv_scale = 1.0f;
+    int K = 0;
+};
+struct AttnW { Mat wqkv; const float* bqkv; Mat wo; const float* bo; };       // wqkv rows: q (D), k (D), v (D)
+struct FfnW { Mat w1; const float* b1; Mat w2; const float* b2; };
 struct NormW { const float *w, *b; };
 struct EncLayer { AttnW att; FfnW ffn; NormW n1, n2; };
 struct DecLayer { AttnW self, cross; FfnW ffn; NormW n1, n2, n3; };
@@ -516,7 +410,10 @@ struct NstEngine {
     NormW enc_norm{}, dec_norm{};
     const float *proj_w = nullptr, *proj_b = nullptr;
     ProjW tau{}, delta{};
-    const float* z[8] = {};
+    Mat zw[4];
+    const float* zb[4] = {};
+    _Float16* blob16 = nullptr;
+    int gemm_mode = MPV_GEMM_F16X3;
     float* ws = nullptr;
     size_t ws_floats = 0;
     long long cap_b = 0;
@@ -529,6 +426,7 @@ struct NstEngine {
 void nst_engine_destroy(NstEngine* e) {
     if (!e) return;
     if (e->blob) (void)hipFree(e->blob);
+    if (e->blob16) (void)hipFree(e->blob16);
     if (e->ws) (void)hipFree(e->ws);
     delete e;
 }
@@ -573,17 +471,25 @@ int carve(mpv_ctx* ctx, NstEngine& e, long long B) {
     return MPV_OK;
 }
 
-int gemm(mpv_ctx* ctx, const float* X, long long ldx, const float* W, const float* bias, const float* R, long long ldr, float* Y, long long ldy, long long M, int N,
-         int K, int act) {
-    GemmArgs a{X, ldx, W, bias, R, ldr, Y, ldy, M, N, K, act};
-    const size_t lds = sizeof(float) * 2 * (G_BM + G_BN) * G_LD;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(nst_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+// Y = act(X W[row0 : row0 + N]^T + bias) + R
+int gemm(mpv_ctx* ctx, const NstEngine& e, const float* X, long long ldx, const Mat& W, int row0, const float* bias, const float* R, long long ldr, float* Y,
+         long long ldy, long long M, int N, int act) {
+    const int K = W.K;
+    const long long tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
+    const dim3 grid((unsigned)(8 * ((tiles + 7) / 8)));
+    if (e.gemm_mode == MPV_GEMM_F32) {
+        GemmArgs a{X, ldx, W.w + (size_t)row0 * K, bias, R, ldr, Y, ldy, M, N, K, act};
+        const size_t lds = sizeof(float) * 2 * (G_BM + G_BN) * G_LD;
+        static bool attr_set = false;
+        if (!attr_set) {
+            MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(nst_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(nst_gemm_kernel, grid, dim3(256), lds, ctx->stream, a);
+    } else {
+        GemmHArgs a{X, ldx, W.h + (size_t)row0 * K, W.l + (size_t)row0 * K, W.inv_scale, bias, R, ldr, Y, ldy, M, N, K, act};
+        hipLaunchKernelGGL(nst_gemm_h3_kernel<0>, grid, dim3(256), 0, ctx->stream, a);
     }
-    const dim3 grid((unsigned)((M + G_BM - 1) / G_BM), (unsigned)((N + G_BN - 1) / G_BN));
-    hipLaunchKernelGGL(nst_gemm_kernel, grid, dim3(256), lds, ctx->stream, a);
     MPV_HIP_TRY(ctx, hipGetLastError());
     return MPV_OK;
 }
@@ -609,8 +515,8 @@ int attention(mpv_ctx* ctx, const NstEngine& e, const float* Q, long long ldq, c
 
 int ffn(mpv_ctx* ctx, NstEngine& e, const FfnW& f, const float* x, float* y, long long rows) {
     const int D = e.d.d_model, dff = e.d.d_ff, act = e.d.activation ? 2 : 1;
-    NST_TRY(gemm(ctx, x, D, f.w1, f.b1, nullptr, 0, e.hid, dff, rows, dff, D, act));
-    return gemm(ctx, e.hid, dff, f.w2, f.b2, x, D, y, D, rows, D, dff, 0);           // + residual
+    NST_TRY(gemm(ctx, e, x, D, f.w1, 0, f.b1, nullptr, 0, e.hid, dff, rows, dff, act));
+    return gemm(ctx, e, e.hid, dff, f.w2, 0, f.b2, x, D, y, D, rows, D, 0);           // + residual
 }
 
 // one pass over B window rows starting at global row b0
@@ -634,9 +540,9 @@ int forward_pass(mpv_ctx* ctx, NstEngine& e, const float* series, int V, long lo
     }
     const long long Me = B * S, Md = B * Ld;
     for (const EncLayer& l : e.enc) {
-        NST_TRY(gemm(ctx, e.ex, D, l.att.wqkv, l.att.bqkv, nullptr, 0, e.qkv, 3 * D, Me, 3 * D, D, 0));
+        NST_TRY(gemm(ctx, e, e.ex, D, l.att.wqkv, 0, l.att.bqkv, nullptr, 0, e.qkv, 3 * D, Me, 3 * D, 0));
         NST_TRY(attention(ctx, e, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, e.delta_v, e.att, B, S, S, 0));
-        NST_TRY(gemm(ctx, e.att, D, l.att.wo, l.att.bo, e.ex, D, e.ey, D, Me, D, D, 0));
+        NST_TRY(gemm(ctx, e, e.att, D, l.att.wo, 0, l.att.bo, e.ex, D, e.ey, D, Me, D, 0));
         NST_TRY(layer_norm(ctx, e.ey, e.ex, l.n1, Me, D));
         NST_TRY(ffn(ctx, e, l.ffn, e.ex, e.ey, Me));
         NST_TRY(layer_norm(ctx, e.ey, e.ex, l.n2, Me, D));
@@ -644,10 +550,10 @@ int forward_pass(mpv_ctx* ctx, NstEngine& e, const float* series, int V, long lo
     NST_TRY(layer_norm(ctx, e.ex, e.ey, e.enc_norm, Me, D));
     float* enc_out = e.ey;
     if (d.latent) {                       // tmdm_ns_transformer.py:155-162, eval mode: z = z_mean(enc); enc = z_out(z)
-        NST_TRY(gemm(ctx, e.ey, D, e.z[0], e.z[1], nullptr, 0, e.ex, D, Me, D, D, 1));
-        NST_TRY(gemm(ctx, e.ex, D, e.z[2], e.z[3], nullptr, 0, e.ey, D, Me, D, D, 0));
-        NST_TRY(gemm(ctx, e.ey, D, e.z[4], e.z[5], nullptr, 0, e.ex, D, Me, D, D, 1));
-        NST_TRY(gemm(ctx, e.ex, D, e.z[6], e.z[7], nullptr, 0, e.ey, D, Me, D, D, 0));
+        NST_TRY(gemm(ctx, e, e.ey, D, e.zw[0], 0, e.zb[0], nullptr, 0, e.ex, D, Me, D, 1));
+        NST_TRY(gemm(ctx, e, e.ex, D, e.zw[1], 0, e.zb[1], nullptr, 0, e.ey, D, Me, D, 0));
+        NST_TRY(gemm(ctx, e, e.ey, D, e.zw[2], 0, e.zb[2], nullptr, 0, e.ex, D, Me, D, 1));
+        NST_TRY(gemm(ctx, e, e.ex, D, e.zw[3], 0, e.zb[3], nullptr, 0, e.ey, D, Me, D, 0));
     }
     // decoder
     {
@@ -657,14 +563,14 @@ int forward_pass(mpv_ctx* ctx, NstEngine& e, const float* series, int V, long lo
     }
     float* ckv = e.qkv + (size_t)B * std::max(S, Ld) * 3 * D;       // cross K | V  [B*S][2D]
     for (const DecLayer& l : e.dec) {
-        NST_TRY(gemm(ctx, e.dx, D, l.self.wqkv, l.self.bqkv, nullptr, 0, e.qkv, 3 * D, Md, 3 * D, D, 0));
+        NST_TRY(gemm(ctx, e, e.dx, D, l.self.wqkv, 0, l.self.bqkv, nullptr, 0, e.qkv, 3 * D, Md, 3 * D, 0));
         NST_TRY(attention(ctx, e, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, nullptr, e.att, B, Ld, Ld, 1));
-        NST_TRY(gemm(ctx, e.att, D, l.self.wo, l.self.bo, e.dx, D, e.dy, D, Md, D, D, 0));
+        NST_TRY(gemm(ctx, e, e.att, D, l.self.wo, 0, l.self.bo, e.dx, D, e.dy, D, Md, D, 0));
         NST_TRY(layer_norm(ctx, e.dy, e.dx, l.n1, Md, D));
-        NST_TRY(gemm(ctx, e.dx, D, l.cross.wqkv, l.cross.bqkv, nullptr, 0, e.qkv, D, Md, D, D, 0));                                   // q
-        NST_TRY(gemm(ctx, enc_out, D, l.cross.wqkv + (size_t)D * D, l.cross.bqkv + D, nullptr, 0, ckv, 2 * D, Me, 2 * D, D, 0));        // k | v
+        NST_TRY(gemm(ctx, e, e.dx, D, l.cross.wqkv, 0, l.cross.bqkv, nullptr, 0, e.qkv, D, Md, D, 0));                      // q
+        NST_TRY(gemm(ctx, e, enc_out, D, l.cross.wqkv, D, l.cross.bqkv + D, nullptr, 0, ckv, 2 * D, Me, 2 * D, 0));       // k | v
         NST_TRY(attention(ctx, e, e.qkv, D, ckv, 2 * D, ckv + D, 2 * D, e.delta_v, e.att, B, Ld, S, 0));
-        NST_TRY(gemm(ctx, e.att, D, l.cross.wo, l.cross.bo, e.dx, D, e.dy, D, Md, D, D, 0));
+        NST_TRY(gemm(ctx, e, e.att, D, l.cross.wo, 0, l.cross.bo, e.dx, D, e.dy, D, Md, D, 0));
         NST_TRY(layer_norm(ctx, e.dy, e.dx, l.n2, Md, D));
         NST_TRY(ffn(ctx, e, l.ffn, e.dx, e.dy, Md));
         NST_TRY(layer_norm(ctx, e.dy, e.dx, l.n3, Md, D));
@@ -709,6 +615,34 @@ int mpv_nst_load(mpv_ctx* ctx, const mpv_nst_desc* d, const float* const* t, int
     e->d = *d;
     std::vector<float> host;
     auto put = [&](const float* p, size_t n) { const size_t at = host.size(); host.insert(host.end(), p, p + n); host.resize((host.size() + 3) & ~size_t(3)); return at; };
+    // a Linear weight [N][K]: fp32 copy + two-term f16 split of w * 2^s, s chosen so the largest entry lands in [2^13, 2^14)
+    std::vector<_Float16> host16;
+    struct MatO { size_t w, h, l; float inv; int K; };
+    auto put_mat = [&](const float* w, size_t N, int K) {
+        MatO o{};
+        o.w = put(w, N * K);
+        o.K = K;
+        float mx = 0.0f;
+        for (size_t i = 0; i < N * K; ++i) mx = std::max(mx, std::fabs(w[i]));
+        int ex = 0;
+        if (mx > 0.0f && std::isfinite(mx)) { (void)std::frexp(mx, &ex); ex = 14 - ex; }      // mx * 2^ex in [2^13, 2^14)
+        const float sc = std::ldexp(1.0f, ex);
+        o.inv = std::ldexp(1.0f, -ex);
+        o.h = host16.size();
+        host16.resize(host16.size() + 2 * N * K);
+        o.l = o.h + N * K;
+        for (size_t i = 0; i < N * K; ++i) {
+            const float v = w[i] * sc;
+            uint32_t bits;
+            std::memcpy(&bits, &v, 4);
+            bits &= 0xFFFFE000u;
+            float hi;
+            std::memcpy(&hi, &bits, 4);
+            host16[o.h + i] = (_Float16)hi;
+            host16[o.l + i] = (_Float16)(v - hi);
+        }
+        return o;
+    };
     int k = 0;
     auto tok = [&](const float* w) {       // [D][F][3] -> [F][3][D]
         std::vector<float> o((size_t)F * 3 * D);
@@ -717,8 +651,8 @@ int mpv_nst_load(mpv_ctx* ctx, const mpv_nst_desc* d, const float* const* t, int
                 for (int tap = 0; tap < 3; ++tap) o[((size_t)f * 3 + tap) * D + c] = w[((size_t)c * F + f) * 3 + tap];
         return put(o.data(), o.size());
     };
-    struct AttnO { size_t wqkv, bqkv, wo, bo; };
-    struct FfnO { size_t w1, b1, w2, b2; };
+    struct AttnO { MatO wqkv; size_t bqkv; MatO wo; size_t bo; };
+    struct FfnO { MatO w1; size_t b1; MatO w2; size_t b2; };
     struct NormO { size_t w, b; };
     auto attn = [&]() {
         AttnO o;
@@ -727,15 +661,15 @@ int mpv_nst_load(mpv_ctx* ctx, const mpv_nst_desc* d, const float* const* t, int
             std::memcpy(&w[(size_t)part * D * D], t[k + 2 * part], sizeof(float) * D * D);
             std::memcpy(&b[(size_t)part * D], t[k + 2 * part + 1], sizeof(float) * D);
         }
-        o.wqkv = put(w.data(), w.size());
+        o.wqkv = put_mat(w.data(), (size_t)3 * D, D);
         o.bqkv = put(b.data(), b.size());
-        o.wo = put(t[k + 6], (size_t)D * D);
+        o.wo = put_mat(t[k + 6], D, D);
         o.bo = put(t[k + 7], D);
         k += 8;
         return o;
     };
     auto ffn_o = [&]() {
-        FfnO o{put(t[k], (size_t)dff * D), put(t[k + 1], dff), put(t[k + 2], (size_t)D * dff), put(t[k + 3], D)};
+        FfnO o{put_mat(t[k], dff, D), put(t[k + 1], dff), put_mat(t[k + 2], D, dff), put(t[k + 3], D)};
         k += 4;
         return o;
     };
@@ -770,17 +704,21 @@ int mpv_nst_load(mpv_ctx* ctx, const mpv_nst_desc* d, const float* const* t, int
         return o;
     };
     const ProjO o_tau = proj(1), o_delta = proj(S);
-    size_t o_z[8] = {};
+    MatO o_zw[4] = {};
+    size_t o_zb[4] = {};
     if (d->latent)
-        for (int i = 0; i < 8; ++i) o_z[i] = put(t[k + i], (i & 1) ? (size_t)D : (size_t)D * D);
+        for (int i = 0; i < 4; ++i) { o_zw[i] = put_mat(t[k + 2 * i], D, D); o_zb[i] = put(t[k + 2 * i + 1], D); }
     if (hipMalloc(&e->blob, host.size() * sizeof(float)) != hipSuccess) { delete e; return mpv_fail(ctx, MPV_ENOMEM, "mpv_nst_load: weight blob"); }
-    if (hipMemcpy(e->blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMalloc(&e->blob16, host16.size() * sizeof(_Float16)) != hipSuccess) { nst_engine_destroy(e); return mpv_fail(ctx, MPV_ENOMEM, "mpv_nst_load: f16 weight blob"); }
+    if (hipMemcpy(e->blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(e->blob16, host16.data(), host16.size() * sizeof(_Float16), hipMemcpyHostToDevice) != hipSuccess) {
         nst_engine_destroy(e);
         return mpv_fail(ctx, MPV_EHIP, "mpv_nst_load: upload failed");
     }
     auto P = [&](size_t off) { return (const float*)(e->blob + off); };
-    auto A = [&](const AttnO& o) { return AttnW{P(o.wqkv), P(o.bqkv), P(o.wo), P(o.bo)}; };
-    auto Fw = [&](const FfnO& o) { return FfnW{P(o.w1), P(o.b1), P(o.w2), P(o.b2)}; };
+    auto M_ = [&](const MatO& o) { Mat m; m.w = P(o.w); m.h = e->blob16 + o.h; m.l = e->blob16 + o.l; m.inv_scale = o.inv; m.K = o.K; return m; };
+    auto A = [&](const AttnO& o) { return AttnW{M_(o.wqkv), P(o.bqkv), M_(o.wo), P(o.bo)}; };
+    auto Fw = [&](const FfnO& o) { return FfnW{M_(o.w1), P(o.b1), M_(o.w2), P(o.b2)}; };
     auto N = [&](const NormO& o) { return NormW{P(o.w), P(o.b)}; };
     e->enc_tok = P(o_etok); e->enc_pe = P(o_epe); e->dec_tok = P(o_dtok); e->dec_pe = P(o_dpe);
     for (const EncO& o : eo) e->enc.push_back(EncLayer{A(o.a), Fw(o.f), N(o.n1), N(o.n2)});
@@ -796,18 +734,20 @@ int mpv_nst_load(mpv_ctx* ctx, const mpv_nst_desc* d, const float* const* t, int
     };
     e->tau = PW(o_tau); e->delta = PW(o_delta);
     if (d->latent)
-        for (int i = 0; i < 8; ++i) e->z[i] = P(o_z[i]);
+        for (int i = 0; i < 4; ++i) { e->zw[i] = M_(o_zw[i]); e->zb[i] = P(o_zb[i]); }
     ctx->nst = e;
     return MPV_OK;
 }
 
 int mpv_nst_forward(mpv_ctx* ctx, const float* series, int32_t nodes, int64_t series_len, int32_t n_windows, int64_t first, int64_t step, const float* mean,
-                    const float* std, int32_t full, int64_t rows_per_pass, float* y0hat) {
+                    const float* std, int32_t full, int32_t gemm, int64_t rows_per_pass, float* y0hat) {
     if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nst_forward: ctx is NULL");
     if (!ctx->nst) return mpv_fail(ctx, MPV_ESTATE, "mpv_nst_forward: call mpv_nst_load first");
     NstEngine& e = *ctx->nst;
     if (!series || !y0hat || nodes < 1 || n_windows < 1 || first < 0 || step < 0 || (mean == nullptr) != (std == nullptr))
         return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_forward: bad argument");
+    if (gemm != MPV_GEMM_F16X3 && gemm != MPV_GEMM_F32) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_forward: gemm must be MPV_GEMM_F16X3 or MPV_GEMM_F32");
+    e.gemm_mode = gemm;
     if (first + (int64_t)(n_windows - 1) * step + e.d.seq_len > series_len)
         return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_forward: the last window runs past the end of the series");
     DeviceGuard dg(ctx->device);

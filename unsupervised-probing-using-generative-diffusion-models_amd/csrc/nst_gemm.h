@@ -1,0 +1,301 @@
+// f(x) backbone, Linear layers: Y[M][N] = act(X[M][K] W[N][K]^T + bias) + R on the matrix cores of gfx950 (included by nst.hip and by
+// tools/ubench/gemm_h3.hip, which times the kernels alone).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float nst_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GEMM  Y[M][N] = act(X[M][K] W[N][K]^T + bias) + R
+// ---------------------------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const float* X; long long ldx;
+    const float* W;           // [N][K]
+    const float* bias;        // [N] | null
+    const float* R; long long ldr;     // residual | null
+    float* Y; long long ldy;
+    long long M;
+    int N, K;
+    int act;                  // 0 none, 1 relu, 2 gelu
+};
+
+constexpr int G_BM = 128, G_BN = 128, G_BK = 32, G_LD = G_BK + 4;
+
+// Workgroup id -> output tile.  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: XCD x takes the x-th
+// contiguous eighth of the tile list, in which the N tiles of one 128-row block of X are neighbours -- they run at the same time
+// on the same XCD, so the X block is fetched from HBM once and served to the others by that L2 (the weights, a few MB, stay
+// resident in every L2).  Returns false for the padding workgroups of the last chunk.
+__device__ __forceinline__ bool gemm_tile(long long M, int N, long long& m0, int& n0) {
+    const long long n_n = (N + G_BN - 1) / G_BN, total = ((M + G_BM - 1) / G_BM) * n_n;
+    const long long per = (total + 7) / 8, id = blockIdx.x;
+    const long long t = (id & 7) * per + (id >> 3);
+    if ((id >> 3) >= per || t >= total) return false;
+    m0 = (t / n_n) * G_BM;
+    n0 = (int)(t % n_n) * G_BN;
+    return true;
+}
+
+__global__ __launch_bounds__(256, 2) void nst_gemm_kernel(const GemmArgs p) {
+    extern __shared__ float sm[];
+    float* As = sm;                               // [2][G_BM][G_LD]
+    float* Bs = sm + 2 * G_BM * G_LD;             // [2][G_BN][G_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    long long m0;
+    int n0;
+    if (!gemm_tile(p.M, p.N, m0, n0)) return;
+    // global -> register staging: thread covers rows (tid>>3) + 32 j, j = 0..3, k quad (tid & 7)
+    const int lr = tid >> 3, lk = (tid & 7) * 4;
+    const float* xa[4];
+    const float* wb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        long long r = m0 + lr + 32 * j;
+        if (r >= p.M) r = p.M - 1;
+        xa[j] = p.X + (size_t)r * p.ldx + lk;
+        int n = n0 + lr + 32 * j;
+        if (n >= p.N) n = p.N - 1;
+        wb[j] = p.W + (size_t)n * p.K + lk;
+    }
+    v4f ra[4], rb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ra[j] = *reinterpret_cast<const v4f*>(xa[j]); rb[j] = *reinterpret_cast<const v4f*>(wb[j]); }
+    v16f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<v4f*>(As + (size_t)(lr + 32 * j) * G_LD + lk) = ra[j];
+        *reinterpret_cast<v4f*>(Bs + (size_t)(lr + 32 * j) * G_LD + lk) = rb[j];
+    }
+    __syncthreads();
+    const int nk = p.K / G_BK;
+    const int li = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ra[j] = *reinterpret_cast<const v4f*>(xa[j] + (size_t)(kt + 1) * G_BK);
+                rb[j] = *reinterpret_cast<const v4f*>(wb[j] + (size_t)(kt + 1) * G_BK);
+            }
+        }
+        const float* a_base = As + (size_t)cur * G_BM * G_LD + (size_t)(wm * 64 + li) * G_LD + 4 * lh;
+        const float* b_base = Bs + (size_t)cur * G_BN * G_LD + (size_t)(wn * 64 + li) * G_LD + 4 * lh;
+#pragma unroll
+        for (int k8 = 0; k8 < G_BK / 8; ++k8) {
+            v4f a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const v4f*>(a_base + (size_t)i * 32 * G_LD + 8 * k8);
+                b[i] = *reinterpret_cast<const v4f*>(b_base + (size_t)i * 32 * G_LD + 8 * k8);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            float* an = As + (size_t)(cur ^ 1) * G_BM * G_LD;
+            float* bn = Bs + (size_t)(cur ^ 1) * G_BN * G_LD;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<v4f*>(an + (size_t)(lr + 32 * j) * G_LD + lk) = ra[j];
+                *reinterpret_cast<v4f*>(bn + (size_t)(lr + 32 * j) * G_LD + lk) = rb[j];
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue: accumulator (i, j) register r holds row wm*64 + i*32 + (r&3) + 8 (r>>2) + 4 lh, column wn*64 + j*32 + li
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + li;
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float y = acc[i][j][r] + bias;
+                if (p.act == 1) y = fmaxf(y, 0.0f);
+                else if (p.act == 2) y = nst_gelu(y);
+                if (p.R) y += p.R[(size_t)m * p.ldr + n];
+                p.Y[(size_t)m * p.ldy + n] = y;
+            }
+    }
+}
+
+// The same GEMM on the f16 matrix pipe at fp32-equivalent accuracy (the split the chain sampler uses): every
+// operand is the sum of two f16 numbers, x = hi + lo with hi = x truncated to 11 significant bits (exact in f16) and lo = x - hi,
+// and the product is hi*hi + hi*lo + lo*hi in fp32 accumulators (the dropped lo*lo term is 2^-22 relative).  Weights are split
+// once at load, scaled by a power of two per matrix so that lo stays a normal f16; activations are split while the tile is
+// written to LDS.  Three v_mfma_f32_32x32x16_f16 per k-step of 16: 5.3x the fp32 pipe's rate.  Inputs must fit f16's range
+// (|x| < 65504): every GEMM of this network reads a LayerNorm output, an attention average of such, or a GELU/ReLU of one.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+
+struct GemmHArgs {
+    const float* X; long long ldx;
+    const _Float16* Wh; const _Float16* Wl;     // [N][K] each
+    float inv_scale;                            // 1 / (power of two the weights were scaled by)
+    const float* bias;
+    const float* R; long long ldr;
+    float* Y; long long ldy;
+    long long M;
+    int N, K;
+    int act;
+};
+
+constexpr int H_LD = G_BK + 8;                  // halves per LDS row
+
+// PROBE (tools/ubench/gemm_h3.hip only): 1 no epilogue stores, 2 one k-tile, 4 no global loads inside the loop
+template <int PROBE = 0>
+__global__ __launch_bounds__(256, 2) void nst_gemm_h3_kernel(const GemmHArgs p) {
+    __shared__ _Float16 Ah[G_BM * H_LD];
+    __shared__ _Float16 Al[G_BM * H_LD];
+    __shared__ _Float16 Bh[G_BN * H_LD];
+    __shared__ _Float16 Bl[G_BN * H_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    long long m0;
+    int n0;
+    if (!gemm_tile(p.M, p.N, m0, n0)) return;
+    const int lr = tid >> 3, lk = (tid & 7) * 4;           // X: rows lr + 32 j, 4 floats at lk
+    const int wr = tid >> 2, wk = (tid & 3) * 8;           // W: rows wr + 64 j, 8 halves at wk
+    const float* xa[4];
+    const _Float16* wh[2];
+    const _Float16* wl[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        long long r = m0 + lr + 32 * j;
+        if (r >= p.M) r = p.M - 1;
+        xa[j] = p.X + (size_t)r * p.ldx + lk;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int n = n0 + wr + 64 * j;
+        if (n >= p.N) n = p.N - 1;
+        wh[j] = p.Wh + (size_t)n * p.K + wk;
+        wl[j] = p.Wl + (size_t)n * p.K + wk;
+    }
+    // Two register sets of staged tiles, so that a global load has two compute phases to land before it is written to LDS.
+    struct Stage { v4f x[4]; h8 h[2], l[2]; };
+    Stage sa, sb;
+    auto fetch = [&](Stage& st, int kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st.x[j] = *reinterpret_cast<const v4f*>(xa[j] + (size_t)kt * G_BK);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            st.h[j] = *reinterpret_cast<const h8*>(wh[j] + (size_t)kt * G_BK);
+            st.l[j] = *reinterpret_cast<const h8*>(wl[j] + (size_t)kt * G_BK);
+        }
+    };
+    auto stash = [&](const Stage& st) {                    // split the activations, write the tile to LDS
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float hi[4], lo[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float v = st.x[j][c];
+                hi[c] = __uint_as_float(__float_as_uint(v) & 0xFFFFE000u);
+                lo[c] = v - hi[c];
+            }
+            u2 ph, pl;
+            ph[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hi[0], hi[1]));
+            ph[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hi[2], hi[3]));
+            pl[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo[0], lo[1]));
+            pl[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo[2], lo[3]));
+            *reinterpret_cast<u2*>(Ah + (lr + 32 * j) * H_LD + lk) = ph;
+            *reinterpret_cast<u2*>(Al + (lr + 32 * j) * H_LD + lk) = pl;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<h8*>(Bh + (wr + 64 * j) * H_LD + wk) = st.h[j];
+            *reinterpret_cast<h8*>(Bl + (wr + 64 * j) * H_LD + wk) = st.l[j];
+        }
+    };
+    v16f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int nk = (PROBE & 2) ? 1 : p.K / G_BK;
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_off = (wm * 64 + li) * H_LD + 8 * lh;
+    const int b_off = (wn * 64 + li) * H_LD + 8 * lh;
+    auto compute = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < G_BK / 16; ++ks) {
+            h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const h8*>(Ah + a_off + i * 32 * H_LD + 16 * ks);
+                al[i] = *reinterpret_cast<const h8*>(Al + a_off + i * 32 * H_LD + 16 * ks);
+                bh[i] = *reinterpret_cast<const h8*>(Bh + b_off + i * 32 * H_LD + 16 * ks);
+                bl[i] = *reinterpret_cast<const h8*>(Bl + b_off + i * 32 * H_LD + 16 * ks);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    fetch(sa, 0);
+    stash(sa);
+    if (nk > 1) fetch(sa, 1);
+    if (nk > 2) fetch(sb, 2);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        compute();                                         // tile kt
+        if (kt + 1 >= nk) break;
+        __syncthreads();
+        stash(sa);                                         // tile kt + 1
+        __syncthreads();
+        if (!(PROBE & 4) && kt + 3 < nk) fetch(sa, kt + 3);
+        compute();                                         // tile kt + 1
+        if (kt + 2 >= nk) break;
+        __syncthreads();
+        stash(sb);                                         // tile kt + 2
+        __syncthreads();
+        if (!(PROBE & 4) && kt + 4 < nk) fetch(sb, kt + 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + li;
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float y = acc[i][j][r] * p.inv_scale + bias;
+                if (p.act == 1) y = fmaxf(y, 0.0f);
+                else if (p.act == 2) y = nst_gelu(y);
+                if (p.R) y += p.R[(size_t)m * p.ldr + n];
+                if (!(PROBE & 1) || y == 1.2345e30f) p.Y[(size_t)m * p.ldy + n] = y;
+            }
+    }
+}
+
+}  // namespace

@@ -197,7 +197,7 @@ class _NsDiffBase(nn.Module):
         gx = self._prior_variance(ctx, series, n_windows, first, step, scale_input)
         if y0hat is None and self.needs_backbone and self._native_backbone():        # windows gathered by the kernel, scaler fused
             y0hat = ctx.nst_forward(series, n_windows, first, step, self.scaler_mean if scale_input else None,
-                                    self.scaler_std if scale_input else None)
+                                    self.scaler_std if scale_input else None, gemm=self.cond_pred_model.gemm_mode)
         elif y0hat is None and self.needs_backbone:
             idx = first + step * torch.arange(n_windows, device=series.device).view(-1, 1) + torch.arange(self.windows, device=series.device)
             wins = series[:, idx, :].permute(1, 0, 2, 3).reshape(n_windows * series.shape[0], self.windows, -1)

@@ -101,9 +101,12 @@ class Model(nn.Module):
     """Non-stationary Transformer f(x).  `latent=True` adds TMDM's z_mean / z_logvar / z_out heads (tmdm_ns_transformer.py:98-118)."""
 
     latent = False
+    gemm_mode = "f16x3"      # Linear layers: "f16x3" (two-term f16 split, fp32-equivalent) | "f32" (exact fp32 matrix pipe)
 
     def __init__(self, configs, native=None, enc_in=None):
         super().__init__()
+        if getattr(configs, "gemm_mode", "f16x3") == "f32":
+            self.gemm_mode = "f32"
         self.pred_len, self.seq_len, self.label_len = configs.pred_len, configs.seq_len, configs.label_len
         self.output_attention = getattr(configs, "output_attention", False)
         if self.output_attention:
@@ -161,7 +164,7 @@ class Model(nn.Module):
             raise RuntimeError("the backbone is not attached to a native handle")
         ctx = self._native.context(self)
         series = x_enc.to(device=ctx.device, dtype=torch.float32).contiguous()
-        return ctx.nst_forward(series, 1, 0, 1, full=True)[0]                  # [B, label_len + pred_len, F]
+        return ctx.nst_forward(series, 1, 0, 1, full=True, gemm=self.gemm_mode)[0]          # [B, label_len + pred_len, F]
 
     def forward(self, x_enc, x_dec=None, enc_self_mask=None, dec_self_mask=None, dec_enc_mask=None):
         """(batch_x [B, seq_len, F], dec_inp) -> (dec_out[:, -pred_len:], dec_out)   (reference :150-183)."""
