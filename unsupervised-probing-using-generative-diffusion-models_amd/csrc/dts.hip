@@ -19,7 +19,9 @@ struct DecW {
     const float *wq2, *bq2, *wkv2, *bkv2, *wp2, *bp2, *wq2_t, *wkv2_t, *wp2_t;
     const float *tw0, *tb0, *tw3, *tb3;
     const float *w0, *b0, *w2, *b2, *w0_t, *w2_t;
-    const float *wproj, *bproj, *wproj_t;          // padded [Mp][Kp]
+    // proj (Conv1d L -> 2L over the token axis) is never applied on its own: its first half is folded into the trend block's first
+    // convolution (tw0 / tb0x below are the composites) and its second half into the real-DFT basis of the Fourier layer
+    const float *wdft, *bdft, *wdft_t;             // [2 NFp][Lp] = DFT basis x proj[L:], its row bias, and the transpose [L][2 NFp]
     const float *wlin, *blin;
 };
 
@@ -32,7 +34,7 @@ struct DtsEngine {
     std::vector<EncW> enc;
     std::vector<DecW> dec;
     const float *wemb = nullptr, *bemb = nullptr, *winv = nullptr, *binv = nullptr, *wcs = nullptr, *wcm = nullptr, *pe_enc = nullptr,
-                *pe_dec = nullptr, *ada = nullptr, *freq = nullptr, *poly = nullptr, *dft = nullptr, *cosT = nullptr, *sinT = nullptr;
+                *pe_dec = nullptr, *ada = nullptr, *freq = nullptr, *poly = nullptr, *cosT = nullptr, *sinT = nullptr;
     // workspace (one allocation, grow-only)
     float* ws = nullptr;
     size_t ws_floats = 0;
@@ -43,9 +45,9 @@ struct DtsEngine {
     struct DecS { float *qkv1, *att1, *lse1, *x1, *q2, *kv2, *att2, *lse2, *x2, *u, *t3; int* fidx; };
     std::vector<EncS> es;
     std::vector<DecS> dsv;
-    float *pr = nullptr, *spec = nullptr, *famp = nullptr, *fph = nullptr, *x3 = nullptr, *trend_sum = nullptr, *season_sum = nullptr,
+    float *spec = nullptr, *famp = nullptr, *fph = nullptr, *x3 = nullptr, *trend_sum = nullptr, *season_sum = nullptr,
           *means = nullptr, *trend = nullptr, *season = nullptr;
-    float *gA = nullptr, *gB = nullptr, *gC = nullptr, *gwide = nullptr, *gqkv = nullptr, *gkv = nullptr, *genc = nullptr, *gpr = nullptr,
+    float *gA = nullptr, *gB = nullptr, *gC = nullptr, *gwide = nullptr, *gqkv = nullptr, *gkv = nullptr, *genc = nullptr,
           *delta = nullptr, *gseason = nullptr, *gmeans = nullptr, *gout = nullptr, *gx = nullptr;
     // sampler state [B][L][F]
     float *img = nullptr, *target = nullptr, *xstart = nullptr, *pmean = nullptr, *noise = nullptr;
@@ -184,11 +186,11 @@ int carve(mpv_ctx* ctx, DtsEngine& e, int B) {
     for (auto& o : dofs)
         o = DO_{take(T * 3 * D), take(T * D), take(BH), take(T * D), take(T * D), take(T * 2 * D), take(T * D), take(BH), take(T * D),
                 take(T * e.M), take((size_t)B * 3 * D), take((size_t)B * e.topk * D)};
-    const size_t o_pr = take(2 * T * D), o_spec = take((size_t)B * 2 * e.NFp * D), o_famp = take((size_t)B * e.topk * D),
+    const size_t o_spec = take((size_t)B * 2 * e.NFp * D), o_famp = take((size_t)B * e.topk * D),
                  o_fph = take((size_t)B * e.topk * D), o_x3 = take(T * D), o_ts = take(T * F), o_ss = take(T * D),
                  o_means = take((size_t)B * e.d.n_dec * F), o_trend = take(T * F), o_season = take(T * F);
     const size_t o_gA = take(T * D), o_gB = take(T * D), o_gC = take(T * D), o_gw = take(T * e.M), o_gqkv = take(T * 3 * D), o_gkv = take(T * 2 * D),
-                 o_genc = take(T * D), o_gpr = take(2 * T * D), o_delta = take(BH), o_gs = take(T * D), o_gm = take((size_t)B * e.d.n_dec * F),
+                 o_genc = take(T * D), o_delta = take(BH), o_gs = take(T * D), o_gm = take((size_t)B * e.d.n_dec * F),
                  o_gout = take(T * F), o_gx = take(T * F);
     const size_t o_img = take(T * F), o_tgt = take(T * F), o_xs = take(T * F), o_pm = take(T * F), o_nz = take(T * F);
     if (e.ws) {
@@ -213,9 +215,9 @@ int carve(mpv_ctx* ctx, DtsEngine& e, int B) {
         e.dsv[i] = DtsEngine::DecS{w + o.qkv1, w + o.att1, w + o.lse1, w + o.x1, w + o.q2, w + o.kv2, w + o.att2, w + o.lse2, w + o.x2, w + o.u, w + o.t3,
                                    reinterpret_cast<int*>(w + o.fidx)};
     }
-    e.pr = w + o_pr; e.spec = w + o_spec; e.famp = w + o_famp; e.fph = w + o_fph; e.x3 = w + o_x3; e.trend_sum = w + o_ts; e.season_sum = w + o_ss;
+    e.spec = w + o_spec; e.famp = w + o_famp; e.fph = w + o_fph; e.x3 = w + o_x3; e.trend_sum = w + o_ts; e.season_sum = w + o_ss;
     e.means = w + o_means; e.trend = w + o_trend; e.season = w + o_season;
-    e.gA = w + o_gA; e.gB = w + o_gB; e.gC = w + o_gC; e.gwide = w + o_gw; e.gqkv = w + o_gqkv; e.gkv = w + o_gkv; e.genc = w + o_genc; e.gpr = w + o_gpr;
+    e.gA = w + o_gA; e.gB = w + o_gB; e.gC = w + o_gC; e.gwide = w + o_gw; e.gqkv = w + o_gqkv; e.gkv = w + o_gkv; e.genc = w + o_genc;
     e.delta = w + o_delta; e.gseason = w + o_gs; e.gmeans = w + o_gm; e.gout = w + o_gout; e.gx = w + o_gx;
     e.img = w + o_img; e.target = w + o_tgt; e.xstart = w + o_xs; e.pmean = w + o_pm; e.noise = w + o_nz;
     return MPV_OK;
@@ -266,12 +268,12 @@ int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t, bool save)
         AttnArgs a2{s.q2, s.kv2, s.kv2 + D, D, 2 * D, 2 * D, nullptr, nullptr, D, s.att2, D, nullptr, 0, s.lse2, nullptr, H, L, L, e.hd, scale};
         DTS_TRY(attn(ctx, 0, a2, B));
         DTS_TRY(lin(ctx, s.att2, D, w.wp2, w.bp2, D, D, T, s.x2, D, PRO_NONE, nullptr, nullptr, 0, s.x1, D));
-        // proj: Conv1d(L -> 2L, k=1) over the token axis, then trend (first L rows) and season (last L rows)
-        DTS_TRY(seqmix(ctx, D, w.wproj, e.L2p, e.Lp, w.bproj, s.x2, (long long)L * D, D, L, e.pr, 2LL * L * D, D, 2 * L, B));
-        hipLaunchKernelGGL(dts_trend_fwd_kernel, dim3(B), dim3(256), sizeof(float) * (3 * D + 3 * F), st, e.pr, 2LL * L * D, w.tw0, w.tb0, w.tw3, w.tb3,
+        // proj (Conv1d(L -> 2L, k=1) over the token axis) folded into its two consumers: trend block on x2 with composite taps, and
+        // the selected spectrum as ONE token mix with (DFT basis x proj[L:])
+        hipLaunchKernelGGL(dts_trend_fwd_kernel, dim3(B), dim3(256), sizeof(float) * (3 * D + 3 * F), st, s.x2, (long long)L * D, w.tw0, w.tb0, w.tw3, w.tb3,
                            e.poly, L, F, D, s.t3, e.trend_sum);
         MPV_HIP_TRY(ctx, hipGetLastError());
-        DTS_TRY(seqmix(ctx, D, e.dft, 2 * e.NFp, e.Lp, nullptr, e.pr + (long long)L * D, 2LL * L * D, D, L, e.spec, 2LL * e.NFp * D, D, 2 * e.NFp, B));
+        DTS_TRY(seqmix(ctx, D, w.wdft, 2 * e.NFp, e.Lp, w.bdft, s.x2, (long long)L * D, D, L, e.spec, 2LL * e.NFp * D, D, 2 * e.NFp, B));
         hipLaunchKernelGGL(dts_fourier_select_kernel, g1d((long long)B * D), dim3(256), 0, st, e.spec, e.NF, e.NFp, D, e.topk, (long long)B * D, s.fidx,
                            e.famp, e.fph);
         hipLaunchKernelGGL(dts_fourier_synth_kernel, g1d(T * D), dim3(256), 0, st, s.fidx, e.famp, e.fph, e.freq + 1, L, D, e.topk, T * D, e.season_sum);
@@ -329,12 +331,11 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
         DTS_TRY(lin(ctx, e.gwide, M, w.w0_t, nullptr, M, D, T, e.gC, D, PRO_GELUGRAD, s.u, nullptr, M));
         DTS_TRY(ln_bwd(ctx, D, e.gC, s.x2, w.ln2w, 0, gcur, 1, T));     // gcur = d_x2 (so far)
         // trend / season branches through proj
-        hipLaunchKernelGGL(dts_trend_bwd_kernel, dim3(B), dim3(256), sizeof(float) * (3 * F + 3 * D), st, gout, s.t3, w.tw0, w.tw3, e.poly, L, F, D, e.gpr,
-                           2LL * L * D);
-        hipLaunchKernelGGL(dts_fourier_bwd_kernel, dim3(B), dim3(256), sizeof(float) * 2 * e.topk * D, st, e.gseason, s.fidx, e.cosT, e.sinT, L, D, e.topk,
-                           e.gpr, 2LL * L * D);
+        hipLaunchKernelGGL(dts_trend_bwd_kernel, dim3(B), dim3(256), sizeof(float) * (3 * F + 3 * D), st, gout, s.t3, w.tw0, w.tw3, e.poly, L, F, D, gcur,
+                           (long long)L * D);
+        hipLaunchKernelGGL(dts_fourier_bwd_kernel, dim3(B), dim3(256), sizeof(float) * 2 * e.topk * D, st, e.gseason, s.fidx, e.cosT, e.sinT, w.wdft_t, L, D,
+                           e.topk, e.NFp, gcur, (long long)L * D);
         MPV_HIP_TRY(ctx, hipGetLastError());
-        DTS_TRY(seqmix(ctx, D, w.wproj_t, e.Lp, e.L2p, nullptr, e.gpr, 2LL * L * D, D, 2 * L, gcur, (long long)L * D, D, L, B, 1));
         // x2 = x1 + proj2(attn2(q2(ln1_1(x1)), kv2(enc)))
         DTS_TRY(lin(ctx, gcur, D, w.wp2_t, nullptr, D, D, T, e.gC, D));                      // d_att2
         DTS_TRY(attn_bwd(ctx, e, B, s.q2, D, s.kv2, s.kv2 + D, 2 * D, s.att2, e.gC, s.lse2, e.gqkv, D, e.gkv, e.gkv + D, 2 * D));
@@ -433,6 +434,9 @@ int mpv_dts_load(mpv_ctx* ctx, const mpv_dts_desc* d, const float* const* tensor
     o.push_back(put(T_[0], (size_t)D * F * 3)); o.push_back(put(T_[1], D)); o.push_back(put(T_[2], (size_t)F * D * 3)); o.push_back(put(T_[3], F));
     o.push_back(put(T_[4], (size_t)F * D * d->combine_taps)); o.push_back(put(T_[5], d->n_dec)); o.push_back(put(T_[6], (size_t)L * D));
     o.push_back(put(T_[7], (size_t)L * D));
+    const double two_pi = 6.283185307179586476925286766559;
+    std::vector<double> dcos(L), dsin(L);                                // angles reduced exactly mod L
+    for (int m = 0; m < L; ++m) { dcos[m] = std::cos(two_pi * m / L); dsin[m] = std::sin(two_pi * m / L); }
     int k = 8;
     for (int i = 0; i < d->n_enc; ++i, k += 14) {
         // order: ln2.w, ln2.b, key.w, key.b, query.w, query.b, value.w, value.b, proj.w, proj.b, mlp0.w, mlp0.b, mlp2.w, mlp2.b
@@ -459,32 +463,63 @@ int mpv_dts_load(mpv_ctx* ctx, const mpv_dts_desc* d, const float* const* tensor
         o.push_back(put(A2[2], DD)); o.push_back(put(A2[3], D)); o.push_back(putv(wkv2)); o.push_back(putv(bkv2)); o.push_back(put(A2[6], DD));
         o.push_back(put(A2[7], D));
         o.push_back(putv(transposed2(A2[2], D, D))); o.push_back(putv(transposed2(wkv2.data(), 2 * D, D))); o.push_back(putv(transposed2(A2[6], D, D)));
-        o.push_back(put(T_[k + 18], (size_t)3 * L * 3)); o.push_back(put(T_[k + 19], 3)); o.push_back(put(T_[k + 20], (size_t)F * D * 3));
+        // trend.0 (Conv1d L -> 3, k=3 along D) composed with proj[:L]:  Wt[p][l'][tap] = sum_l w0[p][l][tap] Wp[l][l'], and its bias per (p, d):
+        // b0[p] + sum_tap [0 <= d+tap-1 < D] sum_l w0[p][l][tap] bp[l]   (zero padding along D drops the proj bias at the borders)
+        {
+            const float* w0 = T_[k + 18]; const float* b0 = T_[k + 19]; const float* Wp = T_[k + 26]; const float* bp = T_[k + 27];
+            std::vector<float> wt((size_t)3 * L * 3), bx((size_t)3 * D);
+            for (int p = 0; p < 3; ++p) {
+                double cb[3] = {0, 0, 0};
+                for (int tap = 0; tap < 3; ++tap) {
+                    for (int lp = 0; lp < L; ++lp) {
+                        double a = 0.0;
+                        for (int l = 0; l < L; ++l) a += (double)w0[((size_t)p * L + l) * 3 + tap] * (double)Wp[(size_t)l * L + lp];
+                        wt[((size_t)p * L + lp) * 3 + tap] = (float)a;
+                    }
+                    for (int l = 0; l < L; ++l) cb[tap] += (double)w0[((size_t)p * L + l) * 3 + tap] * (double)bp[l];
+                }
+                for (int dd = 0; dd < D; ++dd)
+                    bx[(size_t)p * D + dd] = (float)((double)b0[p] + (dd > 0 ? cb[0] : 0.0) + cb[1] + (dd + 1 < D ? cb[2] : 0.0));
+            }
+            o.push_back(putv(wt)); o.push_back(putv(bx));
+        }
+        o.push_back(put(T_[k + 20], (size_t)F * D * 3));
         o.push_back(put(T_[k + 21], F));
         o.push_back(put(T_[k + 22], MD)); o.push_back(put(T_[k + 23], e->M)); o.push_back(put(T_[k + 24], MD)); o.push_back(put(T_[k + 25], D));
         o.push_back(putv(transposed2(T_[k + 22], e->M, D))); o.push_back(putv(transposed2(T_[k + 24], D, e->M)));
-        o.push_back(putv(padded(T_[k + 26], 2 * L, L, e->L2p, e->Lp))); o.push_back(put(T_[k + 27], (size_t)2 * L));
-        const std::vector<float> pt = transposed2(T_[k + 26], 2 * L, L);                                  // [L][2L]
-        o.push_back(putv(padded(pt.data(), L, 2 * L, e->Lp, e->L2p)));
+        // real-DFT basis of bins 1..NF (rows [0, NF) cos, rows [NFp, NFp + NF) -sin) composed with proj[L:] and its bias
+        {
+            const float* Wp = T_[k + 26] + (size_t)L * L; const float* bp = T_[k + 27] + L;
+            std::vector<float> wd((size_t)2 * e->NFp * e->Lp, 0.0f), bd((size_t)2 * e->NFp, 0.0f), wdt((size_t)L * 2 * e->NFp, 0.0f);
+            std::vector<double> row(L);
+            for (int part = 0; part < 2; ++part)
+                for (int kk = 0; kk < e->NF; ++kk) {
+                    const int r = part * e->NFp + kk;
+                    std::fill(row.begin(), row.end(), 0.0);
+                    double bias = 0.0;
+                    for (int t = 0; t < L; ++t) {
+                        const int m = (int)(((long long)(kk + 1) * t) % L);
+                        const double basis = part == 0 ? dcos[m] : -dsin[m];
+                        bias += basis * (double)bp[t];
+                        const float* wr = Wp + (size_t)t * L;
+                        for (int lp = 0; lp < L; ++lp) row[lp] += basis * (double)wr[lp];
+                    }
+                    bd[r] = (float)bias;
+                    for (int lp = 0; lp < L; ++lp) {
+                        wd[(size_t)r * e->Lp + lp] = (float)row[lp];
+                        wdt[(size_t)lp * 2 * e->NFp + r] = (float)row[lp];
+                    }
+                }
+            o.push_back(putv(wd)); o.push_back(putv(bd)); o.push_back(putv(wdt));
+        }
         o.push_back(put(T_[k + 28], (size_t)F * D)); o.push_back(put(T_[k + 29], F));
     }
     const size_t o_ada = put(ada_tables, (size_t)d->timesteps * e->n_ada * 2 * D);
     const size_t o_freq = put(rfftfreq, (size_t)L / 2 + 1);
     const size_t o_poly = put(poly, (size_t)3 * L);
-    // real-DFT basis of bins 1..NF: rows [0, NF) cos(2 pi k t / L), rows [NFp, NFp + NF) -sin(.), angles reduced exactly mod L
-    std::vector<float> dft((size_t)2 * e->NFp * e->Lp, 0.0f), cosT(L), sinT(L);
-    const double two_pi = 6.283185307179586476925286766559;
-    for (int m = 0; m < L; ++m) {
-        cosT[m] = (float)std::cos(two_pi * m / L);
-        sinT[m] = (float)std::sin(two_pi * m / L);
-    }
-    for (int kk = 0; kk < e->NF; ++kk)
-        for (int t = 0; t < L; ++t) {
-            const int m = (int)(((long long)(kk + 1) * t) % L);
-            dft[(size_t)kk * e->Lp + t] = cosT[m];
-            dft[(size_t)(e->NFp + kk) * e->Lp + t] = -sinT[m];
-        }
-    const size_t o_dft = putv(dft), o_cos = putv(cosT), o_sin = putv(sinT);
+    std::vector<float> cosT(L), sinT(L);                                  // basis tables of the Fourier layer's transpose
+    for (int m = 0; m < L; ++m) { cosT[m] = (float)dcos[m]; sinT[m] = (float)dsin[m]; }
+    const size_t o_cos = putv(cosT), o_sin = putv(sinT);
     if (hipMalloc(&e->blob, host.size() * sizeof(float)) != hipSuccess) { delete e; return mpv_fail(ctx, MPV_ENOMEM, "mpv_dts_load: weight blob"); }
     if (hipMemcpy(e->blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         dts_engine_destroy(e);
@@ -505,9 +540,9 @@ int mpv_dts_load(mpv_ctx* ctx, const mpv_dts_desc* d, const float* const* tensor
         w.wq2 = nx(); w.bq2 = nx(); w.wkv2 = nx(); w.bkv2 = nx(); w.wp2 = nx(); w.bp2 = nx(); w.wq2_t = nx(); w.wkv2_t = nx(); w.wp2_t = nx();
         w.tw0 = nx(); w.tb0 = nx(); w.tw3 = nx(); w.tb3 = nx();
         w.w0 = nx(); w.b0 = nx(); w.w2 = nx(); w.b2 = nx(); w.w0_t = nx(); w.w2_t = nx();
-        w.wproj = nx(); w.bproj = nx(); w.wproj_t = nx(); w.wlin = nx(); w.blin = nx();
+        w.wdft = nx(); w.bdft = nx(); w.wdft_t = nx(); w.wlin = nx(); w.blin = nx();
     }
-    e->ada = e->blob + o_ada; e->freq = e->blob + o_freq; e->poly = e->blob + o_poly; e->dft = e->blob + o_dft; e->cosT = e->blob + o_cos;
+    e->ada = e->blob + o_ada; e->freq = e->blob + o_freq; e->poly = e->blob + o_poly; e->cosT = e->blob + o_cos;
     e->sinT = e->blob + o_sin;
     ctx->dts = e;
     return MPV_OK;

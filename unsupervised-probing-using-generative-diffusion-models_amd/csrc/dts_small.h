@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void dts_trend_fwd_kernel(const float* __restr
     const float* x1 = pr + (long long)b * pr_stride;
     for (int i = threadIdx.x; i < 3 * D; i += 256) {
         const int p = i / D, d = i - p * D;
-        float s = b0[p];
+        float s = b0[i];                                // bias per (p, d): see the composite built at load
         for (int l = 0; l < L; ++l) {
             const float* wr = w0 + (p * L + l) * 3;
             const float* xr = x1 + (long long)l * D;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void dts_trend_fwd_kernel(const float* __restr
     }
 }
 
-// g [B][L][F] -> d_x1 into rows [0, L) of dpr
+// g [B][L][F] -> d_x2 (through the composite taps) ADDED to dpr [B][L][D]
 __global__ __launch_bounds__(256) void dts_trend_bwd_kernel(const float* __restrict__ g, const float* __restrict__ t3_save, const float* __restrict__ w0,
                                                             const float* __restrict__ w3, const float* __restrict__ poly, int L, int F, int D,
                                                             float* dpr, long long pr_stride) {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void dts_trend_bwd_kernel(const float* __restr
             s += wr[1] * dt3[p * D + d];
             if (d > 0) s += wr[2] * dt3[p * D + d - 1];
         }
-        out[i] = s;
+        out[i] += s;
     }
 }
 
@@ -245,8 +245,9 @@ __global__ void dts_fourier_synth_kernel(const int* __restrict__ idx, const floa
 // selected bins, so d_x[t'] = 2 sum_j (C_j cos th_j t' + S_j sin th_j t'),  C_j = sum_t g[t] cos th_j t,  S_j = sum_t g[t] sin th_j t.
 // block per sequence; basis tables cosT/sinT[m] = cos/sin(2 pi m / L), m = (k t) mod L.
 __global__ __launch_bounds__(256) void dts_fourier_bwd_kernel(const float* __restrict__ g /*[B][L][D]*/, const int* __restrict__ idx,
-                                                              const float* __restrict__ cosT, const float* __restrict__ sinT, int L, int D, int topk,
-                                                              float* dpr, long long pr_stride) {
+                                                              const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                              const float* __restrict__ wdft_t /*[L][2 NFp]*/, int L, int D, int topk, int NFp, float* dx,
+                                                              long long dx_stride) {
     extern __shared__ float sm[];                 // C[topk][D], S[topk][D]
     float* Cs = sm;
     float* Ss = sm + topk * D;
@@ -267,16 +268,18 @@ __global__ __launch_bounds__(256) void dts_fourier_bwd_kernel(const float* __res
         Ss[i] = s;
     }
     __syncthreads();
-    float* out = dpr + (long long)b * pr_stride + (long long)L * D;   // rows [L, 2L)
+    // d_x2part[t'] = 2 sum_j (C_j cos th_j t' + S_j sin th_j t') pulled back through proj[L:]: with Mre = cos-basis x proj, Mim = -sin-basis x proj
+    // (rows kj and NFp + kj of the composite), d_x2[l'] += 2 sum_j (C_j Mre[kj][l'] - S_j Mim[kj][l'])
+    float* out = dx + (long long)b * dx_stride;
     for (int i = threadIdx.x; i < L * D; i += 256) {
-        const int t = i / D, d = i - t * D;
+        const int l = i / D, d = i - l * D;
+        const float* wr = wdft_t + (long long)l * 2 * NFp;
         float a = 0.0f;
         for (int j = 0; j < topk; ++j) {
-            const int k = idx[((long long)b * topk + j) * D + d] + 1;
-            const int m = (int)(((long long)k * t) % L);
-            a += Cs[j * D + d] * cosT[m] + Ss[j * D + d] * sinT[m];
+            const int kj = idx[((long long)b * topk + j) * D + d];
+            a += Cs[j * D + d] * wr[kj] - Ss[j * D + d] * wr[NFp + kj];
         }
-        out[i] = 2.0f * a;
+        out[i] += 2.0f * a;
     }
 }
 
