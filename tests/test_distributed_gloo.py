@@ -77,7 +77,7 @@ def _oracle_shard(sd, cfg):
     """The CPU oracle as the per-shard computation (same contract as the harness's device shard)."""
     from oracle import nsdiff_oracle as O
 
-    def compute(model, windows, pred_len, scale):
+    def compute(model, windows, pred_len, scale, keep_samples=True):
         V = int(windows[0].shape[0])
         outs, mpv, pm = [], [], []
         for w in windows:
@@ -159,3 +159,75 @@ def test_sharded_harness_cache_equals_unsharded(tmp_path, world, n_windows, nois
     slbp_one = H._load_tensor_list(tmp_path / "w1_slbp.pt")
     slbp_n = H._load_tensor_list(tmp_path / ("w%d_slbp.pt" % world))
     assert len(slbp_n) == n_windows and all(torch.equal(a, b) for a, b in zip(slbp_one, slbp_n))
+
+
+# ---- fewer windows than ranks: the sample axis is split instead ------------------------------------------------------------------
+def _oracle_sample_shard(sd):
+    """The CPU oracle as one rank's share of a sample-axis split: all windows, samples [s_lo, s_hi) of each, drawn from the shared
+    reference stream exactly as the device path slices it."""
+    from oracle import nsdiff_oracle as O
+
+    def compute(model, windows, pred_len, scale, s_lo, s_hi):
+        V, per, P = int(windows[0].shape[0]), s_hi - s_lo, int(model.configs.parallel_sample)
+        outs = []
+        for w in windows:
+            x = torch.as_tensor(w).float()
+            if scale:
+                x = O.scale(x, sd["scaler_mean"], sd["scaler_std"])
+            z = model.host_noise(1, V)[0]                                        # [C, T, V*P, O, F], the full draw of this window
+            C, T = z.shape[0], z.shape[1]
+            z = z.reshape(C, T, V, P, z.shape[-2], z.shape[-1])
+            if per % P == 0:
+                z, p_loc = z[s_lo // P: s_hi // P], P
+            else:
+                z, p_loc = z[s_lo // P: s_lo // P + 1, :, :, s_lo % P: s_lo % P + per], per
+            z = z.reshape(z.shape[0], T, V * p_loc, z.shape[-2], z.shape[-1])
+            cfg = O.NsDiffConfig(24, 12, 1, 8, 6, n_z_samples=per, parallel_sample=p_loc)
+            outs.append(O.evaluation_step(sd, cfg, x, noise=O.replay_noise([z[c, k] for c in range(z.shape[0]) for k in range(T)]))[:, -pred_len:])
+        return torch.stack(outs)
+    return compute
+
+
+def _sample_split_worker(rank, world, port, n_windows, keep, out_dir):
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mpv_amd import distributed as D
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+    try:
+        model, sd, cfg = _tiny_model("torch_cpu")
+        H.SHARD_COMPUTE, H.SAMPLE_SHARD_COMPUTE = _oracle_shard(sd, cfg), _oracle_sample_shard(sd)
+        series, time = _series(n_windows)
+        views, _ = H.build_sliding_windows(series, time, 24, 5)
+        assert D.sample_split(n_windows, 4, 2) == (world > n_windows)
+        torch.manual_seed(5)
+        preds = H.run_evaluation_cache(model, views, 12, os.path.join(out_dir, "s%d_cache.pt" % world), "cpu", force_recompute=True, store_samples=keep)
+        rec = {"ews": np.asarray(preds.ews, dtype=np.float64), "pm": np.asarray(preds.pred_mean, dtype=np.float64), "preds": list(preds)}
+        torch.save(rec, os.path.join(out_dir, "s%d_r%d.pt" % (world, rank)))
+        if world > 1:
+            dist.barrier()
+    finally:
+        H.SHARD_COMPUTE = H.SAMPLE_SHARD_COMPUTE = None
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_windows,keep", [(2, 1, True), (4, 2, True), (2, 1, False)])
+def test_sample_axis_split_equals_unsplit(tmp_path, world, n_windows, keep):
+    """W < world: every rank samples ALL windows with n_z_samples / world samples (whole chunks at world 2, single samples of a
+    chunk at world 4); merged moments give the single-process curve and the gathered cache holds the same samples in the same order."""
+    _sample_split_worker(0, 1, 0, n_windows, keep, str(tmp_path))
+    mp.spawn(_sample_split_worker, args=(world, _free_port(), n_windows, keep, str(tmp_path)), nprocs=world, join=True)
+    one = torch.load(tmp_path / "s1_r0.pt", weights_only=False)
+    for r in range(world):
+        got = torch.load(tmp_path / ("s%d_r%d.pt" % (world, r)), weights_only=False)
+        np.testing.assert_allclose(got["ews"], one["ews"], rtol=2e-6)
+        np.testing.assert_allclose(got["pm"], one["pm"], rtol=2e-6, atol=1e-7)
+        assert len(got["preds"]) == (n_windows if keep else 0)
+        for a, b in zip(one["preds"], got["preds"]):
+            assert tuple(a.shape) == tuple(b.shape) == (3, 12, 1, 4)
+            torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-6)              # same draws; the matmul batch differs
+    if keep:
+        from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+        cache = H._load_tensor_list(tmp_path / ("s%d_cache.pt" % world))
+        assert len(cache) == n_windows and tuple(cache[0].shape) == (3, 12, 1, 4)

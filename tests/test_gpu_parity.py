@@ -646,3 +646,25 @@ def test_uncertainty_ews_curve_only_mode(tmp_path, golden_cases, monkeypatch):
     np.testing.assert_allclose(np.array(res["ews"], dtype=np.float64), golden_cases["net_ews"], rtol=RTOL)
     np.testing.assert_allclose(np.array(res["pred_mean"], dtype=np.float64), golden_cases["net_pred_mean"], rtol=RTOL)
     np.testing.assert_allclose(res["time_points"], golden_cases["net_tp"])
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sample_axis_shards_union_is_the_unsplit_run(world):
+    """The device side of the harness's sample-axis split (fewer windows than ranks): rank r samples ALL windows with samples
+    [r S/world, (r+1) S/world) -- whole parallel_sample chunks (world 2), or a slice of one chunk (world 4, 8) -- from the shared
+    reference stream; the ranks' blocks side by side are the single-process samples (the collectives around it: tests/test_distributed_gloo.py)."""
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+    sd = O.random_state_dict(2, 6, 24, 12, 8, seed=4)
+    sd["scaler_mean"], sd["scaler_std"] = torch.tensor([0.3, -0.2]), torch.tensor([1.7, 0.6])
+    model = _variant_model(sd, "cond_var", 2, 6, 24, 12, 8, 8, 4, noise_source="torch_cpu")
+    g = torch.Generator().manual_seed(3)
+    windows = [torch.randn(5, 24, 2, generator=g).cumsum(1) * 0.2 for _ in range(3)]
+    torch.manual_seed(31)
+    whole, _, _ = H._native_shard(model, windows, 12, True)                          # [3, 5, 12, 2, 8]
+    parts = []
+    for r in range(world):
+        torch.manual_seed(31)
+        parts.append(H._native_sample_shard(model, windows, 12, True, r * (8 // world), (r + 1) * (8 // world), seed=0).cpu())
+        assert tuple(parts[-1].shape) == (3, 5, 12, 2, 8 // world)
+    assert int(model.configs.n_z_samples) == 8 and int(model.configs.parallel_sample) == 4      # restored
+    assert rel_err(torch.cat(parts, dim=-1), whole) < 1e-5

@@ -103,10 +103,44 @@ def barrier():
 
 
 def sample_split(n_windows: int, n_samples: int, chunk: int) -> bool:
-    """True when the sample axis, not the window axis, should be sharded: fewer windows than ranks and the sample count
-    divides into whole `parallel_sample` chunks per rank."""
+    """True when the sample axis, not the window axis, should be sharded: fewer windows than ranks, and each rank's
+    n_samples / world samples are either whole `parallel_sample` chunks or a whole fraction of one chunk."""
     world = world_size()
-    return active() and 0 < n_windows < world and n_samples % world == 0 and (n_samples // world) % max(1, min(chunk, n_samples // world)) == 0
+    if not (active() and 0 < n_windows < world and n_samples % world == 0):
+        return False
+    per, chunk = n_samples // world, max(1, min(chunk, n_samples))
+    return per % chunk == 0 or chunk % per == 0
+
+
+def sample_bounds(n_samples: int) -> Tuple[int, int]:
+    per = n_samples // world_size()
+    return rank() * per, (rank() + 1) * per
+
+
+def broadcast_int(value: int) -> int:
+    """Rank 0's integer on every rank (a shared Philox seed)."""
+    if not active():
+        return int(value)
+    nccl = dist.get_backend() == "nccl"
+    t = torch.tensor([int(value)], dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()) if nccl else "cpu")
+    dist.broadcast(t, src=0)
+    return int(t.item())
+
+
+def gather_samples(local: torch.Tensor) -> torch.Tensor:
+    """Each rank's [..., S/world] block of the sample axis -> the full [..., S] tensor on the CPU, rank order."""
+    if not active():
+        return local.detach().cpu()
+    world = world_size()
+    nccl = dist.get_backend() == "nccl"
+    send = local.detach().contiguous()
+    send = send.to(torch.device("cuda", torch.cuda.current_device())) if nccl else send.cpu()
+    recv = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+    if nccl:
+        dist.all_gather_into_tensor(recv, send)
+    else:
+        dist.all_gather(list(recv.unbind(0)), send)
+    return torch.cat(list(recv.unbind(0)), dim=-1).cpu()
 
 
 def merge_row_moments(mean: torch.Tensor, m2: torch.Tensor, n_local: int):

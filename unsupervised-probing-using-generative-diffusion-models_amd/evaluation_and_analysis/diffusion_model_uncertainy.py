@@ -308,6 +308,8 @@ def _stack_windows(window_list: Sequence[torch.Tensor]) -> torch.Tensor:
 # replaces the device computation of ONE shard (tests/test_distributed_gloo.py injects the CPU oracle here so that the
 # sharding, gathering and cache logic around it run under gloo without a GPU).  Never set by the product.
 SHARD_COMPUTE = None
+# The same for the sample-axis split: callable(model, windows, pred_len, scale, s_lo, s_hi) -> samples [W, V, pred_len, F, s_hi - s_lo].
+SAMPLE_SHARD_COMPUTE = None
 
 
 def _skip_host_noise(model, n_windows: int, nodes: int):
@@ -397,6 +399,68 @@ def _native_shard(model, windows, pred_len, scale, keep_samples=True, graph=None
     return torch.cat(preds, dim=0), torch.cat(mpv_parts), torch.cat(mean_parts)
 
 
+def _native_sample_shard(model, windows, pred_len, scale, s_lo, s_hi, seed):
+    """Sample-axis split (fewer windows than ranks): ALL windows, this rank's samples [s_lo, s_hi) of each.  Stacked NsDiff family only.
+    torch_cpu noise: every rank draws the reference's full stream and keeps the draws of its own samples (whole chunks, or a slice
+    of the parallel_sample axis of one chunk), so the union over ranks is bit-for-bit the single-process result; Philox: one shared
+    seed, rank-distinct keys."""
+    cfg = model.configs
+    S, P = model._check_sampling_config()
+    per = s_hi - s_lo
+    V = int(windows[0].shape[0])
+    ctx = model.native_context()
+    rows = _stack_windows(windows).to(ctx.device)                             # [W*V, windows, F]
+    noise = None
+    if getattr(model, "noise_source", "philox") == "torch_cpu":
+        z = model.host_noise(len(windows), V)                                 # [W, C, T, V*P, O, F]
+        W_, C_, T_, _, O_, F_ = z.shape
+        z = z.reshape(W_, C_, T_, V, P, O_, F_)
+        if per % P == 0:
+            z = z[:, s_lo // P: s_hi // P]
+            p_loc = P
+        else:
+            z = z[:, s_lo // P: s_lo // P + 1, :, :, s_lo % P: s_lo % P + per]
+            p_loc = per
+        c_loc = z.shape[1]
+        # stacked launch over W*V rows: [1, C', T, (W*V)*P', O, F]
+        noise = z.permute(1, 2, 0, 3, 4, 5, 6).reshape(1, c_loc, T_, W_ * V * p_loc, O_, F_).contiguous()
+    else:
+        p_loc = P if per % P == 0 else per
+    keep = (cfg.n_z_samples, cfg.parallel_sample)
+    cfg.n_z_samples, cfg.parallel_sample = per, p_loc
+    try:
+        samples, _ = model.sample_windows(rows, 1, 0, 1, scale_input=scale, noise=noise, seed=None if noise is not None else seed + dist_utils.rank())
+    finally:
+        cfg.n_z_samples, cfg.parallel_sample = keep
+    return samples.reshape(len(windows), V, model.pred_len, model.dataset_nf, per)[:, :, -pred_len:].contiguous()
+
+
+def _sample_split(model, window_list, pred_len, scale, keep_samples):
+    """More ranks than windows: shard the SAMPLE axis.  Every rank samples all windows with n_z_samples / world samples; per-row
+    (mean, M2) of the inverse-scaled samples are merged with `distributed.merge_row_moments` (one all-gather, Chan's update in rank
+    order: every rank gets the same curve), and when the caller keeps the samples they are all-gathered along the sample axis."""
+    S = int(model.configs.n_z_samples)
+    s_lo, s_hi = dist_utils.sample_bounds(S)
+    seed = 0
+    if getattr(model, "noise_source", "philox") != "torch_cpu":              # (torch_cpu: the shared CPU stream must stay untouched)
+        seed = dist_utils.broadcast_int(int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()))
+    if SAMPLE_SHARD_COMPUTE is not None:
+        local = SAMPLE_SHARD_COMPUTE(model, list(window_list), pred_len, scale, s_lo, s_hi)
+    else:
+        local = _native_sample_shard(model, list(window_list), pred_len, scale, s_lo, s_hi, seed)
+    x = local.double()
+    if _uses_scaler(model):                                                   # summarize_pred_future_list inverse-scales first (:286-303)
+        x = x * model.scaler_std.to(x.device).double().view(1, 1, 1, -1, 1) + model.scaler_mean.to(x.device).double().view(1, 1, 1, -1, 1)
+    mean = x.mean(dim=-1)
+    m2 = ((x - mean.unsqueeze(-1)) ** 2).sum(dim=-1)
+    var, mean = dist_utils.merge_row_moments(mean, m2, s_hi - s_lo)            # [W, V, O, F] each
+    mpv = var.flatten(1).mean(dim=1).float().cpu().numpy()
+    pm = mean.flatten(1).mean(dim=1).float().cpu().numpy()
+    if not keep_samples:
+        return None, mpv, pm
+    return list(dist_utils.gather_samples(local).unbind(0)), mpv, pm
+
+
 def _summary_only(model, rows4, scale, noise):
     """[w, V, windows, F] stacked windows -> (None, mpv [w], pred_mean [w]) without a sample tensor: sigma head over
     w*V rows, then ONE sampler launch with w windows of V nodes whose epilogue reduces every (node, horizon, feature) row."""
@@ -428,10 +492,15 @@ def _sample_stacked(model, window_list, pred_len, scale: bool, keep_samples: boo
 
     With torch.distributed active every rank computes a contiguous block of windows (`distributed.shard_bounds`), then
     the per-window scalars AND the sample tensors are all-gathered, so every rank returns the complete, identical
-    result: the reference's list holds one entry per window (reference :323-339) and the cache written from it must too."""
+    result: the reference's list holds one entry per window (reference :323-339) and the cache written from it must too.
+    With fewer windows than ranks (a single SLBP window, a short real-data series) the sample axis is split instead
+    (`_sample_split`)."""
     n = len(window_list)
     if n == 0:
         return [], np.zeros(0, np.float32), np.zeros(0, np.float32)
+    if graph is None and hasattr(model, "_prior_variance") and hasattr(model, "configs") and dist_utils.sample_split(
+            n, int(model.configs.n_z_samples), int(model.configs.parallel_sample)):
+        return _sample_split(model, window_list, pred_len, scale, keep_samples)
     lo, hi = dist_utils.shard_bounds(n)
     V = int(window_list[0].shape[0])
     compute = SHARD_COMPUTE or _native_shard
