@@ -276,6 +276,8 @@ typedef struct {
     int32_t d_h;           /* base channels = time-embedding width                                 */
     int32_t Td_h;          /* taps the k = T+1 convolution reduces the time axis to (even)         */
     int32_t timesteps;     /* diffusion_steps: rows 0..timesteps of the time-embedding table       */
+    int32_t gemm;          /* MPV_GEMM_F16X3 (0, default): the k = T+1 convolutions and the graph-conv Linear maps as two-term f16
+                              splits on the f16 matrix pipe, fp32-equivalent; MPV_GEMM_F32: exact fp32 pipe */
 } mpv_stg_desc;
 
 /* One step of UGnet.forward's module sequence (down path, middle, up path), host pointers in PyTorch layouts.

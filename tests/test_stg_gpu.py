@@ -29,9 +29,10 @@ def build(z, tag, **over):
     return m.to(dev()).eval(), net, V
 
 
+@pytest.mark.parametrize("gemm", ["f16x3", "f32"])
 @pytest.mark.parametrize("tag", ["tiny", "ddpm", "c5"])
-def test_ugnet_forward_matches_reference(z, tag):
-    m, net, V = build(z, tag)
+def test_ugnet_forward_matches_reference(z, tag, gemm):
+    m, net, V = build(z, tag, gemm_mode=gemm)
     ctx = m.native_context()
     ctx.stg_set_graph(T(z["edge_%s" % tag]), V)
     x, xm = T(z["x_%s" % tag]).to(dev()), T(z["xm_%s" % tag]).to(dev())

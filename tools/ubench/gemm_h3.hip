@@ -8,7 +8,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int PROBE>
-float run(const GemmHArgs& a, int reps) {
+float run(const NstGemmHArgs& a, int reps) {
     const long long tiles = ((a.M + G_BM - 1) / G_BM) * ((a.N + G_BN - 1) / G_BN);
     const dim3 grid((unsigned)(8 * ((tiles + 7) / 8)));
     hipEvent_t e0, e1;
@@ -34,7 +34,7 @@ int main() {
     CK(hipMemset(X, 0, M * 1536 * 4)); CK(hipMemset(R, 0, M * 512 * 4)); CK(hipMemset(bias, 0, 1536 * 4)); CK(hipMemset(Wh, 0, 1536 * 512 * 2));
     CK(hipMemset(Wl, 0, 1536 * 512 * 2));
     for (const Shape& s : shapes) {
-        GemmHArgs a{X, s.K, Wh, Wl, 1.0f, bias, s.res ? R : nullptr, 512, Y, s.N, M, s.N, s.K, s.act};
+        NstGemmHArgs a{X, s.K, Wh, Wl, 1.0f, bias, s.res ? R : nullptr, 512, Y, s.N, M, s.N, s.K, s.act, s.K};
         const double gf = 2.0 * M * s.N * s.K / 1e9;
         const float full = run<0>(a, 5), nostore = run<1>(a, 5), onek = run<2>(a, 5), noload = run<4>(a, 5), loop_only = run<5>(a, 5);
         printf("%-10s N=%4d K=%3d: full %.3f ms (%.0f TF/s) | no stores %.3f | one k-tile %.3f | no loads in loop %.3f | no loads, no stores %.3f\n", s.name, s.N, s.K,

@@ -69,7 +69,7 @@ DTS_PLAN_COLS = 10
 
 
 class StgDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("T_h", "T_p", "nf", "d_h", "Td_h", "timesteps")]
+    _fields_ = [(n, C.c_int32) for n in ("T_h", "T_p", "nf", "d_h", "Td_h", "timesteps", "gemm")]
 
 
 class StgStep(C.Structure):
@@ -545,7 +545,10 @@ class Context:
         head = [_host_f32(t) for t in (ugnet.x_proj.weight, ugnet.x_proj.bias, ugnet.out[0].weight, ugnet.out[0].bias, ugnet.out[1].weight,
                                         ugnet.out[1].bias)]
         head_arr = (_F * 6)(*[_fptr(t) for t in head])
-        desc = StgDesc(ugnet.T_h, ugnet.T_p, ugnet.F, d_h, int(ugnet.net_param["Td_h"]), T_steps)
+        gemm = ugnet.net_param.get("gemm_mode", "f16x3")
+        if gemm not in ("f16x3", "f32"):
+            raise MpvError("DiffSTG supports gemm_mode 'f16x3' and 'f32'")
+        desc = StgDesc(ugnet.T_h, ugnet.T_p, ugnet.F, d_h, int(ugnet.net_param["Td_h"]), T_steps, GEMM_MODES[gemm])
         self._bind_stream()
         self._check(self.lib.mpv_stg_load(self._h, C.byref(desc), arr, len(steps), head_arr, _fptr(temb)), "mpv_stg_load")
         self.stg = (ugnet.T_h, ugnet.T_p, ugnet.F)

@@ -478,7 +478,7 @@ int gemm(mpv_ctx* ctx, const NstEngine& e, const float* X, long long ldx, const 
     const long long tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
     const dim3 grid((unsigned)(8 * ((tiles + 7) / 8)));
     if (e.gemm_mode == MPV_GEMM_F32) {
-        GemmArgs a{X, ldx, W.w + (size_t)row0 * K, bias, R, ldr, Y, ldy, M, N, K, act};
+        NstGemmArgs a{X, ldx, W.w + (size_t)row0 * K, bias, R, ldr, Y, ldy, M, N, K, act};
         const size_t lds = sizeof(float) * 2 * (G_BM + G_BN) * G_LD;
         static bool attr_set = false;
         if (!attr_set) {
@@ -487,7 +487,7 @@ int gemm(mpv_ctx* ctx, const NstEngine& e, const float* X, long long ldx, const 
         }
         hipLaunchKernelGGL(nst_gemm_kernel, grid, dim3(256), lds, ctx->stream, a);
     } else {
-        GemmHArgs a{X, ldx, W.h + (size_t)row0 * K, W.l + (size_t)row0 * K, W.inv_scale, bias, R, ldr, Y, ldy, M, N, K, act};
+        NstGemmHArgs a{X, ldx, W.h + (size_t)row0 * K, W.l + (size_t)row0 * K, W.inv_scale, bias, R, ldr, Y, ldy, M, N, K, act, K};
         hipLaunchKernelGGL(nst_gemm_h3_kernel<0>, grid, dim3(256), 0, ctx->stream, a);
     }
     MPV_HIP_TRY(ctx, hipGetLastError());

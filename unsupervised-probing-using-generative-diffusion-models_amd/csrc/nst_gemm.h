@@ -13,7 +13,7 @@ __device__ __forceinline__ float nst_gelu(float x) { return 0.5f * x * (1.0f + e
 // ---------------------------------------------------------------------------------------------------------------------
 // GEMM  Y[M][N] = act(X[M][K] W[N][K]^T + bias) + R
 // ---------------------------------------------------------------------------------------------------------------------
-struct GemmArgs {
+struct NstGemmArgs {
     const float* X; long long ldx;
     const float* W;           // [N][K]
     const float* bias;        // [N] | null
@@ -40,7 +40,47 @@ __device__ __forceinline__ bool gemm_tile(long long M, int N, long long& m0, int
     return true;
 }
 
-__global__ __launch_bounds__(256, 2) void nst_gemm_kernel(const GemmArgs p) {
+constexpr int C_LD = G_BN + 4;                  // floats per row of the output tile staged in LDS
+
+// Output tile: accumulators -> LDS [128][C_LD] -> rows of 512 contiguous bytes (a wave writes two whole rows per instruction; the
+// accumulator layout itself would give 128-byte pieces of 64 different rows).  Bias, activation and residual are applied on the way out.
+// N must be a multiple of 4.
+template <bool PROBE_NO_STORE = false>
+__device__ __forceinline__ void gemm_store_tile(float* Cs, const v16f (&acc)[2][2], float scale, long long m0, int n0, long long M, int N, const float* bias,
+                                                int act, const float* R, long long ldr, float* Y, long long ldy) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    __syncthreads();                              // every wave is done with the operand tiles
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * C_LD + wn * 64 + j * 32 + li] = acc[i][j][r] * scale;
+    __syncthreads();
+    const int c4 = (tid & 31) * 4, n = n0 + c4;
+    if (n >= N) return;
+    v4f b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (bias) b4 = *reinterpret_cast<const v4f*>(bias + n);
+#pragma unroll 4
+    for (int it = 0; it < G_BM / 8; ++it) {
+        const int row = it * 8 + (tid >> 5);
+        const long long m = m0 + row;
+        if (m >= M) break;
+        v4f y = *reinterpret_cast<const v4f*>(Cs + row * C_LD + c4) + b4;
+        if (act == 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[c] = fmaxf(y[c], 0.0f);
+        } else if (act == 2) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[c] = nst_gelu(y[c]);
+        }
+        if (R) y += *reinterpret_cast<const v4f*>(R + (size_t)m * ldr + n);
+        if (!PROBE_NO_STORE || y[0] == 1.2345e30f) *reinterpret_cast<v4f*>(Y + (size_t)m * ldy + n) = y;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void nst_gemm_kernel(const NstGemmArgs p) {
     extern __shared__ float sm[];
     float* As = sm;                               // [2][G_BM][G_LD]
     float* Bs = sm + 2 * G_BM * G_LD;             // [2][G_BN][G_LD]
@@ -117,25 +157,7 @@ __global__ __launch_bounds__(256, 2) void nst_gemm_kernel(const GemmArgs p) {
         }
         __syncthreads();
     }
-    // epilogue: accumulator (i, j) register r holds row wm*64 + i*32 + (r&3) + 8 (r>>2) + 4 lh, column wn*64 + j*32 + li
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + li;
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-                float y = acc[i][j][r] + bias;
-                if (p.act == 1) y = fmaxf(y, 0.0f);
-                else if (p.act == 2) y = nst_gelu(y);
-                if (p.R) y += p.R[(size_t)m * p.ldr + n];
-                p.Y[(size_t)m * p.ldy + n] = y;
-            }
-    }
+    gemm_store_tile(sm, acc, 1.0f, m0, n0, p.M, p.N, p.bias, p.act, p.R, p.ldr, p.Y, p.ldy);      // LDS is large enough: 2 (128 + 128) x 36 floats
 }
 
 // The same GEMM on the f16 matrix pipe at fp32-equivalent accuracy (the split the chain sampler uses): every
@@ -147,27 +169,29 @@ __global__ __launch_bounds__(256, 2) void nst_gemm_kernel(const GemmArgs p) {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
-struct GemmHArgs {
+struct NstGemmHArgs {
     const float* X; long long ldx;
-    const _Float16* Wh; const _Float16* Wl;     // [N][K] each
+    const _Float16* Wh; const _Float16* Wl;     // [N][ldw] each, zero beyond column K
     float inv_scale;                            // 1 / (power of two the weights were scaled by)
     const float* bias;
     const float* R; long long ldr;
     float* Y; long long ldy;
     long long M;
-    int N, K;
+    int N, K;                                   // K a multiple of 4; the k loop runs over ldw (K rounded up to 32), X columns >= K read as 0
     int act;
+    int ldw;
 };
 
 constexpr int H_LD = G_BK + 8;                  // halves per LDS row
 
 // PROBE (tools/ubench/gemm_h3.hip only): 1 no epilogue stores, 2 one k-tile, 4 no global loads inside the loop
 template <int PROBE = 0>
-__global__ __launch_bounds__(256, 2) void nst_gemm_h3_kernel(const GemmHArgs p) {
-    __shared__ _Float16 Ah[G_BM * H_LD];
-    __shared__ _Float16 Al[G_BM * H_LD];
-    __shared__ _Float16 Bh[G_BN * H_LD];
-    __shared__ _Float16 Bl[G_BN * H_LD];
+__global__ __launch_bounds__(256, 2) void nst_gemm_h3_kernel(const NstGemmHArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[G_BM * C_LD];           // operand tiles (40 KB of it), then the output tile
+    _Float16* Ah = reinterpret_cast<_Float16*>(smem);
+    _Float16* Al = Ah + G_BM * H_LD;
+    _Float16* Bh = Al + G_BM * H_LD;
+    _Float16* Bl = Bh + G_BN * H_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     long long m0;
@@ -188,15 +212,16 @@ __global__ __launch_bounds__(256, 2) void nst_gemm_h3_kernel(const GemmHArgs p) 
     for (int j = 0; j < 2; ++j) {
         int n = n0 + wr + 64 * j;
         if (n >= p.N) n = p.N - 1;
-        wh[j] = p.Wh + (size_t)n * p.K + wk;
-        wl[j] = p.Wl + (size_t)n * p.K + wk;
+        wh[j] = p.Wh + (size_t)n * p.ldw + wk;
+        wl[j] = p.Wl + (size_t)n * p.ldw + wk;
     }
     // Two register sets of staged tiles, so that a global load has two compute phases to land before it is written to LDS.
     struct Stage { v4f x[4]; h8 h[2], l[2]; };
     Stage sa, sb;
     auto fetch = [&](Stage& st, int kt) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) st.x[j] = *reinterpret_cast<const v4f*>(xa[j] + (size_t)kt * G_BK);
+        for (int j = 0; j < 4; ++j)
+            st.x[j] = (kt * G_BK + lk < p.K) ? *reinterpret_cast<const v4f*>(xa[j] + (size_t)kt * G_BK) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             st.h[j] = *reinterpret_cast<const h8*>(wh[j] + (size_t)kt * G_BK);
@@ -234,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void nst_gemm_h3_kernel(const GemmHArgs p) 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const int nk = (PROBE & 2) ? 1 : p.K / G_BK;
+    const int nk = (PROBE & 2) ? 1 : p.ldw / G_BK;
     const int li = lane & 31, lh = lane >> 5;
     const int a_off = (wm * 64 + li) * H_LD + 8 * lh;
     const int b_off = (wn * 64 + li) * H_LD + 8 * lh;
@@ -278,24 +303,7 @@ __global__ __launch_bounds__(256, 2) void nst_gemm_h3_kernel(const GemmHArgs p) 
         __syncthreads();
         if (!(PROBE & 4) && kt + 4 < nk) fetch(sb, kt + 4);
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + li;
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-                float y = acc[i][j][r] * p.inv_scale + bias;
-                if (p.act == 1) y = fmaxf(y, 0.0f);
-                else if (p.act == 2) y = nst_gelu(y);
-                if (p.R) y += p.R[(size_t)m * p.ldr + n];
-                if (!(PROBE & 1) || y == 1.2345e30f) p.Y[(size_t)m * p.ldy + n] = y;
-            }
-    }
+    gemm_store_tile<(PROBE & 1) != 0>(smem, acc, p.inv_scale, m0, n0, p.M, p.N, p.bias, p.act, p.R, p.ldr, p.Y, p.ldy);
 }
 
 }  // namespace

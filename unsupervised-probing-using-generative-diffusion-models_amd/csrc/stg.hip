@@ -16,8 +16,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <unordered_map>
 
 #include "chain_common.h"
+#include "nst_gemm.h"
 
 namespace {
 
@@ -365,8 +367,12 @@ inline dim3 g1d(long long n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
 
+struct SplitW { const _Float16* h; const _Float16* l; float inv_scale; int ldw; };    // two-term f16 split of one GEMM weight (nst_gemm.h)
+
 struct StgEngine {
     mpv_stg_desc d{};
+    _Float16* blob16 = nullptr;
+    std::unordered_map<const float*, SplitW> split;     // fp32 weight pointer -> its split copy
     std::vector<Step> steps;
     float* blob = nullptr;
     const float *wx = nullptr, *bx = nullptr, *wo = nullptr, *bo = nullptr, *wl = nullptr, *bl = nullptr, *temb = nullptr;
@@ -383,6 +389,7 @@ struct StgEngine {
 void stg_engine_destroy(StgEngine* e) {
     if (!e) return;
     if (e->blob) (void)hipFree(e->blob);
+    if (e->blob16) (void)hipFree(e->blob16);
     if (e->ws) (void)hipFree(e->ws);
     if (e->graph) (void)hipFree(e->graph);
     delete e;
@@ -395,8 +402,17 @@ namespace {
         if (int rc_ = (expr)) return rc_; \
     } while (0)
 
-int gemm(mpv_ctx* ctx, const float* X, long long ldx, const float* W, const float* bias, int K, int N, long long rows, float* Y, long long ldy, int relu = 0,
-         const float* r1 = nullptr) {
+int gemm(mpv_ctx* ctx, const StgEngine& e, const float* X, long long ldx, const float* W, const float* bias, int K, int N, long long rows, float* Y, long long ldy,
+         int relu = 0, const float* r1 = nullptr) {
+    const auto sp = e.split.find(W);
+    if (e.d.gemm != MPV_GEMM_F32 && sp != e.split.end() && K % 4 == 0 && N % 4 == 0) {
+        // two-term f16 split on the f16 matrix pipe, fp32-equivalent: the k = T+1 convolutions and the graph-conv Linear maps
+        NstGemmHArgs a{X, ldx, sp->second.h, sp->second.l, sp->second.inv_scale, bias, r1, ldy, Y, ldy, rows, N, K, relu, sp->second.ldw};
+        const long long tiles = ((rows + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
+        hipLaunchKernelGGL(nst_gemm_h3_kernel<0>, dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(256), 0, ctx->stream, a);
+        MPV_HIP_TRY(ctx, hipGetLastError());
+        return MPV_OK;
+    }
     int KC = 64;
     if (K < 64) KC = (K + 15) & ~15;
     GemmArgs a{X, ldx, W, bias, Y, ldy, rows, K, N, KC, relu, r1};
@@ -491,14 +507,14 @@ int forward(mpv_ctx* ctx, StgEngine& e, const float* xt, const float* xm, long l
             }
 #undef STG_TCN
             MPV_HIP_TRY(ctx, hipGetLastError());
-            STG_TRY(gemm(ctx, e.hn, (long long)co * s.T, s.r.wdown, s.r.bdown, co * s.T, C, N, e.z, C));
-            STG_TRY(gemm(ctx, e.z, C, s.r.wg, s.r.bg4, C, 4 * C, N, e.kqvs, 4 * C));
+            STG_TRY(gemm(ctx, e, e.hn, (long long)co * s.T, s.r.wdown, s.r.bdown, co * s.T, C, N, e.z, C));
+            STG_TRY(gemm(ctx, e, e.z, C, s.r.wg, s.r.bg4, C, 4 * C, N, e.kqvs, 4 * C));
             hipLaunchKernelGGL(stg_gate_kernel, g1d(N * C), dim3(256), 0, st, e.kqvs, s.r.gbias, e.graph, e.graph + e.V + 1, e.V, C, N * C, e.sp);
             MPV_HIP_TRY(ctx, hipGetLastError());
             // up-sampling product with the block's shortcut added in its epilogue: the block input itself (identity) or the 1x1
             // convolution the TCN kernel left in e.up
             if (!s.r.ws && cur_c != co) return mpv_fail(ctx, MPV_ESTATE, "DiffSTG: identity shortcut with differing channel counts");
-            STG_TRY(gemm(ctx, e.sp, C, s.r.wup, s.r.bup, C, co * s.T, N, out, (long long)co * s.T, 0, s.r.ws ? e.up : cur));
+            STG_TRY(gemm(ctx, e, e.sp, C, s.r.wup, s.r.bup, C, co * s.T, N, out, (long long)co * s.T, 0, s.r.ws ? e.up : cur));
         }
         MPV_HIP_TRY(ctx, hipGetLastError());
         cur = out;
@@ -507,7 +523,7 @@ int forward(mpv_ctx* ctx, StgEngine& e, const float* xt, const float* xm, long l
     }
     hipLaunchKernelGGL(stg_outconv_kernel, g1d(N * F * T2), dim3(256), 0, st, cur, e.wo, e.bo, T2, F, d_h, N * F * T2, e.e1);
     MPV_HIP_TRY(ctx, hipGetLastError());
-    return gemm(ctx, e.e1, T2, e.wl, e.bl, T2, T, N * F, e.eps, T);
+    return gemm(ctx, e, e.e1, T2, e.wl, e.bl, T2, T, N * F, e.eps, T);
 }
 
 }  // namespace
@@ -613,6 +629,51 @@ int mpv_stg_load(mpv_ctx* ctx, const mpv_stg_desc* d, const mpv_stg_step* steps,
         }
     }
     e->wx = P(o_wx); e->bx = P(o_bx); e->wo = P(o_wo); e->bo = P(o_bo); e->wl = P(o_wl); e->bl = P(o_bl); e->temb = P(o_temb);
+    // two-term f16 split (power-of-two scaled so the low term stays a normal f16) of the three big GEMM weights of every block
+    {
+        std::vector<_Float16> host16;
+        struct Pending { const float* key; size_t at, n; float inv; int ldw; };
+        std::vector<Pending> pend;
+        auto add = [&](const float* dev_w, size_t off, size_t rows_, size_t K_) {      // rows padded with zeros to a multiple of the GEMM's k-tile
+            const float* w = host.data() + off;
+            const size_t Kp = (K_ + G_BK - 1) / G_BK * G_BK, n = rows_ * Kp;
+            float mx = 0.0f;
+            for (size_t i = 0; i < rows_ * K_; ++i) mx = std::max(mx, std::fabs(w[i]));
+            int ex = 0;
+            if (mx > 0.0f && std::isfinite(mx)) { (void)std::frexp(mx, &ex); ex = 14 - ex; }
+            const float sc = std::ldexp(1.0f, ex);
+            const size_t at = host16.size();
+            host16.resize(at + 2 * n, (_Float16)0.0f);
+            for (size_t r = 0; r < rows_; ++r)
+                for (size_t c = 0; c < K_; ++c) {
+                    const float v = w[r * K_ + c] * sc;
+                    uint32_t bits;
+                    std::memcpy(&bits, &v, 4);
+                    bits &= 0xFFFFE000u;
+                    float hi;
+                    std::memcpy(&hi, &bits, 4);
+                    host16[at + r * Kp + c] = (_Float16)hi;
+                    host16[at + n + r * Kp + c] = (_Float16)(v - hi);
+                }
+            pend.push_back(Pending{dev_w, at, n, std::ldexp(1.0f, -ex), (int)Kp});
+        };
+        for (int i = 0; i < n_steps; ++i) {
+            const Step& st = e->steps[i];
+            if (st.kind != 0) continue;
+            const size_t C = (size_t)Td * st.c_out, CT = (size_t)st.c_out * st.T;
+            add(st.r.wdown, offs[i][10], C, CT);
+            add(st.r.wg, offs[i][12], 4 * C, C);
+            add(st.r.wup, offs[i][15], CT, C);
+        }
+        if (!host16.empty()) {
+            if (hipMalloc(&e->blob16, host16.size() * sizeof(_Float16)) != hipSuccess ||
+                hipMemcpy(e->blob16, host16.data(), host16.size() * sizeof(_Float16), hipMemcpyHostToDevice) != hipSuccess) {
+                stg_engine_destroy(e);
+                return mpv_fail(ctx, MPV_ENOMEM, "mpv_stg_load: f16 weight blob");
+            }
+            for (const Pending& pd : pend) e->split[pd.key] = SplitW{e->blob16 + pd.at, e->blob16 + pd.at + pd.n, pd.inv, pd.ldw};
+        }
+    }
     ctx->stg = e;
     return MPV_OK;
 }
