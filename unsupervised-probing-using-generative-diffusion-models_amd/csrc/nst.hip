@@ -192,10 +192,11 @@ struct AttnArgs {
 };
 
 constexpr int A_KC = 128;               // keys per chunk
-constexpr int A_QT = 64;                // queries per workgroup (16 per wave)
+constexpr int A_QW = 2;                 // 16-query tiles per wave (K / V fragments are read from LDS once for both)
+constexpr int A_QT = 64 * A_QW;         // queries per workgroup
 
 template <int E>
-__global__ __launch_bounds__(256) void nst_attn_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void nst_attn_kernel(const AttnArgs p) {
     constexpr int KLD = E + 4, VLD = A_KC + 4, ES = E / 16;
     __shared__ float Ks[A_KC * KLD];
     __shared__ float Vt[E * VLD];
@@ -207,24 +208,42 @@ __global__ __launch_bounds__(256) void nst_attn_kernel(const AttnArgs p) {
     const int q0 = blockIdx.x * A_QT;
     const float qs = p.scale * LOG2E * (p.tau ? p.tau[b] : 1.0f);
     const float ds = p.scale * LOG2E;
-    // Q fragments: lane (query lq, g) holds Q[query][16 s + 4 g + i], pre-scaled
-    int qrow = q0 + wave * 16 + lq;
-    const int qclamp = qrow < p.L ? qrow : p.L - 1;
-    v4f qf[ES];
-    {
+    // Q fragments of the wave's tiles: lane (query lq, g) holds Q[query][16 s + 4 g + i], pre-scaled
+    int qrow[A_QW];
+    bool live[A_QW];                    // the tile holds at least one real query (wave-uniform)
+    v4f qf[A_QW][ES], o[A_QW][ES];      // O^T tiles: d = 16 dt + 4 g + r, column = query
+    float m_run[A_QW], l_run[A_QW];
+#pragma unroll
+    for (int t = 0; t < A_QW; ++t) {
+        const int qt0 = q0 + (wave * A_QW + t) * 16;
+        qrow[t] = qt0 + lq;
+        live[t] = qt0 < p.L;
+        const int qclamp = qrow[t] < p.L ? qrow[t] : p.L - 1;
         const float* qp = p.Q + ((size_t)b * p.L + qclamp) * p.ldq + (size_t)h * E + 4 * g;
 #pragma unroll
-        for (int s = 0; s < ES; ++s) qf[s] = *reinterpret_cast<const v4f*>(qp + 16 * s) * qs;
+        for (int s = 0; s < ES; ++s) {
+            qf[t][s] = *reinterpret_cast<const v4f*>(qp + 16 * s) * qs;
+            o[t][s] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        m_run[t] = -INFINITY;
+        l_run[t] = 0.0f;
     }
-    v4f o[ES];                          // O^T tiles: d = 16 dt + 4 g + r, column = query
-#pragma unroll
-    for (int dt = 0; dt < ES; ++dt) o[dt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    float m_run = -INFINITY, l_run = 0.0f;
     const int s_end = p.causal ? min(p.S, q0 + A_QT) : p.S;
     for (int k0 = 0; k0 < s_end; k0 += A_KC) {
+        // only the 16-key tiles that hold a key this workgroup (n_kt) / this query tile (w_kt, causal) can see are staged and multiplied
+        const int n_kt = min(A_KC / 16, (s_end - k0 + 15) >> 4);
+        int w_kt[A_QW];
+#pragma unroll
+        for (int t = 0; t < A_QW; ++t) {
+            const int qt0 = q0 + (wave * A_QW + t) * 16;
+            w_kt[t] = !live[t] ? 0 : (p.causal ? max(0, min(n_kt, ((qt0 + 15 - k0) >> 4) + 1)) : n_kt);
+        }
+        int w_max = 0;
+#pragma unroll
+        for (int t = 0; t < A_QW; ++t) w_max = max(w_max, w_kt[t]);
         __syncthreads();                // previous chunk fully consumed
         // stage K chunk [key][E] and V chunk transposed [e][key]
-        for (int i = tid; i < A_KC * (E / 4); i += 256) {
+        for (int i = tid; i < n_kt * 16 * (E / 4); i += 256) {
             const int key = i / (E / 4), e4 = (i % (E / 4)) * 4;
             const int src = k0 + key < p.S ? k0 + key : p.S - 1;
             const v4f kv = *reinterpret_cast<const v4f*>(p.K + ((size_t)b * p.S + src) * p.ldk + (size_t)h * E + e4);
@@ -238,63 +257,92 @@ __global__ __launch_bounds__(256) void nst_attn_kernel(const AttnArgs p) {
         if (tid < A_KC) Dl[tid] = (p.delta && k0 + tid < p.S) ? p.delta[(size_t)b * p.S + k0 + tid] * ds : 0.0f;
         __syncthreads();
         // S^T tiles: rows = keys (16 kt + 4 g + r), column = query
-        v4f sc[A_KC / 16];
-        float cmax = -INFINITY;
+        v4f sc[A_QW][A_KC / 16];
+        float cmax[A_QW];
+#pragma unroll
+        for (int t = 0; t < A_QW; ++t) cmax[t] = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < A_KC / 16; ++kt) {
-            v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (kt >= w_max) continue;
+            v4f acc[A_QW];
+#pragma unroll
+            for (int t = 0; t < A_QW; ++t) acc[t] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
             const float* kp = Ks + (kt * 16 + lq) * KLD + 4 * g;
 #pragma unroll
             for (int s = 0; s < ES; ++s) {
                 const v4f kf = *reinterpret_cast<const v4f*>(kp + 16 * s);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[i], qf[s][i], acc, 0, 0, 0);
+                for (int t = 0; t < A_QW; ++t) {
+                    if (kt >= w_kt[t]) continue;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[i], qf[t][s][i], acc[t], 0, 0, 0);
+                }
             }
             const v4f dl = *reinterpret_cast<const v4f*>(Dl + kt * 16 + 4 * g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + kt * 16 + 4 * g + r;
-                float v = acc[r] + dl[r];
-                if (key >= p.S || (p.causal && key > qrow)) v = -INFINITY;
-                acc[r] = v;
-                cmax = fmaxf(cmax, v);
+            for (int t = 0; t < A_QW; ++t) {
+                if (kt >= w_kt[t]) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kt * 16 + 4 * g + r;
+                    float v = acc[t][r] + dl[r];
+                    if (key >= p.S || (p.causal && key > qrow[t])) v = -INFINITY;
+                    acc[t][r] = v;
+                    cmax[t] = fmaxf(cmax[t], v);
+                }
+                sc[t][kt] = acc[t];
             }
-            sc[kt] = acc;
         }
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-        const float m_new = fmaxf(m_run, cmax);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.0f;
 #pragma unroll
-        for (int kt = 0; kt < A_KC / 16; ++kt)
+        for (int t = 0; t < A_QW; ++t) {
+            if (w_kt[t] == 0) continue;
+            float cm = cmax[t];
+            cm = fmaxf(cm, __shfl_xor(cm, 16));
+            cm = fmaxf(cm, __shfl_xor(cm, 32));
+            const float m_new = fmaxf(m_run[t], cm);
+            const float alpha = exp2f(m_run[t] - m_new);            // (every live query sees key 0 in chunk 0, so m_new is finite)
+            m_run[t] = m_new;
+            float psum = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = exp2f(sc[kt][r] - m_new);
-                sc[kt][r] = e;
-                psum += e;
+            for (int kt = 0; kt < A_KC / 16; ++kt) {
+                if (kt >= w_kt[t]) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f(sc[t][kt][r] - m_new);
+                    sc[t][kt][r] = e;
+                    psum += e;
+                }
             }
-        psum += __shfl_xor(psum, 16);
-        psum += __shfl_xor(psum, 32);
-        l_run = l_run * alpha + psum;
+            psum += __shfl_xor(psum, 16);
+            psum += __shfl_xor(psum, 32);
+            l_run[t] = l_run[t] * alpha + psum;
 #pragma unroll
-        for (int dt = 0; dt < ES; ++dt) o[dt] *= alpha;
+            for (int dt = 0; dt < ES; ++dt) o[t][dt] *= alpha;
+        }
         // O^T[d][query] += V^T[d][key] P^T[key][query]
 #pragma unroll
-        for (int kt = 0; kt < A_KC / 16; ++kt)
+        for (int kt = 0; kt < A_KC / 16; ++kt) {
+            if (kt >= w_max) continue;
 #pragma unroll
             for (int dt = 0; dt < ES; ++dt) {
                 const v4f vf = *reinterpret_cast<const v4f*>(Vt + (dt * 16 + lq) * VLD + kt * 16 + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], sc[kt][r], o[dt], 0, 0, 0);
-            }
-    }
-    if (qrow < p.L) {
-        const float inv = 1.0f / l_run;
-        float* op = p.O + ((size_t)b * p.L + qrow) * p.ldo + (size_t)h * E + 4 * g;
+                for (int t = 0; t < A_QW; ++t) {
+                    if (kt >= w_kt[t]) continue;
 #pragma unroll
-        for (int dt = 0; dt < ES; ++dt) *reinterpret_cast<v4f*>(op + 16 * dt) = o[dt] * inv;
+                    for (int r = 0; r < 4; ++r) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], sc[t][kt][r], o[t][dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < A_QW; ++t) {
+        if (qrow[t] < p.L) {
+            const float inv = 1.0f / l_run[t];
+            float* op = p.O + ((size_t)b * p.L + qrow[t]) * p.ldo + (size_t)h * E + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < ES; ++dt) *reinterpret_cast<v4f*>(op + 16 * dt) = o[t][dt] * inv;
+        }
     }
 }
 
