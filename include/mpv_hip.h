@@ -396,6 +396,19 @@ int mpv_nst_forward(mpv_ctx* ctx, const float* series, int32_t nodes, int64_t se
  * 1 statistics [B][2][F] (mean, std), 2 tau [B], 3 delta [B][S], 4 encoder output [B][S][D]. */
 int mpv_nst_debug_tensor(mpv_ctx* ctx, int32_t which, float* out_dev, int64_t capacity);
 
+/* The single-series generator of the SLBP sensitivity data sets (shallow-lake bream X / pike Y; dataset/SLBP_dynamic_gene.py:26-58, parameter
+ * table :10-24): dX = [i_b + r X N/(N+H1) - c_b X^2 - p_r F_R Y] dt + sqrt(2D) dW, dY = [i_p + c_e p_r F_R Y V/(V+H2) - m_p Y - c_p Y^2] dt +
+ * sqrt(0.2 D) dW, F_R = X^2/(X^2+H4^2), V = K H3^2/(X^2+H3^2).  Additive noise: the reference's Milstein scheme reduces to Euler-Maruyama.
+ * N(t) = N_start through burn_ticks, then a linear ramp to N_end over `ticks`.  x0: dev [n_trajectories][2]; series_out: dev
+ * [n_trajectories][ceil(ticks/stride)][2] (every stride-th tick, the harness's [T][F] single-series layout). */
+typedef struct mpv_slbp_desc {
+    int32_t n_trajectories, ticks, burn_ticks, stride;
+    float i_b, i_p, r, H1, H2, H3, H4, c_b, c_p, p_r, c_e, m_p, K, D;
+    float dt, N_start, N_end;
+    uint64_t seed;
+} mpv_slbp_desc;
+int mpv_slbp_simulate(mpv_ctx* ctx, const mpv_slbp_desc* desc, const float* x0, float* series_out);
+
 /* Debug/validation helper: write the Philox normals mpv_nsdiff_sample would consume, in the
  * dense layout [n_chains][T][F] (chain-major), so a CPU checker can replay them. */
 int mpv_nsdiff_philox_normals(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out_dev);

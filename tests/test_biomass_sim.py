@@ -82,3 +82,36 @@ def test_sis_and_wilson_cowan_generators_match_float32_restatement(model, par):
     old = ctx.biomass_simulate(torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(x0).cuda()[None], 64, 0, 1,
                                0.7, 10.0, 0.5, 0.005, 0.1, 0.0, 1.0, 9)
     assert torch.equal(bio, old)
+
+
+def test_slbp_restatement_behaves_like_the_lake_model():
+    """CPU: the float32 restatement of the SLBP generator (unpinned: torchsde absent) keeps both populations positive and the bream
+    stock rises with the nutrient level, the regime shift the sensitivity data sets are built around."""
+    x0 = np.array([0.6, 0.3], dtype=np.float32)
+    low = BO.simulate_slbp(x0, 3000, 200, 10, 0.1, 0.0, 0.0, seed=3)
+    high = BO.simulate_slbp(x0, 3000, 200, 10, 0.1, 3.0, 3.0, seed=3)
+    assert low.shape == (300, 2) and np.isfinite(low).all() and np.isfinite(high).all()
+    assert (low > 0).all() and (high > 0).all() and high[-1, 0] > low[-1, 0]
+    again = BO.simulate_slbp(x0, 3000, 200, 10, 0.1, 0.0, 0.0, seed=3)
+    assert np.array_equal(low, again)
+
+
+@pytest.mark.gpu
+def test_slbp_generator_matches_float32_restatement():
+    """mpv_slbp_simulate (the SLBP single-series data sets, BASELINE configs[0] input), tick by tick, several trajectories at once."""
+    from mpv_amd import _native, synthetic
+    ctx = _native.Context(torch.device("cuda", 0))
+    rng = np.random.default_rng(8)
+    x0 = rng.uniform(0.0, 1.0, (3, 2)).astype(np.float32)
+    ticks, burn, stride = 2001, 77, 7
+    got = ctx.slbp_simulate(torch.from_numpy(x0).cuda(), ticks, burn, stride, 0.1, 0.2, 2.5, seed=41, D=1e-3).cpu().numpy()
+    assert got.shape == (3, (ticks + stride - 1) // stride, 2)
+    for traj in range(3):
+        want = BO.simulate_slbp(x0[traj], ticks, burn, stride, 0.1, 0.2, 2.5, seed=41, traj=traj, D=1e-3)
+        err = np.abs(got[traj] - want).max() / np.abs(want).max()
+        print("SLBP trajectory %d: max rel err %.3e, final (bream, pike) = (%.4f, %.4f)" % (traj, err, want[-1, 0], want[-1, 1]))
+        assert err < 1e-4
+    series, t, n = synthetic.slbp_series_device(ctx, ticks=20_000, seed=2, sampling_stride=100)
+    assert tuple(series.shape) == (200, 2) and len(t) == len(n) == 200 and bool(torch.isfinite(series).all()) and n[0] == 0.0
+    with pytest.raises(_native.MpvError, match="unknown SLBP"):
+        ctx.slbp_simulate(torch.from_numpy(x0).cuda(), 10, 0, 1, 0.1, 0.0, 1.0, seed=1, bogus=1.0)

@@ -27,7 +27,7 @@ EXPORTS = (
     "mpv_reduce", "mpv_chain_timing", "mpv_chain_timing_enable", "mpv_tmdm_load", "mpv_tmdm_sample",
     "mpv_stg_load", "mpv_stg_set_graph", "mpv_stg_forward", "mpv_stg_sample",
     "mpv_biomass_simulate", "mpv_network_sde_simulate", "mpv_dts_load", "mpv_dts_forward", "mpv_dts_vjp", "mpv_dts_debug_tensor", "mpv_dts_sample",
-    "mpv_nst_load", "mpv_nst_forward", "mpv_nst_debug_tensor",
+    "mpv_nst_load", "mpv_nst_forward", "mpv_nst_debug_tensor", "mpv_slbp_simulate",
 )
 
 
@@ -110,6 +110,14 @@ class SdeDesc(C.Structure):
                 ("eps_start", C.c_float), ("eps_end", C.c_float), ("seed", C.c_uint64)]
 
 
+class SlbpDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_trajectories", "ticks", "burn_ticks", "stride")] + \
+               [(n, C.c_float) for n in ("i_b", "i_p", "r", "H1", "H2", "H3", "H4", "c_b", "c_p", "p_r", "c_e", "m_p", "K", "D", "dt", "N_start", "N_end")] + \
+               [("seed", C.c_uint64)]
+
+
+# parameter table of the reference generator (dataset/SLBP_dynamic_gene.py:10-24), D = its first value
+SLBP_PARAMS = dict(i_b=3e-4, i_p=3e-4, r=7.5e-3, H1=0.5, H2=0.1, H3=20.0, H4=15.0, c_b=7.5e-5, c_p=2.75e-4, p_r=5e-2, c_e=0.1, m_p=2.25e-3, K=1.0, D=1e-5)
 SDE_MODELS = {"biomass": 0, "SIS": 1, "neuronal": 2}
 _lib = None
 
@@ -139,6 +147,7 @@ def load_library():
         "mpv_tmdm_sample": (C.c_int, [vp, C.POINTER(SampleShape), vp, vp, C.POINTER(SampleOut)]),
         "mpv_biomass_simulate": (C.c_int, [vp, C.POINTER(BiomassDesc), vp, vp, vp, vp]),
         "mpv_network_sde_simulate": (C.c_int, [vp, C.POINTER(SdeDesc), vp, vp, vp, vp]),
+        "mpv_slbp_simulate": (C.c_int, [vp, C.POINTER(SlbpDesc), vp, vp]),
         "mpv_nsdiff_philox_normals": (C.c_int, [vp, u64, u64, i64, vp]),
         "mpv_chain_stats": (C.c_int, [vp, C.POINTER(u64), C.POINTER(u64), C.c_int]),
         "mpv_sigma_load": (C.c_int, [vp, C.POINTER(SigmaDesc), C.POINTER(SigmaWeights)]),
@@ -644,6 +653,26 @@ class Context:
         self._check(self.lib.mpv_network_sde_simulate(self._h, C.byref(desc), C.c_void_p(row_ptr.data_ptr()), C.c_void_p(col_idx.data_ptr()),
                                                       _dev_ptr(x0, self.device, "x0"), _dev_ptr(out, self.device, "series_out")),
                     "mpv_network_sde_simulate")
+        return out
+
+    def slbp_simulate(self, x0: torch.Tensor, ticks: int, burn_ticks: int, stride: int, dt: float, n_start: float, n_end: float, seed: int,
+                      **params) -> torch.Tensor:
+        """The SLBP bream / pike SDE (reference dataset/SLBP_dynamic_gene.py): x0 [n_traj, 2] on device -> [n_traj, ceil(ticks/stride), 2];
+        params override SLBP_PARAMS; the nutrient level ramps linearly from n_start to n_end over the recorded ticks."""
+        par = dict(SLBP_PARAMS)
+        unknown = set(params) - set(par)
+        if unknown:
+            raise MpvError("unknown SLBP parameter(s): {}".format(sorted(unknown)))
+        par.update(params)
+        if x0.dim() != 2 or x0.shape[1] != 2:
+            raise MpvError("x0 must be [n_trajectories, 2]")
+        n = x0.shape[0]
+        out = torch.empty((n, (ticks + stride - 1) // stride, 2), device=self.device, dtype=torch.float32)
+        desc = SlbpDesc(n, ticks, burn_ticks, stride, par["i_b"], par["i_p"], par["r"], par["H1"], par["H2"], par["H3"], par["H4"], par["c_b"],
+                        par["c_p"], par["p_r"], par["c_e"], par["m_p"], par["K"], par["D"], dt, n_start, n_end, seed & (2 ** 64 - 1))
+        self._bind_stream()
+        self._check(self.lib.mpv_slbp_simulate(self._h, C.byref(desc), _dev_ptr(x0, self.device, "x0"), _dev_ptr(out, self.device, "series_out")),
+                    "mpv_slbp_simulate")
         return out
 
     def chain_stats(self, reset: bool = False):

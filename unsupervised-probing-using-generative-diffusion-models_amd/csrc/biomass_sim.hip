@@ -85,7 +85,61 @@ __global__ __launch_bounds__(SIM_THREADS) void biomass_em_kernel(const SimArgs p
     }
 }
 
+// ---- SLBP (shallow-lake bream / pike, the single-series sensitivity data set): dataset/SLBP_dynamic_gene.py:26-58 --------------
+//   dX = [ i_b + r X N/(N + H1) - c_b X^2 - p_r F_R Y ] dt + sqrt(2 D) dW_1 ,   F_R = X^2 / (X^2 + H4^2)
+//   dY = [ i_p + c_e p_r F_R Y V/(V + H2) - m_p Y - c_p Y^2 ] dt + sqrt(0.2 D) dW_2 ,   V = K H3^2 / (X^2 + H3^2)
+// The noise is additive, so the reference's Milstein scheme is Euler-Maruyama.  N(t): N_start through the burn-in, then a linear ramp
+// to N_end over the recorded ticks.  Two variables and a serial time axis: one THREAD per trajectory.
+struct SlbpArgs {
+    mpv_slbp_desc d;
+    const float* x0;        // [n_traj][2]
+    float* out;             // [n_traj][L][2]
+    int L;
+    float n_step, sx, sy;   // nutrient increment per tick, noise scales sqrt(2 D dt), sqrt(0.2 D dt)
+};
+
+__global__ __launch_bounds__(64) void slbp_em_kernel(const SlbpArgs p) {
+#pragma clang fp contract(off)
+    const int traj = blockIdx.x * 64 + threadIdx.x;
+    if (traj >= p.d.n_trajectories) return;
+    const mpv_slbp_desc& d = p.d;
+    float X = p.x0[2 * traj], Y = p.x0[2 * traj + 1];
+    const float h3 = d.H3 * d.H3, h4 = d.H4 * d.H4, kh3 = d.K * h3;
+    const int total = d.burn_ticks + d.ticks;
+    float zc[4];
+    for (int t = 0; t < total; ++t) {
+        const int i = t - d.burn_ticks;
+        const float N = i < 0 ? d.N_start : d.N_start + (float)i * p.n_step;
+        if ((t & 1) == 0) chain::philox_normals((unsigned long long)traj, (unsigned)(t >> 1), (unsigned)d.seed, (unsigned)(d.seed >> 32), 0u, zc);
+        const float z1 = (t & 1) ? zc[2] : zc[0], z2 = (t & 1) ? zc[3] : zc[1];
+        const float x2 = X * X;
+        const float V = kh3 / (x2 + h3);
+        const float FR = x2 / (x2 + h4);
+        const float dX = ((d.i_b + (d.r * X) * (N / (N + d.H1))) - d.c_b * x2) - (d.p_r * FR) * Y;
+        const float dY = ((d.i_p + (((d.c_e * d.p_r) * FR) * Y) * (V / (V + d.H2))) - d.m_p * Y) - d.c_p * (Y * Y);
+        X = (X + dX * d.dt) + p.sx * z1;
+        Y = (Y + dY * d.dt) + p.sy * z2;
+        if (i >= 0 && (i % d.stride) == 0) {
+            float* o = p.out + ((long long)traj * p.L + i / d.stride) * 2;
+            o[0] = X;
+            o[1] = Y;
+        }
+    }
+}
+
 }  // namespace
+
+int launch_slbp_sim(mpv_ctx* ctx, const mpv_slbp_desc& d, const float* x0, float* series_out) {
+    SlbpArgs a{};
+    a.d = d; a.x0 = x0; a.out = series_out;
+    a.L = (d.ticks + d.stride - 1) / d.stride;
+    a.n_step = d.ticks > 1 ? (d.N_end - d.N_start) / (float)(d.ticks - 1) : 0.0f;
+    a.sx = sqrtf(2.0f * d.D) * sqrtf(d.dt);
+    a.sy = sqrtf(0.2f * d.D) * sqrtf(d.dt);
+    hipLaunchKernelGGL(slbp_em_kernel, dim3((d.n_trajectories + 63) / 64), dim3(64), 0, ctx->stream, a);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
 
 int launch_biomass_sim(mpv_ctx* ctx, const mpv_biomass_desc& d, const int32_t* row_ptr, const int32_t* col_idx, const float* x0,
                        float* series_out) {

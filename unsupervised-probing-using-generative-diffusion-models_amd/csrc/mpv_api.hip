@@ -354,6 +354,15 @@ int mpv_network_sde_simulate(mpv_ctx* ctx, const mpv_sde_desc* d, const int32_t*
     return launch_network_sde(ctx, *d, row_ptr, col_idx, x0, series_out);
 }
 
+int mpv_slbp_simulate(mpv_ctx* ctx, const mpv_slbp_desc* d, const float* x0, float* series_out) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_slbp_simulate: ctx is NULL");
+    if (!d || !x0 || !series_out) return mpv_fail(ctx, MPV_EINVAL, "mpv_slbp_simulate: NULL argument");
+    if (d->n_trajectories < 1 || d->ticks < 1 || d->burn_ticks < 0 || d->stride < 1 || !(d->dt > 0.0f) || !(d->D >= 0.0f))
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_slbp_simulate: need n_trajectories >= 1, ticks >= 1, burn_ticks >= 0, stride >= 1, dt > 0, D >= 0");
+    DeviceGuard g(ctx->device);
+    return launch_slbp_sim(ctx, *d, x0, series_out);
+}
+
 int mpv_chain_stats(mpv_ctx* ctx, uint64_t* tile_steps, uint64_t* safe_steps, int reset) {
     if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_chain_stats: ctx is NULL");
     DeviceGuard g(ctx->device);

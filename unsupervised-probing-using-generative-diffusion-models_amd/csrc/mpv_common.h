@@ -95,6 +95,7 @@ int chain_f16_summary_capacity(const mpv_ctx* ctx, int nf);
 int launch_biomass_sim(mpv_ctx* ctx, const mpv_biomass_desc& d, const int32_t* row_ptr, const int32_t* col_idx, const float* x0,
                        float* series_out);
 int launch_network_sde(mpv_ctx* ctx, const mpv_sde_desc& d, const int32_t* row_ptr, const int32_t* col_idx, const float* x0, float* series_out);
+int launch_slbp_sim(mpv_ctx* ctx, const mpv_slbp_desc& d, const float* x0, float* series_out);
 int launch_philox_dump(mpv_ctx* ctx, uint64_t seed, uint64_t offset, int64_t n_chains, float* out);
 int launch_sigma_head(mpv_ctx* ctx, const float* series, int V, int64_t L, int n_windows, int64_t first, int64_t step,
                       const float* mean, const float* std, float add_eps, float* gx);

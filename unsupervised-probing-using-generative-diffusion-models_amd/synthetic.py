@@ -184,3 +184,14 @@ def neuronal_trajectory_device(ctx, nodes: int = 500, ticks: int = 100_000, seed
                                       torch.from_numpy(x0).to(ctx.device).unsqueeze(0), ticks, burn_ticks, sampling_stride, tau, mu, 0.0, eta, dt,
                                       eps_start, eps_end, seed)
     return series[0], (np.arange(ticks, dtype=np.float32) * np.float32(dt))[::sampling_stride]
+
+
+def slbp_series_device(ctx, ticks: int = 100_000, seed: int = 0, sampling_stride: int = 100, dt: float = 0.1, burn_ticks: int = 2000,
+                       n_start: float = 0.0, n_end: float = 3.0, **params):
+    """The 2-feature SLBP series (bream, pike) under a nutrient ramp, integrated by the HIP kernel (csrc/biomass_sim.hip::slbp_em_kernel;
+    reference dataset/SLBP_dynamic_gene.py) -> (series [L, 2] on ctx.device, time stamps, nutrient level per stamp)."""
+    x0 = torch.from_numpy(np.random.default_rng(seed).uniform(0.0, 1.0, (1, 2)).astype(np.float32)).to(ctx.device)   # torch.rand(2, 1) there
+    series = ctx.slbp_simulate(x0, ticks, burn_ticks, sampling_stride, dt, n_start, n_end, seed, **params)[0]
+    t = (np.arange(ticks, dtype=np.float32) * np.float32(dt))[::sampling_stride]
+    n = (np.float32(n_start) + np.arange(ticks, dtype=np.float32) * np.float32((n_end - n_start) / max(ticks - 1, 1)))[::sampling_stride]
+    return series, t, n
