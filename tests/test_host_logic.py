@@ -308,3 +308,15 @@ def test_model_hook_runs_before_the_state_dict_is_loaded(tmp_path, ckpt_wofx):
         U.MODEL_HOOK = None
     plain, _ = U.load_diffusion_model(str(tmp_path / "model_trained"), "cpu", train_model_select="wo_UANS")    # no hook: entries dropped
     assert plain.cond_pred_model is None
+
+
+def test_headline_sampler_kernel_keeps_its_step_body_free_of_scratch_traffic():
+    """Build-time guard: the split-f16 chain kernel is vector-issue bound, so a spill inside the reverse-step body costs
+    issue slots directly.  tools/check_spills.py compiles the kernel, finds the step body of every instantiation and exits 1 if the
+    headline one (F = 1, Philox, three products) touches scratch there."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    run = subprocess.run([sys.executable, str(ROOT / "tools" / "check_spills.py")], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    assert "F=1, philox=1, products=3" in run.stdout
