@@ -192,7 +192,7 @@ struct AttnArgs {
 };
 
 constexpr int A_KC = 128;               // keys per chunk
-constexpr int A_QW = 2;                 // 16-query tiles per wave (K / V fragments are read from LDS once for both)
+constexpr int A_QW = 1;                 // 16-query tiles per wave (2 measured no faster: the kernel is not LDS-read bound)
 constexpr int A_QT = 64 * A_QW;         // queries per workgroup
 
 template <int E>
@@ -242,17 +242,34 @@ __global__ __launch_bounds__(256, 2) void nst_attn_kernel(const AttnArgs p) {
 #pragma unroll
         for (int t = 0; t < A_QW; ++t) w_max = max(w_max, w_kt[t]);
         __syncthreads();                // previous chunk fully consumed
-        // stage K chunk [key][E] and V chunk transposed [e][key]
-        for (int i = tid; i < n_kt * 16 * (E / 4); i += 256) {
-            const int key = i / (E / 4), e4 = (i % (E / 4)) * 4;
-            const int src = k0 + key < p.S ? k0 + key : p.S - 1;
-            const v4f kv = *reinterpret_cast<const v4f*>(p.K + ((size_t)b * p.S + src) * p.ldk + (size_t)h * E + e4);
-            *reinterpret_cast<v4f*>(Ks + key * KLD + e4) = kv;
-            const v4f vv = *reinterpret_cast<const v4f*>(p.V + ((size_t)b * p.S + src) * p.ldv + (size_t)h * E + e4);
-            Vt[(e4 + 0) * VLD + key] = vv[0];
-            Vt[(e4 + 1) * VLD + key] = vv[1];
-            Vt[(e4 + 2) * VLD + key] = vv[2];
-            Vt[(e4 + 3) * VLD + key] = vv[3];
+        // stage K chunk [key][E] and V chunk transposed [e][key]: every load of the chunk is issued before the first LDS write, so the
+        // global latency is paid once per chunk and not once per 256 float4
+        {
+            constexpr int NST = A_KC * (E / 4) / 256;
+            const int n_st = n_kt * 16 * (E / 4);
+            v4f kr[NST], vr[NST];
+#pragma unroll
+            for (int j = 0; j < NST; ++j) {
+                const int i = tid + 256 * j;
+                if (i < n_st) {
+                    const int key = i / (E / 4), e4 = (i % (E / 4)) * 4;
+                    const int src = k0 + key < p.S ? k0 + key : p.S - 1;
+                    kr[j] = *reinterpret_cast<const v4f*>(p.K + ((size_t)b * p.S + src) * p.ldk + (size_t)h * E + e4);
+                    vr[j] = *reinterpret_cast<const v4f*>(p.V + ((size_t)b * p.S + src) * p.ldv + (size_t)h * E + e4);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NST; ++j) {
+                const int i = tid + 256 * j;
+                if (i < n_st) {
+                    const int key = i / (E / 4), e4 = (i % (E / 4)) * 4;
+                    *reinterpret_cast<v4f*>(Ks + key * KLD + e4) = kr[j];
+                    Vt[(e4 + 0) * VLD + key] = vr[j][0];
+                    Vt[(e4 + 1) * VLD + key] = vr[j][1];
+                    Vt[(e4 + 2) * VLD + key] = vr[j][2];
+                    Vt[(e4 + 3) * VLD + key] = vr[j][3];
+                }
+            }
         }
         if (tid < A_KC) Dl[tid] = (p.delta && k0 + tid < p.S) ? p.delta[(size_t)b * p.S + k0 + tid] * ds : 0.0f;
         __syncthreads();
