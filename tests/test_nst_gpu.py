@@ -146,3 +146,45 @@ def test_load_rejects_unsupported_shapes():
     m, f = holder(cfg, O.random_state(cfg, 0))
     with pytest.raises(_native.MpvError, match="head width"):
         f(torch.zeros(2, 16, 1, device=dev()), None)
+
+
+def test_uncertainty_ews_on_a_full_nsdiff_model_directory(tmp_path, monkeypatch):
+    """A `task_model: NsDiff` / `train_model_select: NsDiff_model` directory in the reference's on-disk layout (checkpoint dict with
+    `cond_pred_model.*`, YAML with the backbone's keys) goes through `uncertainty_ews` end to end: strict load, f(x) -> g(x) -> sampler ->
+    reduction on device.  The curve equals a second run through the `y0hat=` input fed with the restatement's mean (same draws)."""
+    import numpy as np
+    from helpers import write_model_dir
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+    from oracle import nsdiff_oracle as NO
+    O = oracle()
+    cfg = O.config(dataset_nf=1, windows=40, pred_len=24, d_model=64, n_heads=2, d_ff=32, e_layers=2, d_layers=1)
+    sd = NO.random_state_dict(1, 10, 40, 24, 16, seed=11)                                  # sampler + sigma head + scaler
+    sd["scaler_mean"], sd["scaler_std"] = torch.tensor([0.8]), torch.tensor([0.4])
+    fx = O.random_state(cfg, seed=5)
+    sd.update({"cond_pred_model." + k: v for k, v in fx.items()})
+    net = dict(device="cuda", scaler_type="StandardScaler", task_model="NsDiff", rolling_length=16, diffusion_schedule="linear", diffusion_steps=10,
+               beta_start=1e-4, beta_end=0.02, n_z_samples=8, parallel_sample=4, windows=40, pred_len=24, dataset_nf=1, load_pretrain=False,
+               d_model=64, n_heads=2, d_ff=32, e_layers=2, d_layers=1, activation="gelu", p_hidden_dims=[64, 64], p_hidden_layers=2,
+               output_attention=False, noise_source="torch_cpu")
+    mdir = tmp_path / "model"
+    write_model_dir(mdir, sd, net, select="NsDiff_model")
+    g = torch.Generator().manual_seed(9)
+    series = (torch.randn(200, 6, generator=g).cumsum(0) * 0.05 + 0.8)                      # [ticks, V]
+    from test_gpu_parity import _reseed_after
+    _reseed_after(monkeypatch, H, "load_model_from_dir", 17)                                  # (constructing the model draws from the stream)
+    res = H.uncertainty_ews(model_save_file=mdir, torch_time_series=series, time_data=torch.arange(200) * 0.1, dynamic_type="biomass",
+                            sampling_t=0.1, sample_window_step=40, device=dev(), save_nsdiff_g=False)
+    assert len(res["ews"]) == 5 and np.isfinite(np.array(res["ews"], dtype=np.float64)).all()
+    model, _ = H.load_model_from_dir(mdir, device=torch.device(dev()))
+    assert type(model.cond_pred_model).__name__ == "Model" and torch.equal(model.cond_pred_model.decoder.projection.weight.cpu(),
+                                                                               fx["decoder.projection.weight"])
+    # the same five windows with the mean supplied from the CPU restatement instead of the native backbone
+    full = series.t().unsqueeze(-1)                                                          # [V, ticks, 1]
+    wins = torch.stack([full[:, 40 * w: 40 * w + 40] for w in range(5)])
+    scaled = (wins - sd["scaler_mean"]) / sd["scaler_std"]
+    y0 = O.forward(fx, cfg, scaled.reshape(30, 40, 1))[0].reshape(5, 6, 24, 1)
+    torch.manual_seed(17)
+    noise = model.host_noise(5, 6)
+    _, _, mpv, pm = model.sample_windows(full.to(dev()), 5, 0, 40, scale_input=True, y0hat=y0, noise=noise, summary=True)
+    np.testing.assert_allclose(np.array(res["ews"], dtype=np.float64), mpv.cpu().double().numpy(), rtol=2e-4)
+    np.testing.assert_allclose(np.array(res["pred_mean"], dtype=np.float64), pm.cpu().double().numpy(), rtol=2e-4, atol=1e-6)
