@@ -257,3 +257,22 @@ def test_gpu_harness_window_loop_with_attached_prior(golden_tmdm, tmp_path):
     want = torch.stack([p.double().var(dim=-1, unbiased=False).mean() for p in preds])
     assert rel_err(torch.tensor(np.array(ews, dtype=np.float64)), want) < 1e-5
     assert len(H._load_tensor_list(tmp_path / "c.pt")) == len(wins)
+
+
+@pytest.mark.gpu
+def test_gpu_harness_batches_windows_through_the_native_prior(golden_tmdm, tmp_path):
+    """TMDM in the harness with its own (native) prior network: one prior call and one sampler launch for a block of windows gives what
+    the reference's window-by-window loop of evaluation_step gives (shared reference noise stream)."""
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+    nf, steps = 2, 10
+    m = _model(golden_tmdm, "f2t10", nf, steps, device="cuda:0", noise_source="torch_cpu")
+    g = torch.Generator().manual_seed(3)
+    series = torch.randn(4, 60, nf, generator=g)
+    wins, tp = H.build_sliding_windows(series, np.arange(60) * 0.1, m.windows, 10)
+    torch.manual_seed(8)
+    preds = H.run_evaluation_cache(m, list(wins), m.pred_len, tmp_path / "c.pt", torch.device("cuda", 0), force_recompute=True)
+    torch.manual_seed(8)
+    loop = [m.evaluation_step(m.scaler_transform(torch.as_tensor(w).float().to("cuda:0")))[0] for w in wins]
+    assert len(preds) == len(loop) == len(wins)
+    for a, b in zip(preds, loop):
+        assert tuple(a.shape) == (4, m.pred_len, nf, m.n_z_samples) and rel_err(a, b) < 1e-5

@@ -362,18 +362,24 @@ def _native_shard(model, windows, pred_len, scale, keep_samples=True, graph=None
     inv_mean = model.scaler_mean.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
     preds, mpv_parts, mean_parts = [], [], []
     if not hasattr(model, "_prior_variance"):
-        # a model family without the stacked NsDiff entry (TMDM: its prior is the caller's torch module): the reference's
-        # own window loop, one evaluation_step per window (still the native sampler), then the device reduction
-        for w in windows:
-            x = torch.as_tensor(w).float()
+        # TMDM: the prior network (native ns-Transformer VAE mean, or a module the caller assigned) over all rows of a block of windows in
+        # one call, then ONE sampler launch for the block (the reference loops window by window, tmdm_adapter.py:116-155)
+        block = max(1, 4096 // max(V, 1))
+        for start in range(0, len(windows), block):
+            part = windows[start: start + block]
+            rows = _stack_windows(part).to(ctx.device)                        # [w*V, windows, F]
             if scale:
-                x = model.scaler_transform(x.to(model.scaler_mean.device))
-            outs, _ = model.evaluation_step(x)
-            outs = outs[:, -pred_len:].contiguous()
-            mpv, pm, _ = ctx.reduce(outs.to(ctx.device).unsqueeze(0).contiguous(), inv_std, inv_mean)
+                rows = model.scaler_transform(rows)
+            if getattr(model, "cond_pred_model", None) is None:
+                raise NotImplementedError("TMDM without a prior network: assign one to `cond_pred_model`")
+            with torch.no_grad():
+                _, y0, _, _ = model.cond_pred_model(rows, None, model._decoder_input(rows), None)
+            prior = y0[:, -model.pred_len:, :].reshape(len(part), V, model.pred_len, model.dataset_nf)
+            samples = model.sample_windows(prior)[:, :, -pred_len:].contiguous()          # [w, V, pred_len, F, S]
+            mpv, pm, _ = ctx.reduce(samples, inv_std, inv_mean)
             mpv_parts.append(mpv)
             mean_parts.append(pm)
-            preds.append(outs.unsqueeze(0))
+            preds.append(samples if dist_utils.active() else samples.cpu())
     else:
         chunk = _windows_per_launch(model, V)
         for start in range(0, len(windows), chunk):
