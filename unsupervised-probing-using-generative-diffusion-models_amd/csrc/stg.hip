@@ -107,8 +107,11 @@ struct TcnArgs {
     int co, T, d_h;
     const float *wsb, *bsb;         // the BLOCK's shortcut 1x1 conv [co][ci], [co] | null (identity)
     float* sc;                      // [N][co][T] shortcut(x), written when wsb
+    long long rows;                 // N
 };
 
+// (A matrix-pipe version of this block -- each causal convolution as a 16-channel x 16-step MFMA tile GEMM over (channel, tap) pairs, B
+// operand read straight out of the padded row in LDS -- was built and measured: 3.6 windows/s at C5 against 4.65 for this kernel.)
 // A thread owns one time step and ALL output channels (CO accumulators): an input sample is read from LDS once per tap instead of
 // once per output channel, the weights are staged in LDS as [k][c][4] so that one broadcast ds_read_b128 feeds four FMAs, and the
 // LayerNorm over the channels of a time step is register-local.  When the block's shortcut is a 1x1 convolution it is formed here
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void stg_tcn_ln_kernel(const TcnArgs p) {
     float* WB = W2 + CO * CO * 4;             // [ci][CO]     block shortcut (1x1 conv) | unused
     float* xs = WB + ci * CO;                 // [ci][T+2], two zeros in front (causal padding)
     float* h1 = xs + ci * TP;                 // [CO][T+2]
-    const long long n = blockIdx.x;
+    float* tvs = h1 + CO * TP;                // [CO] time-embedding projection of this step (the same for every row)
     for (int i = threadIdx.x; i < ci * CO; i += 256) {
         const int k = i / CO, c = i - k * CO;
         const float* w = p.w1 + (c * ci + k) * 3;
@@ -134,21 +137,25 @@ __global__ __launch_bounds__(256) void stg_tcn_ln_kernel(const TcnArgs p) {
         const float* w = p.w2 + (c * CO + k) * 3;
         *reinterpret_cast<f32x4*>(W2 + i * 4) = f32x4{w[0], w[1], w[2], 0.0f};
     }
+    for (int c = threadIdx.x; c < CO; c += 256) {
+        h1[c * TP] = h1[c * TP + 1] = 0.0f;
+        float a = p.bt[c];
+        for (int d = 0; d < p.d_h; ++d) a += p.wt[c * p.d_h + d] * p.temb[d];
+        tvs[c] = a;
+    }
+    // weights and the time embedding are staged once; the workgroup then walks over its rows
+    for (long long n = blockIdx.x; n < p.rows; n += gridDim.x) {
+    __syncthreads();                          // (first row: the staging above; later rows: the previous row is done with xs / h1)
     for (int i = threadIdx.x; i < ci * TP; i += 256) {
         const int c = i / TP, t = i - c * TP - 2;
         float v = 0.0f;
         if (t >= 0) v = c < p.c1 ? p.src1[(n * p.c1 + c) * T + t] : p.src2[(n * p.c2 + (c - p.c1)) * T + t];
         xs[i] = v;
     }
-    for (int c = threadIdx.x; c < CO; c += 256) h1[c * TP] = h1[c * TP + 1] = 0.0f;
+    __syncthreads();
     float tv[CO];
 #pragma unroll
-    for (int c = 0; c < CO; ++c) {
-        float a = p.bt[c];
-        for (int d = 0; d < p.d_h; ++d) a += p.wt[c * p.d_h + d] * p.temb[d];
-        tv[c] = a;
-    }
-    __syncthreads();
+    for (int c = 0; c < CO; ++c) tv[c] = tvs[c];
     for (int t = threadIdx.x; t < T; t += 256) {
         float acc[CO], sk[CO], sb[CO];
 #pragma unroll
@@ -205,6 +212,7 @@ __global__ __launch_bounds__(256) void stg_tcn_ln_kernel(const TcnArgs p) {
 #pragma unroll
         for (int c = 0; c < CO; ++c) p.out[(n * CO + c) * T + t] = acc[c] * rstd * p.lnw[c] + p.lnb[c];
     }
+    }                                         // rows
 }
 
 // ---- ResGatedGraphConv aggregation + ReLU: kqvs [N][4C] = (key | query | value | skip) -> out [N][C] ------------------------------
@@ -489,13 +497,16 @@ int forward(mpv_ctx* ctx, StgEngine& e, const float* xt, const float* xm, long l
             if (cur_c + c2 != s.c_in) return mpv_fail(ctx, MPV_ESTATE, "DiffSTG: block input channels do not match the layout");
             const int co = s.c_out, C = Td * co;
             TcnArgs a{cur, cur_c, src2, c2, s.r.w1, s.r.b1, s.r.ws1, s.r.bs1, s.r.wt, s.r.bt, temb, s.r.w2, s.r.b2, s.r.lnw, s.r.lnb, e.hn, co, s.T, d_h,
-                      s.r.ws, s.r.bs, e.up};
-            const size_t lds = sizeof(float) * ((size_t)s.c_in * (s.T + 2) + (size_t)co * (s.T + 2) + (size_t)s.c_in * co * 5 + (size_t)co * co * 4);
+                      s.r.ws, s.r.bs, e.up, N};
+            const size_t lds = sizeof(float) * ((size_t)s.c_in * (s.T + 2) + (size_t)co * (s.T + 2) + (size_t)s.c_in * co * 5 + (size_t)co * co * 4 + co);
+            // a workgroup stages the weights once and walks over its rows: as many workgroups as fit the chip at this LDS footprint
+            const long long per_cu = std::max<long long>(1, std::min<long long>(4, (long long)ctx->max_lds / (long long)lds));
+            const unsigned tcn_grid = (unsigned)std::min<long long>(N, per_cu * ctx->cu_count);
             if (lds > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "DiffSTG: a node row does not fit the LDS (sequence too long)");
 #define STG_TCN(CO_)                                                                                                                          \
     do {                                                                                                                                      \
         MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(stg_tcn_ln_kernel<CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(stg_tcn_ln_kernel<CO_>, dim3((unsigned)N), dim3(256), lds, st, a);                                                 \
+        hipLaunchKernelGGL(stg_tcn_ln_kernel<CO_>, dim3(tcn_grid), dim3(256), lds, st, a);                                                 \
     } while (0)
             switch (co) {
                 case 2: STG_TCN(2); break;
