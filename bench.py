@@ -102,8 +102,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=("c2", "c3", "c5"), default="c2",
+    ap.add_argument("--config", choices=("c2", "c3", "c4", "c5"), default="c2",
                     help="c2 (default, the headline): NsDiff 100-node biomass, N=32, T=50; c3: DiffusionTS 100-node SIS, N=32, T=100; "
+                         "c4: NsDiff 500-node Wilson-Cowan, N=64, T=50, ONE trajectory split over the ranks (strong scaling); "
                          "c5: DiffSTG 200-node small-world biomass, N=32, 50 inference steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=4, help="windows of the workload timed on the CPU oracle (each ~25 s on 16 threads)")
@@ -131,6 +132,9 @@ def main():
     if args.config == "c5":
         from mpv_amd.bench_stg import main_c5
         return main_c5(args, log)
+    if args.config == "c4":
+        from mpv_amd.bench_c4 import main_c4
+        return main_c4(args, log)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

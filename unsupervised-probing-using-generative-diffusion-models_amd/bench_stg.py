@@ -118,13 +118,13 @@ def main_c5(args, log):
     out = {
         "metric": "rolling windows/sec (N=32, 50 inference steps), DiffSTG", "value": wps * args.steps / elapsed, "unit": "windows/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (k = T+1 convolutions and graph-conv Linear maps on v_mfma_f32_16x16x4_f32, rest fp32 VALU)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (k = T+1 convolutions and graph-conv Linear maps as two-term f16 splits on v_mfma_f32_32x32x16_f16 with fp32 accumulate, rest fp32 VALU)", "data": "synthetic",
         "config": {"workload": "DiffSTG on 200-node small-world biomass trajectory (BASELINE configs[4]): T_h=T_p=100, d_h=4, multipliers [2,2], "
                                "2 blocks per resolution (12 residual blocks), Td_h=10, parallel_sampling=32 (6400 node rows per window), 50 DDIM steps; "
                                "{} window(s) per step of the {} of the trajectory".format(wps, n_total),
                    "windows_per_step_per_gpu": wps, "noise": "on-device Philox4x32-10", "weights": "seeded default init"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
-                     "traffic": None, "kernel": "stg_gemm_kernel + stg_tcn_ln_kernel + stg_gate_kernel (whole sampler call)",
+                     "traffic": None, "kernel": "nst_gemm_h3_kernel + stg_tcn_ln_kernel + stg_gate_kernel (whole sampler call)",
                      "flop_per_window": flop_per_window, "flop_per_row_forward": fpr,
                      "note": "achieved = algorithmic FLOPs / wall time of the timed steps; the network is small (2.7e7 FLOP per node row per step), "
                              "so activation traffic through HBM between its ~60 kernels per step matters as much as the matrix pipe"},
