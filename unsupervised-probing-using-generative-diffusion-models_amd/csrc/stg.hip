@@ -255,6 +255,67 @@ __global__ void stg_res_out_kernel(const float* __restrict__ up, const float* __
 }
 
 // ---- Downsample: Conv2d(c, c, (1,3), stride 2, pad 1); Upsample: ConvTranspose2d(c, c, (1,4), stride 2, pad 1) ---------------
+// Resampling convolutions of the U-Net (Downsample: Conv1d(c, c, 3, stride 2, pad 1); Upsample: ConvTranspose1d(c, c, 4, stride 2, pad 1)), one
+// node row per pass of a persistent workgroup: the row is staged in LDS once, a thread owns one output step and ALL output channels (an input
+// sample is read once per tap, not once per output channel), weights sit in LDS as [ci][tap][co] so one broadcast ds_read_b128 feeds 4 FMAs.
+template <int C, bool UP>
+__global__ __launch_bounds__(256) void stg_resample_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, int T, int To,
+                                                           long long rows, float* __restrict__ out) {
+    constexpr int KT = UP ? 4 : 3;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* W = sm;                              // [C][KT][C]
+    float* xs = W + C * KT * C;                 // [C][T + 2], one zero on each side
+    const int TP = T + 2, tid = threadIdx.x;
+    for (int i = tid; i < C * KT * C; i += 256) {
+        const int ci = i / (KT * C), k = (i / C) % KT, co = i % C;
+        W[i] = UP ? w[(ci * C + co) * 4 + k] : w[(co * C + ci) * 3 + k];       // ConvTranspose weights are [in][out][k]
+    }
+    for (int c = tid; c < C; c += 256) xs[c * TP] = xs[c * TP + T + 1] = 0.0f;
+    for (long long n = blockIdx.x; n < rows; n += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < C * T; i += 256) {
+            const int c = i / T, t = i - c * T;
+            xs[c * TP + 1 + t] = x[n * C * T + i];
+        }
+        __syncthreads();
+        for (int t = tid; t < To; t += 256) {
+            float acc[C];
+#pragma unroll
+            for (int co = 0; co < C; ++co) acc[co] = b[co];
+            if (UP) {                            // t = 2 j + k - 1: even t takes taps (1, j = t/2) and (3, j = t/2 - 1); odd t taps (0, (t+1)/2) and (2, (t-1)/2)
+                const int ka = (t & 1) ? 0 : 1, ja = (t & 1) ? (t + 1) >> 1 : t >> 1, kb = ka + 2, jb = ja - 1;
+#pragma nounroll
+                for (int ci = 0; ci < C; ++ci) {
+                    const float xa = xs[ci * TP + 1 + ja], xb = xs[ci * TP + 1 + jb];     // ja == T and jb == -1 read the zero pads
+                    const float* wa = W + (ci * KT + ka) * C;
+                    const float* wb = W + (ci * KT + kb) * C;
+#pragma unroll
+                    for (int co = 0; co < C; co += 4) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(wa + co), b4 = *reinterpret_cast<const f32x4*>(wb + co);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[co + e] += a4[e] * xa + b4[e] * xb;
+                    }
+                }
+            } else {
+#pragma nounroll
+                for (int ci = 0; ci < C; ++ci) {
+                    const float x0 = xs[ci * TP + 2 * t], x1 = xs[ci * TP + 2 * t + 1], x2 = xs[ci * TP + 2 * t + 2];      // input steps 2t-1, 2t, 2t+1 (pads are zero)
+                    const float* w0 = W + ci * KT * C;
+#pragma unroll
+                    for (int co = 0; co < C; co += 4) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(w0 + co), b4 = *reinterpret_cast<const f32x4*>(w0 + C + co),
+                                    c4 = *reinterpret_cast<const f32x4*>(w0 + 2 * C + co);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[co + e] += (a4[e] * x0 + b4[e] * x1) + c4[e] * x2;
+                    }
+                }
+            }
+#pragma unroll
+            for (int co = 0; co < C; ++co) out[(n * C + co) * To + t] = acc[co];
+        }
+    }
+}
+
 __global__ void stg_down_kernel(const float* __restrict__ x, const float* __restrict__ w /*[c][c][3]*/, const float* __restrict__ b, int c, int T, int To,
                                 long long n, float* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // (node*c + co)*To + t
@@ -481,11 +542,29 @@ int forward(mpv_ctx* ctx, StgEngine& e, const float* xt, const float* xm, long l
     for (size_t i = 0; i < e.steps.size(); ++i) {
         const Step& s = e.steps[i];
         float* out = e.act[i + 1];
-        if (s.kind == 1) {
-            const int To = (s.T - 1) / 2 + 1;
-            hipLaunchKernelGGL(stg_down_kernel, g1d(N * s.c_out * To), dim3(256), 0, st, cur, s.cw, s.cb, s.c_out, s.T, To, N * s.c_out * To, out);
-        } else if (s.kind == 2) {
-            hipLaunchKernelGGL(stg_up_kernel, g1d(N * s.c_out * 2 * s.T), dim3(256), 0, st, cur, s.cw, s.cb, s.c_out, s.T, 2 * s.T, N * s.c_out * 2 * s.T, out);
+        if (s.kind == 1 || s.kind == 2) {
+            const bool up = s.kind == 2;
+            const int c = s.c_out, To = up ? 2 * s.T : (s.T - 1) / 2 + 1;
+            const size_t lds = sizeof(float) * ((size_t)c * (up ? 4 : 3) * c + (size_t)c * (s.T + 2));
+            const long long per_cu = std::max<long long>(1, std::min<long long>(8, (long long)ctx->max_lds / (long long)std::max<size_t>(lds, 1)));
+            const unsigned grid = (unsigned)std::min<long long>(N, per_cu * ctx->cu_count);
+#define STG_RESAMPLE(C_)                                                                                                                       \
+    do {                                                                                                                                      \
+        if (up) {                                                                                                                             \
+            MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(stg_resample_kernel<C_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((stg_resample_kernel<C_, true>), dim3(grid), dim3(256), lds, st, cur, s.cw, s.cb, s.T, To, N, out);             \
+        } else {                                                                                                                              \
+            MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(stg_resample_kernel<C_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((stg_resample_kernel<C_, false>), dim3(grid), dim3(256), lds, st, cur, s.cw, s.cb, s.T, To, N, out);            \
+        }                                                                                                                                     \
+    } while (0)
+            if (lds <= ctx->max_lds && c == 4) STG_RESAMPLE(4);
+            else if (lds <= ctx->max_lds && c == 8) STG_RESAMPLE(8);
+            else if (lds <= ctx->max_lds && c == 16) STG_RESAMPLE(16);
+            else if (lds <= ctx->max_lds && c == 32) STG_RESAMPLE(32);
+            else if (up) hipLaunchKernelGGL(stg_up_kernel, g1d(N * c * To), dim3(256), 0, st, cur, s.cw, s.cb, c, s.T, To, N * c * To, out);
+            else hipLaunchKernelGGL(stg_down_kernel, g1d(N * c * To), dim3(256), 0, st, cur, s.cw, s.cb, c, s.T, To, N * c * To, out);
+#undef STG_RESAMPLE
         } else {
             const float* src2 = nullptr;
             int c2 = 0;
