@@ -164,15 +164,27 @@ __global__ __launch_bounds__(256) void stg_tcn_ln_kernel(const TcnArgs p) {
             sk[c] = p.ws1 ? p.bs1[c] : xs[c * TP + t + 2];
             sb[c] = p.wsb ? p.bsb[c] : 0.0f;
         }
+        if (!p.ws1 && !p.wsb) {                  // identity shortcuts (most blocks): the convolution alone
 #pragma nounroll
-        for (int k = 0; k < ci; ++k) {
-            const float x0 = xs[k * TP + t], x1 = xs[k * TP + t + 1], x2 = xs[k * TP + t + 2];
+            for (int k = 0; k < ci; ++k) {
+                const float x0 = xs[k * TP + t], x1 = xs[k * TP + t + 1], x2 = xs[k * TP + t + 2];
 #pragma unroll
-            for (int c = 0; c < CO; ++c) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(W1 + (k * CO + c) * 4);
-                acc[c] += w[0] * x0 + w[1] * x1 + w[2] * x2;
-                sk[c] += w[3] * x2;
-                sb[c] += WB[k * CO + c] * x2;
+                for (int c = 0; c < CO; ++c) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(W1 + (k * CO + c) * 4);
+                    acc[c] += w[0] * x0 + w[1] * x1 + w[2] * x2;
+                }
+            }
+        } else {
+#pragma nounroll
+            for (int k = 0; k < ci; ++k) {
+                const float x0 = xs[k * TP + t], x1 = xs[k * TP + t + 1], x2 = xs[k * TP + t + 2];
+#pragma unroll
+                for (int c = 0; c < CO; ++c) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(W1 + (k * CO + c) * 4);
+                    acc[c] += w[0] * x0 + w[1] * x1 + w[2] * x2;
+                    sk[c] += w[3] * x2;
+                    sb[c] += WB[k * CO + c] * x2;
+                }
             }
         }
 #pragma unroll
