@@ -215,18 +215,38 @@ __global__ void dts_fourier_select_kernel(const float* __restrict__ spec, int NF
     const float* im = re + (long long)NFp * D;
     float best[DTS_MAX_TOPK];
     int bi[DTS_MAX_TOPK];
-    for (int j = 0; j < topk; ++j) { best[j] = -1.0f; bi[j] = 0; }
-    for (int k = 0; k < NF; ++k) {
-        const float a = hypotf(re[(long long)k * D], im[(long long)k * D]);
-        int j = topk;
-        while (j > 0 && a > best[j - 1]) --j;                          // strict: an earlier bin wins a tie
-        if (j < topk) {
-            for (int q = topk - 1; q > j; --q) { best[q] = best[q - 1]; bi[q] = bi[q - 1]; }
-            best[j] = a;
-            bi[j] = k;
+#pragma unroll
+    for (int j = 0; j < DTS_MAX_TOPK; ++j) { best[j] = -1.0f; bi[j] = 0; }
+    constexpr int CH = 12;                                             // bins fetched per batch: the loads go out together, then the serial insertion runs
+    for (int k0 = 0; k0 < NF; k0 += CH) {
+        float rr[CH], ii[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int k = min(k0 + u, NF - 1);
+            rr[u] = re[(long long)k * D];
+            ii[u] = im[(long long)k * D];
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int k = k0 + u;
+            if (k >= NF) break;
+            const float a = hypotf(rr[u], ii[u]);
+            if (!(a > best[topk - 1])) continue;                       // strict: an earlier bin wins a tie
+            // insertion with compile-time register indices only (a run-time index would put best[] / bi[] in scratch memory)
+            int j = 0;
+#pragma unroll
+            for (int q = 0; q < DTS_MAX_TOPK; ++q) j += (q < topk && best[q] >= a) ? 1 : 0;
+#pragma unroll
+            for (int q = DTS_MAX_TOPK - 1; q > 0; --q)
+                if (q < topk && q > j) { best[q] = best[q - 1]; bi[q] = bi[q - 1]; }
+#pragma unroll
+            for (int q = 0; q < DTS_MAX_TOPK; ++q)
+                if (q == j) { best[q] = a; bi[q] = k; }
         }
     }
-    for (int j = 0; j < topk; ++j) {
+#pragma unroll
+    for (int j = 0; j < DTS_MAX_TOPK; ++j) {
+        if (j >= topk) break;
         const long long o = (b * topk + j) * D + d;
         idx[o] = bi[j];
         amp[o] = best[j];
