@@ -106,11 +106,11 @@ int attn_launch(mpv_ctx* ctx, int mode, const AttnArgs& a, int B) {
         if (int rc = set_lds(ctx, dts_attn_fwd_kernel<E>, lds)) return rc;        // (a one-pass softmax with the 13 score tiles of a query tile in
         hipLaunchKernelGGL(dts_attn_fwd_kernel<E>, grid, block, lds, ctx->stream, a);   //  registers measured 15 % slower than this online one)
     } else if (mode == 1) {
-        const size_t lds = sizeof(float) * (2 * (size_t)Lkp * RS + 16 * (Lkp + 4));
+        const size_t lds = sizeof(float) * (2 * (size_t)Lkp * RS);
         if (int rc = set_lds(ctx, dts_attn_dq_kernel<E>, lds)) return rc;
         hipLaunchKernelGGL(dts_attn_dq_kernel<E>, grid, block, lds, ctx->stream, a);
     } else {
-        const size_t lds = sizeof(float) * (2 * (size_t)Lqp * RS + 32 * (Lqp + 4) + 2 * Lqp);
+        const size_t lds = sizeof(float) * (2 * (size_t)Lqp * RS + 2 * Lqp);
         if (int rc = set_lds(ctx, dts_attn_dkv_kernel<E>, lds)) return rc;
         hipLaunchKernelGGL(dts_attn_dkv_kernel<E>, grid, block, lds, ctx->stream, a);
     }
