@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "dts_small.h"
+#include "nst_gemm.h"
 
 using namespace dts;
 
@@ -73,6 +74,19 @@ int lin(mpv_ctx* ctx, const float* X, int ldx, const float* W, const float* bias
     const long long per_cu = std::max<long long>(1, std::min<long long>(4, (long long)ctx->max_lds / (long long)lds));
     const int grid = (int)std::min<long long>(tiles, per_cu * ctx->cu_count);
     hipLaunchKernelGGL(dts_lin_kernel, dim3(grid), dim3(LIN_THREADS), lds, ctx->stream, a);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+// Y = X W^T (W [N][K]) on the tiled exact-fp32 MFMA GEMM of nst_gemm.h (128x128x32 LDS tiles, two workgroups per CU), for the two
+// products of an MLP's backward whose operands are too wide for dts_lin_kernel's "all of W + a 64-token tile in LDS" to leave more than
+// one workgroup per CU.  act 3: the epilogue multiplies by gelu'(U).
+int wide_gemm(mpv_ctx* ctx, const float* X, int ldx, const float* W, int K, int N, long long rows, float* Y, int ldy, const float* U = nullptr, int ldu = 0) {
+    NstGemmArgs a{X, ldx, W, nullptr, U, ldu, Y, ldy, rows, N, K, U ? 3 : 0};
+    const size_t lds = sizeof(float) * 2 * (G_BM + G_BN) * G_LD;
+    if (int rc = set_lds(ctx, nst_gemm_kernel, lds)) return rc;
+    const long long tiles = ((rows + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
+    hipLaunchKernelGGL(nst_gemm_kernel, dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(256), lds, ctx->stream, a);
     MPV_HIP_TRY(ctx, hipGetLastError());
     return MPV_OK;
 }
@@ -327,8 +341,13 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
         MPV_HIP_TRY(ctx, hipGetLastError());
         std::swap(gcur, gnext);                                          // gcur = d_x3
         // x3 = x2 + mlp(ln2(x2))
-        DTS_TRY(lin(ctx, gcur, D, w.w2_t, nullptr, D, M, T, e.gwide, M));
-        DTS_TRY(lin(ctx, e.gwide, M, w.w0_t, nullptr, M, D, T, e.gC, D, PRO_GELUGRAD, s.u, nullptr, M));
+        if (D % G_BK == 0 && M % G_BK == 0) {                                  // d_hidden = (g W2) * gelu'(u), then d_ln = d_hidden W0
+            DTS_TRY(wide_gemm(ctx, gcur, D, w.w2_t, D, M, T, e.gwide, M, s.u, M));
+            DTS_TRY(wide_gemm(ctx, e.gwide, M, w.w0_t, M, D, T, e.gC, D));
+        } else {
+            DTS_TRY(lin(ctx, gcur, D, w.w2_t, nullptr, D, M, T, e.gwide, M));
+            DTS_TRY(lin(ctx, e.gwide, M, w.w0_t, nullptr, M, D, T, e.gC, D, PRO_GELUGRAD, s.u, nullptr, M));
+        }
         DTS_TRY(ln_bwd(ctx, D, e.gC, s.x2, w.ln2w, 0, gcur, 1, T));     // gcur = d_x2 (so far)
         // trend / season branches through proj
         hipLaunchKernelGGL(dts_trend_bwd_kernel, dim3(B), dim3(256), sizeof(float) * (3 * F + 3 * D), st, gout, s.t3, w.tw0, w.tw3, e.poly, L, F, D, gcur,
@@ -357,8 +376,13 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
         const EncW& w = e.enc[i];
         const DtsEngine::EncS& s = e.es[i];
         const float* sc = ada_t + (size_t)i * 2 * D;
-        DTS_TRY(lin(ctx, genc, D, w.w2_t, nullptr, D, M, T, e.gwide, M));
-        DTS_TRY(lin(ctx, e.gwide, M, w.w0_t, nullptr, M, D, T, e.gC, D, PRO_GELUGRAD, s.u, nullptr, M));
+        if (D % G_BK == 0 && M % G_BK == 0) {
+            DTS_TRY(wide_gemm(ctx, genc, D, w.w2_t, D, M, T, e.gwide, M, s.u, M));
+            DTS_TRY(wide_gemm(ctx, e.gwide, M, w.w0_t, M, D, T, e.gC, D));
+        } else {
+            DTS_TRY(lin(ctx, genc, D, w.w2_t, nullptr, D, M, T, e.gwide, M));
+            DTS_TRY(lin(ctx, e.gwide, M, w.w0_t, nullptr, M, D, T, e.gC, D, PRO_GELUGRAD, s.u, nullptr, M));
+        }
         DTS_TRY(ln_bwd(ctx, D, e.gC, s.x1, w.ln2w, 0, genc, 1, T));    // genc = d_x1
         DTS_TRY(lin(ctx, genc, D, w.wp_t, nullptr, D, D, T, e.gC, D));
         DTS_TRY(attn_bwd(ctx, e, B, s.qkv, 3 * D, s.qkv + D, s.qkv + 2 * D, 3 * D, s.att, e.gC, s.lse, e.gqkv, 3 * D, e.gqkv + D, e.gqkv + 2 * D, 3 * D));

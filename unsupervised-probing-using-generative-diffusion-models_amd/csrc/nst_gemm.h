@@ -21,7 +21,7 @@ struct NstGemmArgs {
     float* Y; long long ldy;
     long long M;
     int N, K;
-    int act;                  // 0 none, 1 relu, 2 gelu
+    int act;                  // 0 none, 1 relu, 2 gelu, 3 multiply by gelu'(R) instead of adding R
 };
 
 constexpr int G_BM = 128, G_BN = 128, G_BK = 32, G_LD = G_BK + 4;
@@ -75,7 +75,12 @@ __device__ __forceinline__ void gemm_store_tile(float* Cs, const v16f (&acc)[2][
 #pragma unroll
             for (int c = 0; c < 4; ++c) y[c] = nst_gelu(y[c]);
         }
-        if (R) y += *reinterpret_cast<const v4f*>(R + (size_t)m * ldr + n);
+        if (act == 3) {                           // y *= gelu'(R[m][n]): the GELU backward of an MLP, R = the saved pre-activation
+            const v4f u = *reinterpret_cast<const v4f*>(R + (size_t)m * ldr + n);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                y[c] *= 0.5f * (1.0f + erff(u[c] * 0.70710678118654752f)) + u[c] * 0.39894228040143268f * __expf(-0.5f * u[c] * u[c]);
+        } else if (R) y += *reinterpret_cast<const v4f*>(R + (size_t)m * ldr + n);
         if (!PROBE_NO_STORE || y[0] == 1.2345e30f) *reinterpret_cast<v4f*>(Y + (size_t)m * ldy + n) = y;
     }
 }
