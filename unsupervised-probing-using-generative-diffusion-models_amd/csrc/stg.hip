@@ -108,6 +108,7 @@ struct TcnArgs {
     const float *wsb, *bsb;         // the BLOCK's shortcut 1x1 conv [co][ci], [co] | null (identity)
     float* sc;                      // [N][co][T] shortcut(x), written when wsb
     long long rows;                 // N
+    int tseg, nseg;                 // time steps per workgroup item, items per row (nseg * tseg >= T)
 };
 
 // (A matrix-pipe version of this block -- each causal convolution as a 16-channel x 16-step MFMA tile GEMM over (channel, tap) pairs, B
@@ -119,13 +120,16 @@ struct TcnArgs {
 template <int CO>
 __global__ __launch_bounds__(256) void stg_tcn_ln_kernel(const TcnArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int ci = p.c1 + p.c2, T = p.T, TP = T + 2;
+    // A workgroup handles one SEGMENT of a row's time axis (p.tseg steps, p.nseg segments per row) with a causal halo: tcn2 at step t reads
+    // h1[t-2..t] and h1 at step t reads x[t-2..t], so a segment [t0, t1) stages x[t0-4, t1) and forms h1 on [t0-2, t1).  Halving the
+    // segment halves the LDS footprint: the concatenating blocks (ci = 2 co) go from one to two or three workgroups per CU.
+    const int ci = p.c1 + p.c2, T = p.T, XP = p.tseg + 4, HP = p.tseg + 2;
     float* W1 = sm;                           // [ci][CO][4] = (w1 tap0, tap1, tap2, tcn1.shortcut)
     float* W2 = W1 + ci * CO * 4;             // [CO][CO][4] = (w2 tap0, tap1, tap2, 0)
     float* WB = W2 + CO * CO * 4;             // [ci][CO]     block shortcut (1x1 conv) | unused
-    float* xs = WB + ci * CO;                 // [ci][T+2], two zeros in front (causal padding)
-    float* h1 = xs + ci * TP;                 // [CO][T+2]
-    float* tvs = h1 + CO * TP;                // [CO] time-embedding projection of this step (the same for every row)
+    float* xs = WB + ci * CO;                 // [ci][tseg+4]: x at steps t0-4 .. t1-1 (zeros before the row starts)
+    float* h1 = xs + ci * XP;                 // [CO][tseg+2]: h1 at steps t0-2 .. t1-1 (zeros before the row starts: tcn2's causal padding)
+    float* tvs = h1 + CO * HP;                // [CO] time-embedding projection of this step (the same for every row)
     for (int i = threadIdx.x; i < ci * CO; i += 256) {
         const int k = i / CO, c = i - k * CO;
         const float* w = p.w1 + (c * ci + k) * 3;
@@ -138,93 +142,101 @@ __global__ __launch_bounds__(256) void stg_tcn_ln_kernel(const TcnArgs p) {
         *reinterpret_cast<f32x4*>(W2 + i * 4) = f32x4{w[0], w[1], w[2], 0.0f};
     }
     for (int c = threadIdx.x; c < CO; c += 256) {
-        h1[c * TP] = h1[c * TP + 1] = 0.0f;
         float a = p.bt[c];
         for (int d = 0; d < p.d_h; ++d) a += p.wt[c * p.d_h + d] * p.temb[d];
         tvs[c] = a;
     }
-    // weights and the time embedding are staged once; the workgroup then walks over its rows
-    for (long long n = blockIdx.x; n < p.rows; n += gridDim.x) {
-    __syncthreads();                          // (first row: the staging above; later rows: the previous row is done with xs / h1)
-    for (int i = threadIdx.x; i < ci * TP; i += 256) {
-        const int c = i / TP, t = i - c * TP - 2;
-        float v = 0.0f;
-        if (t >= 0) v = c < p.c1 ? p.src1[(n * p.c1 + c) * T + t] : p.src2[(n * p.c2 + (c - p.c1)) * T + t];
-        xs[i] = v;
-    }
-    __syncthreads();
-    float tv[CO];
-#pragma unroll
-    for (int c = 0; c < CO; ++c) tv[c] = tvs[c];
-    for (int t = threadIdx.x; t < T; t += 256) {
-        float acc[CO], sk[CO], sb[CO];
-#pragma unroll
-        for (int c = 0; c < CO; ++c) {
-            acc[c] = p.b1[c];
-            sk[c] = p.ws1 ? p.bs1[c] : xs[c * TP + t + 2];
-            sb[c] = p.wsb ? p.bsb[c] : 0.0f;
+    // weights and the time embedding are staged once; the workgroup then walks over its (row, segment) items
+    for (long long item = blockIdx.x; item < p.rows * p.nseg; item += gridDim.x) {
+        const long long n = item / p.nseg;
+        const int t0 = (int)(item - n * p.nseg) * p.tseg, t1 = min(T, t0 + p.tseg), tl = t1 - t0;
+        __syncthreads();                      // (first item: the staging above; later items: the previous one is done with xs / h1)
+        for (int i = threadIdx.x; i < ci * XP; i += 256) {
+            const int c = i / XP, t = t0 - 4 + (i - c * XP);
+            float v = 0.0f;
+            if (t >= 0 && t < t1) v = c < p.c1 ? p.src1[(n * p.c1 + c) * T + t] : p.src2[(n * p.c2 + (c - p.c1)) * T + t];
+            xs[i] = v;
         }
-        if (!p.ws1 && !p.wsb) {                  // identity shortcuts (most blocks): the convolution alone
-#pragma nounroll
-            for (int k = 0; k < ci; ++k) {
-                const float x0 = xs[k * TP + t], x1 = xs[k * TP + t + 1], x2 = xs[k * TP + t + 2];
+        __syncthreads();
+        float tv[CO];
 #pragma unroll
-                for (int c = 0; c < CO; ++c) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(W1 + (k * CO + c) * 4);
-                    acc[c] += w[0] * x0 + w[1] * x1 + w[2] * x2;
-                }
+        for (int c = 0; c < CO; ++c) tv[c] = tvs[c];
+        for (int u = threadIdx.x; u < tl + 2; u += 256) {            // h1 at step t = t0 - 2 + u from x at local columns u .. u+2
+            const int t = t0 - 2 + u;
+            if (t < 0) {
+#pragma unroll
+                for (int c = 0; c < CO; ++c) h1[c * HP + u] = 0.0f;
+                continue;
             }
-        } else {
-#pragma nounroll
-            for (int k = 0; k < ci; ++k) {
-                const float x0 = xs[k * TP + t], x1 = xs[k * TP + t + 1], x2 = xs[k * TP + t + 2];
-#pragma unroll
-                for (int c = 0; c < CO; ++c) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(W1 + (k * CO + c) * 4);
-                    acc[c] += w[0] * x0 + w[1] * x1 + w[2] * x2;
-                    sk[c] += w[3] * x2;
-                    sb[c] += WB[k * CO + c] * x2;
-                }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < CO; ++c) {
-            h1[c * TP + t + 2] = (acc[c] + sk[c]) + tv[c];
-            if (p.wsb) p.sc[(n * CO + c) * T + t] = sb[c];
-        }
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 256) {
-        float acc[CO];
-#pragma unroll
-        for (int c = 0; c < CO; ++c) acc[c] = p.b2[c];
-#pragma nounroll
-        for (int k = 0; k < CO; ++k) {
-            const float x0 = h1[k * TP + t], x1 = h1[k * TP + t + 1], x2 = h1[k * TP + t + 2];
+            float acc[CO], sk[CO], sb[CO];
 #pragma unroll
             for (int c = 0; c < CO; ++c) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(W2 + (k * CO + c) * 4);
-                acc[c] += w[0] * x0 + w[1] * x1 + w[2] * x2;
+                acc[c] = p.b1[c];
+                sk[c] = p.ws1 ? p.bs1[c] : xs[c * XP + u + 2];
+                sb[c] = p.wsb ? p.bsb[c] : 0.0f;
+            }
+            if (!p.ws1 && !p.wsb) {              // identity shortcuts (most blocks): the convolution alone
+#pragma nounroll
+                for (int k = 0; k < ci; ++k) {
+                    const float x0 = xs[k * XP + u], x1 = xs[k * XP + u + 1], x2 = xs[k * XP + u + 2];
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(W1 + (k * CO + c) * 4);
+                        acc[c] += w[0] * x0 + w[1] * x1 + w[2] * x2;
+                    }
+                }
+            } else {
+#pragma nounroll
+                for (int k = 0; k < ci; ++k) {
+                    const float x0 = xs[k * XP + u], x1 = xs[k * XP + u + 1], x2 = xs[k * XP + u + 2];
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(W1 + (k * CO + c) * 4);
+                        acc[c] += w[0] * x0 + w[1] * x1 + w[2] * x2;
+                        sk[c] += w[3] * x2;
+                        sb[c] += WB[k * CO + c] * x2;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                h1[c * HP + u] = (acc[c] + sk[c]) + tv[c];
+                if (p.wsb && t >= t0) p.sc[(n * CO + c) * T + t] = sb[c];          // (halo steps belong to the previous segment)
             }
         }
-        float s = 0.0f;
+        __syncthreads();
+        for (int v = threadIdx.x; v < tl; v += 256) {                 // output step t = t0 + v from h1 at local columns v .. v+2
+            const int t = t0 + v;
+            float acc[CO];
 #pragma unroll
-        for (int c = 0; c < CO; ++c) {
-            acc[c] += h1[c * TP + t + 2];
-            s += acc[c];
+            for (int c = 0; c < CO; ++c) acc[c] = p.b2[c];
+#pragma nounroll
+            for (int k = 0; k < CO; ++k) {
+                const float x0 = h1[k * HP + v], x1 = h1[k * HP + v + 1], x2 = h1[k * HP + v + 2];
+#pragma unroll
+                for (int c = 0; c < CO; ++c) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(W2 + (k * CO + c) * 4);
+                    acc[c] += w[0] * x0 + w[1] * x1 + w[2] * x2;
+                }
+            }
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                acc[c] += h1[c * HP + v + 2];
+                s += acc[c];
+            }
+            const float mean = s / (float)CO;                        // LayerNorm([1, co]) over the channels of this time step
+            float q = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                acc[c] -= mean;
+                q += acc[c] * acc[c];
+            }
+            const float rstd = 1.0f / sqrtf(q / (float)CO + 1e-5f);
+#pragma unroll
+            for (int c = 0; c < CO; ++c) p.out[(n * CO + c) * T + t] = acc[c] * rstd * p.lnw[c] + p.lnb[c];
         }
-        const float mean = s / (float)CO;                        // LayerNorm([1, co]) over the channels of this time step
-        float q = 0.0f;
-#pragma unroll
-        for (int c = 0; c < CO; ++c) {
-            acc[c] -= mean;
-            q += acc[c] * acc[c];
-        }
-        const float rstd = 1.0f / sqrtf(q / (float)CO + 1e-5f);
-#pragma unroll
-        for (int c = 0; c < CO; ++c) p.out[(n * CO + c) * T + t] = acc[c] * rstd * p.lnw[c] + p.lnb[c];
-    }
-    }                                         // rows
+    }                                         // items
 }
 
 // ---- ResGatedGraphConv aggregation + ReLU: kqvs [N][4C] = (key | query | value | skip) -> out [N][C] ------------------------------
@@ -588,11 +600,20 @@ int forward(mpv_ctx* ctx, StgEngine& e, const float* xt, const float* xm, long l
             if (cur_c + c2 != s.c_in) return mpv_fail(ctx, MPV_ESTATE, "DiffSTG: block input channels do not match the layout");
             const int co = s.c_out, C = Td * co;
             TcnArgs a{cur, cur_c, src2, c2, s.r.w1, s.r.b1, s.r.ws1, s.r.bs1, s.r.wt, s.r.bt, temb, s.r.w2, s.r.b2, s.r.lnw, s.r.lnb, e.hn, co, s.T, d_h,
-                      s.r.ws, s.r.bs, e.up, N};
-            const size_t lds = sizeof(float) * ((size_t)s.c_in * (s.T + 2) + (size_t)co * (s.T + 2) + (size_t)s.c_in * co * 5 + (size_t)co * co * 4 + co);
-            // a workgroup stages the weights once and walks over its rows: as many workgroups as fit the chip at this LDS footprint
+                      s.r.ws, s.r.bs, e.up, N, 0, 1};
+            // segments of the time axis (256 steps keep every thread busy in one pass) until at least two workgroups fit a CU
+            static const int seg_env = getenv("MPV_STG_TCN_SEG") ? atoi(getenv("MPV_STG_TCN_SEG")) : 0;
+            auto lds_of = [&](int tseg) { return sizeof(float) * ((size_t)s.c_in * (tseg + 4) + (size_t)co * (tseg + 2) + (size_t)s.c_in * co * 5 + (size_t)co * co * 4 + co); };
+            a.nseg = seg_env > 0 ? seg_env : 1;
+            a.tseg = (s.T + a.nseg - 1) / a.nseg;
+            while (seg_env == 0 && a.tseg > 64 && (lds_of(a.tseg) > ctx->max_lds / 2 || a.tseg > 256)) {
+                ++a.nseg;
+                a.tseg = (s.T + a.nseg - 1) / a.nseg;
+            }
+            const size_t lds = lds_of(a.tseg);
+            // a workgroup stages the weights once and walks over its items: as many workgroups as fit the chip at this LDS footprint
             const long long per_cu = std::max<long long>(1, std::min<long long>(4, (long long)ctx->max_lds / (long long)lds));
-            const unsigned tcn_grid = (unsigned)std::min<long long>(N, per_cu * ctx->cu_count);
+            const unsigned tcn_grid = (unsigned)std::min<long long>(N * a.nseg, per_cu * ctx->cu_count);
             if (lds > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "DiffSTG: a node row does not fit the LDS (sequence too long)");
 #define STG_TCN(CO_)                                                                                                                          \
     do {                                                                                                                                      \
