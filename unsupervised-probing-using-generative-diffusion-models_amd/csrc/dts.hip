@@ -153,14 +153,14 @@ int ln_bwd(mpv_ctx* ctx, int D, const float* g, const float* x, const float* gam
 int mlp_fwd(mpv_ctx* ctx, int D, int M, const float* X, const float* W0, const float* b0, const float* W2, const float* b2, const float* lnw,
             const float* lnb, float* Y, float* U, long long rows) {
     MlpArgs a{X, W0, b0, W2, b2, lnw, lnb, Y, U, rows};
-    const size_t lds = sizeof(float) * ((size_t)M * (D + 4) + (size_t)D * (M + 4) + 64 * (D + 4));
-    const long long tiles = (rows + 63) / 64;
-    const long long per_cu = std::max<long long>(1, std::min<long long>(4, (long long)ctx->max_lds / (long long)lds));
+    const size_t lds = sizeof(float) * ((size_t)M * (D + 4) + (size_t)D * (M + 4));
+    const long long tiles = ((rows + 15) / 16 + MLP_WAVES - 1) / MLP_WAVES;              // 16-token tiles, MLP_WAVES of them per workgroup pass
+    const long long per_cu = std::max<long long>(1, std::min<long long>(2, (long long)ctx->max_lds / (long long)lds));
     const int grid = (int)std::min<long long>(tiles, per_cu * ctx->cu_count);
 #define DTS_MLP(DT_, MT_)                                                                              \
     do {                                                                                               \
         if (int rc = set_lds(ctx, dts_mlp_fwd_kernel<DT_, MT_>, lds)) return rc;                       \
-        hipLaunchKernelGGL((dts_mlp_fwd_kernel<DT_, MT_>), dim3(grid), dim3(256), lds, ctx->stream, a); \
+        hipLaunchKernelGGL((dts_mlp_fwd_kernel<DT_, MT_>), dim3(grid), dim3(64 * MLP_WAVES), lds, ctx->stream, a); \
     } while (0)
     if (D == 64 && M == 256) DTS_MLP(4, 16);
     else if (D == 32 && M == 128) DTS_MLP(2, 8);

@@ -506,66 +506,64 @@ struct MlpArgs {
     long long rows;
 };
 
+constexpr int MLP_WAVES = 8;             // both weight matrices fill the LDS of a CU: one workgroup per CU, so it carries two waves per SIMD
+
 template <int DT, int MT>
-__global__ __launch_bounds__(256) void dts_mlp_fwd_kernel(const MlpArgs p) {
+__global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_fwd_kernel(const MlpArgs p) {
     constexpr int D = 16 * DT, M = 16 * MT, KS = D + 4, MS = M + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* W0l = lds;                     // [M][KS]
     float* W2l = W0l + M * KS;            // [D][MS]
-    float* Xl = W2l + D * MS;             // [64][KS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
-    for (int i = tid; i < M * (D / 4); i += 256) {
+    for (int i = tid; i < M * (D / 4); i += 64 * MLP_WAVES) {
         const int n = i / (D / 4), c = i - n * (D / 4);
         *reinterpret_cast<f32x4*>(W0l + n * KS + 4 * c) = *reinterpret_cast<const f32x4*>(p.W0 + (size_t)n * D + 4 * c);
     }
-    for (int i = tid; i < D * (M / 4); i += 256) {
+    for (int i = tid; i < D * (M / 4); i += 64 * MLP_WAVES) {
         const int n = i / (M / 4), c = i - n * (M / 4);
         *reinterpret_cast<f32x4*>(W2l + n * MS + 4 * c) = *reinterpret_cast<const f32x4*>(p.W2 + (size_t)n * M + 4 * c);
     }
-    const long long n_tiles = (p.rows + 63) / 64;
-    const int srow = tid >> 2, spart = tid & 3;
-    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        __syncthreads();
-        {   // stage 64 rows, LayerNorm applied (4 threads per row)
-            const long long tok = tile * 64 + srow;
-            const bool live = tok < p.rows;
-            const float* xr = p.X + (live ? tok : 0) * (long long)D;
-            float* dst = Xl + srow * KS;
-            f32x4 v[(DT + 3) / 4 > 0 ? DT : 1];
-            float s = 0.0f;
-            int cnt = 0;
-            for (int c = spart; c < D / 4; c += 4, ++cnt) {
-                v[cnt] = live ? *reinterpret_cast<const f32x4*>(xr + 4 * c) : f32x4{0, 0, 0, 0};
-                s += (v[cnt][0] + v[cnt][1]) + (v[cnt][2] + v[cnt][3]);
-            }
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            const float mean = s / (float)D;
-            float q = 0.0f;
-            for (int k = 0; k < cnt; ++k)
+    __syncthreads();
+    // Every wave walks over its own 16-token tiles, nothing else goes through LDS: the tile's rows are loaded straight into the B-operand
+    // layout (lane = token r16, k-slot g: X[tok][16 s + 4 g ..]), the LayerNorm statistics of a token are combined over its four lanes with
+    // two shuffles, and no barrier separates the waves -- one wave's GELU (vector pipe) runs under another wave's MFMAs.
+    f32x4 lw[DT], lb[DT];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[k][e] -= mean;
-                    q += v[k][e] * v[k][e];
-                }
-            q += __shfl_xor(q, 1);
-            q += __shfl_xor(q, 2);
-            const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
-            cnt = 0;
-            for (int c = spart; c < D / 4; c += 4, ++cnt) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(p.lnw + 4 * c), bb = *reinterpret_cast<const f32x4*>(p.lnb + 4 * c);
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = v[cnt][e] * rstd * a[e] + bb[e];
-                *reinterpret_cast<f32x4*>(dst + 4 * c) = o;
-            }
-        }
-        __syncthreads();
-        const long long tok = tile * 64 + 16 * wave + r16;
+    for (int s = 0; s < DT; ++s) {
+        lw[s] = *reinterpret_cast<const f32x4*>(p.lnw + 16 * s + 4 * g);
+        lb[s] = *reinterpret_cast<const f32x4*>(p.lnb + 16 * s + 4 * g);
+    }
+    const long long n_tiles = (p.rows + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * MLP_WAVES) {
+        asm volatile("" ::: "memory");        // the weight fragments are re-read from LDS every tile (hoisted out of the loop they need 320 registers)
+        const long long tok = tile * 16 + r16;
         const bool live = tok < p.rows;
+        const float* xr = p.X + (live ? tok : 0) * (long long)D + 4 * g;
         f32x4 xb[DT];
+        float sum = 0.0f;
 #pragma unroll
-        for (int s = 0; s < DT; ++s) xb[s] = *reinterpret_cast<const f32x4*>(Xl + (16 * wave + r16) * KS + 16 * s + 4 * g);
+        for (int s = 0; s < DT; ++s) {
+            xb[s] = live ? *reinterpret_cast<const f32x4*>(xr + 16 * s) : f32x4{0, 0, 0, 0};
+            sum += (xb[s][0] + xb[s][1]) + (xb[s][2] + xb[s][3]);
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum / (float)D;
+        float q = 0.0f;
+#pragma unroll
+        for (int s = 0; s < DT; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xb[s][e] -= mean;
+                q += xb[s][e] * xb[s][e];
+            }
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
+#pragma unroll
+        for (int s = 0; s < DT; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xb[s][e] = xb[s][e] * rstd * lw[s][e] + lb[s][e];
         f32x4 u[MT];
 #pragma unroll
         for (int nt = 0; nt < MT; ++nt) {
