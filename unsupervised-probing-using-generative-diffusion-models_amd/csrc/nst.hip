@@ -191,12 +191,12 @@ struct AttnArgs {
     float scale;
 };
 
-constexpr int A_KC = 128;               // keys per chunk
+constexpr int A_KC = 64;                // keys per chunk (35 KB of LDS per workgroup: four per CU)
 constexpr int A_QW = 1;                 // 16-query tiles per wave (2 measured no faster: the kernel is not LDS-read bound)
 constexpr int A_QT = 64 * A_QW;         // queries per workgroup
 
 template <int E>
-__global__ __launch_bounds__(256, 2) void nst_attn_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, 4) void nst_attn_kernel(const AttnArgs p) {
     constexpr int KLD = E + 4, VLD = A_KC + 4, ES = E / 16;
     __shared__ float Ks[A_KC * KLD];
     __shared__ float Vt[E * VLD];
