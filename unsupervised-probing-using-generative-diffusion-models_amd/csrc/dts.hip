@@ -171,6 +171,27 @@ int mlp_fwd(mpv_ctx* ctx, int D, int M, const float* X, const float* W0, const f
     return MPV_OK;
 }
 
+// d_ln = W0^T (gelu'(u) * (W2^T g)) in one kernel (see dts_mlp_bwd_kernel); -100 when no fused instance exists
+int mlp_bwd(mpv_ctx* ctx, int D, int M, const float* G, const float* U, const float* W2T, const float* W0T, float* Y, long long rows) {
+    MlpBwdArgs a{G, U, W2T, W0T, Y, rows};
+    const size_t lds = sizeof(float) * ((size_t)M * (D + 4) + (size_t)D * (M + 4));
+    const long long tiles = ((rows + 15) / 16 + MLP_WAVES - 1) / MLP_WAVES;
+    const long long per_cu = std::max<long long>(1, std::min<long long>(2, (long long)ctx->max_lds / (long long)lds));
+    const int grid = (int)std::min<long long>(tiles, per_cu * ctx->cu_count);
+#define DTS_MLPB(DT_, MT_)                                                                                           \
+    do {                                                                                                            \
+        if (int rc = set_lds(ctx, dts_mlp_bwd_kernel<DT_, MT_>, lds)) return rc;                                    \
+        hipLaunchKernelGGL((dts_mlp_bwd_kernel<DT_, MT_>), dim3(grid), dim3(64 * MLP_WAVES), lds, ctx->stream, a);  \
+    } while (0)
+    if (D == 64 && M == 256) DTS_MLPB(4, 16);
+    else if (D == 32 && M == 128) DTS_MLPB(2, 8);
+    else if (D == 16 && M == 64) DTS_MLPB(1, 4);
+    else return -100;
+#undef DTS_MLPB
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
 // x_out = x + mlp(ln2(x)); u (pre-GELU hidden) is kept only when the backward pass will read it
 int mlp_block(mpv_ctx* ctx, DtsEngine& e, const float* x, const float* lnw, const float* lnb, const float* w0, const float* b0, const float* w2,
               const float* b2, float* u, float* out, long long T, bool save);
@@ -341,7 +362,11 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
         MPV_HIP_TRY(ctx, hipGetLastError());
         std::swap(gcur, gnext);                                          // gcur = d_x3
         // x3 = x2 + mlp(ln2(x2))
-        if (D % G_BK == 0 && M % G_BK == 0) {                                  // d_hidden = (g W2) * gelu'(u), then d_ln = d_hidden W0
+        const int fused = mlp_bwd(ctx, D, M, gcur, s.u, w.w2_t, w.w0_t, e.gC, T);       // d_ln = W0^T (gelu'(u) * (W2^T g)), hidden gradient on chip
+        if (fused == MPV_OK) {
+        } else if (fused != -100) {
+            return fused;
+        } else if (D % G_BK == 0 && M % G_BK == 0) {                           // d_hidden = (g W2) * gelu'(u), then d_ln = d_hidden W0
             DTS_TRY(wide_gemm(ctx, gcur, D, w.w2_t, D, M, T, e.gwide, M, s.u, M));
             DTS_TRY(wide_gemm(ctx, e.gwide, M, w.w0_t, M, D, T, e.gC, D));
         } else {
@@ -376,7 +401,11 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
         const EncW& w = e.enc[i];
         const DtsEngine::EncS& s = e.es[i];
         const float* sc = ada_t + (size_t)i * 2 * D;
-        if (D % G_BK == 0 && M % G_BK == 0) {
+        const int fused = mlp_bwd(ctx, D, M, genc, s.u, w.w2_t, w.w0_t, e.gC, T);
+        if (fused == MPV_OK) {
+        } else if (fused != -100) {
+            return fused;
+        } else if (D % G_BK == 0 && M % G_BK == 0) {
             DTS_TRY(wide_gemm(ctx, genc, D, w.w2_t, D, M, T, e.gwide, M, s.u, M));
             DTS_TRY(wide_gemm(ctx, e.gwide, M, w.w0_t, M, D, T, e.gC, D));
         } else {

@@ -603,4 +603,73 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_fwd_kernel(const MlpAr
     }
 }
 
+// The backward of the same MLP w.r.t. its LayerNorm output, fused the same way:  d_ln = W0^T (gelu'(u) * (W2^T g)).  A wave's 16 tokens: the
+// gradient rows are loaded in B-operand layout, W2^T g lands in accumulator layout [hidden unit = 16 nt + 4 (lane>>4) + reg][token], is
+// multiplied by gelu'(u) (u read in that same layout) and is the B operand of the second product as it stands.  The 256-wide hidden gradient never
+// reaches HBM (the two-GEMM path writes and re-reads 656 MB per call).  W2T = W2 transposed [M][D], W0T = W0 transposed [D][M].
+struct MlpBwdArgs {
+    const float *G, *U, *W2T, *W0T;
+    float* Y;                       // [rows][D]
+    long long rows;
+};
+
+template <int DT, int MT>
+__global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_bwd_kernel(const MlpBwdArgs p) {
+    constexpr int D = 16 * DT, M = 16 * MT, KS = D + 4, MS = M + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* W2l = lds;                     // [M][KS]   W2^T
+    float* W0l = W2l + M * KS;            // [D][MS]   W0^T
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    for (int i = tid; i < M * (D / 4); i += 64 * MLP_WAVES) {
+        const int n = i / (D / 4), c = i - n * (D / 4);
+        *reinterpret_cast<f32x4*>(W2l + n * KS + 4 * c) = *reinterpret_cast<const f32x4*>(p.W2T + (size_t)n * D + 4 * c);
+    }
+    for (int i = tid; i < D * (M / 4); i += 64 * MLP_WAVES) {
+        const int n = i / (M / 4), c = i - n * (M / 4);
+        *reinterpret_cast<f32x4*>(W0l + n * MS + 4 * c) = *reinterpret_cast<const f32x4*>(p.W0T + (size_t)n * M + 4 * c);
+    }
+    __syncthreads();
+    const long long n_tiles = (p.rows + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * MLP_WAVES) {
+        asm volatile("" ::: "memory");        // keep the weight fragments in LDS, not in 320 hoisted registers
+        const long long tok = tile * 16 + r16;
+        const bool live = tok < p.rows;
+        const float* gr = p.G + (live ? tok : 0) * (long long)D + 4 * g;
+        f32x4 gb[DT];
+#pragma unroll
+        for (int s = 0; s < DT; ++s) gb[s] = live ? *reinterpret_cast<const f32x4*>(gr + 16 * s) : f32x4{0, 0, 0, 0};
+        f32x4 e[MT];
+#pragma unroll
+        for (int nt = 0; nt < MT; ++nt) {
+            f32x4 acc = {0, 0, 0, 0};
+            const float* wa = W2l + (16 * nt + r16) * KS + 4 * g;
+#pragma unroll
+            for (int s = 0; s < DT; ++s) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(wa + 16 * s);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) DTS_MMA(acc, a[q], gb[s][q]);
+            }
+            const f32x4 u = live ? *reinterpret_cast<const f32x4*>(p.U + tok * (long long)M + 16 * nt + 4 * g) : f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] *= gelu_grad_f(u[q]);
+            e[nt] = acc;
+        }
+#pragma unroll
+        for (int mt = 0; mt < DT; ++mt) {
+            f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            const float* wa = W0l + (16 * mt + r16) * MS + 4 * g;
+#pragma unroll
+            for (int nt = 0; nt < MT; nt += 2) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(wa + 16 * nt), a1 = *reinterpret_cast<const f32x4*>(wa + 16 * nt + 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    DTS_MMA(acc0, a0[r], e[nt][r]);
+                    DTS_MMA(acc1, a1[r], e[nt + 1][r]);
+                }
+            }
+            if (live) *reinterpret_cast<f32x4*>(p.Y + tok * (long long)D + 16 * mt + 4 * g) = acc0 + acc1;
+        }
+    }
+}
+
 }  // namespace dts
