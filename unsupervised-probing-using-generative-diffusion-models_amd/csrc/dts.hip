@@ -68,6 +68,32 @@ int set_lds(mpv_ctx* ctx, K kernel, size_t bytes) {
 int lin(mpv_ctx* ctx, const float* X, int ldx, const float* W, const float* bias, int K, int N, long long rows, float* Y, int ldy, int pro = PRO_NONE,
         const float* P1 = nullptr, const float* P2 = nullptr, int ldp = 0, const float* R = nullptr, int ldr = 0, int accumulate = 0) {
     LinArgs a{X, ldx, W, bias, R, ldr, Y, ldy, P1, P2, ldp, rows, K, N, pro, accumulate};
+    static const bool tile_kernel = getenv("MPV_DTS_LIN_TILE") != nullptr;              // validation aid: the workgroup-tile kernel for every call
+    if (!tile_kernel && K % 16 == 0 && N % 16 == 0) {
+        const size_t wl = sizeof(float) * (size_t)N * (K + 4);
+        const long long wtiles = ((rows + 15) / 16 + LINW_WAVES - 1) / LINW_WAVES;
+        const long long wper = std::max<long long>(1, std::min<long long>(3, (long long)ctx->max_lds / (long long)std::max<size_t>(wl, 1)));
+        const dim3 wgrid((unsigned)std::min<long long>(wtiles, wper * ctx->cu_count)), wblock(64 * LINW_WAVES);
+#define DTS_LINW(KT_)                                                                         \
+    do {                                                                                      \
+        if (int rc = set_lds(ctx, dts_lin_wave_kernel<KT_>, wl)) return rc;                   \
+        hipLaunchKernelGGL(dts_lin_wave_kernel<KT_>, wgrid, wblock, wl, ctx->stream, a);      \
+        MPV_HIP_TRY(ctx, hipGetLastError());                                                  \
+        return MPV_OK;                                                                        \
+    } while (0)
+        switch (K / 16) {
+            case 1: DTS_LINW(1);
+            case 2: DTS_LINW(2);
+            case 3: DTS_LINW(3);
+            case 4: DTS_LINW(4);
+            case 6: DTS_LINW(6);
+            case 8: DTS_LINW(8);
+            case 12: DTS_LINW(12);
+            case 16: DTS_LINW(16);
+            default: break;                       // other widths: the workgroup-tile kernel below
+        }
+#undef DTS_LINW
+    }
     const size_t lds = sizeof(float) * (size_t)(N + LIN_TM) * (K + 4);
     if (int rc = set_lds(ctx, dts_lin_kernel, lds)) return rc;
     const long long tiles = (rows + LIN_TM - 1) / LIN_TM;

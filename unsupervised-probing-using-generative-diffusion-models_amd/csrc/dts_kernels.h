@@ -152,6 +152,101 @@ __global__ __launch_bounds__(LIN_THREADS) void dts_lin_kernel(const LinArgs p) {
     }
 }
 
+// The same Linear with one 16-token tile per WAVE and nothing but W in LDS: a tile's rows are loaded from global memory straight into the
+// B-operand layout (lane = token r16, k-slot g: X[tok][16 s + 4 g ..]), the prologue (LayerNorm statistics over a token's four lanes with two
+// shuffles, AdaLN, GELU, GELU') runs in registers, and no barrier separates the waves.  8 waves per workgroup, as many workgroups per CU as W's
+// footprint allows (W 192 x 64: three).  KT = K / 16.
+constexpr int LINW_WAVES = 8;
+
+template <int KT>
+__global__ __launch_bounds__(64 * LINW_WAVES) void dts_lin_wave_kernel(const LinArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int K = 16 * KT, KS = K + 4;
+    float* Wl = lds;                                // [N][KS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    for (int i = tid; i < p.N * (K / 4); i += 64 * LINW_WAVES) {
+        const int n = i / (K / 4), c = i - n * (K / 4);
+        *reinterpret_cast<f32x4*>(Wl + n * KS + 4 * c) = *reinterpret_cast<const f32x4*>(p.W + (size_t)n * K + 4 * c);
+    }
+    __syncthreads();
+    const long long n_tiles = (p.rows + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * LINW_WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * LINW_WAVES) {
+        asm volatile("" ::: "memory");              // weight fragments stay in LDS (hoisted out of the loop they would spill)
+        const long long tok = tile * 16 + r16;
+        const bool live = tok < p.rows;
+        const float* xr = p.X + (live ? tok : 0) * (long long)p.ldx + 4 * g;
+        f32x4 xb[KT];
+#pragma unroll
+        for (int s = 0; s < KT; ++s) xb[s] = live ? *reinterpret_cast<const f32x4*>(xr + 16 * s) : f32x4{0, 0, 0, 0};
+        if (p.pro == PRO_LN || p.pro == PRO_ADALN) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KT; ++s) sum += (xb[s][0] + xb[s][1]) + (xb[s][2] + xb[s][3]);
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum / (float)K;
+            float q = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KT; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xb[s][e] -= mean;
+                    q += xb[s][e] * xb[s][e];
+                }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            const float rstd = 1.0f / sqrtf(q / (float)K + 1e-5f);
+#pragma unroll
+            for (int s = 0; s < KT; ++s) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(p.P1 + 16 * s + 4 * g), b = *reinterpret_cast<const f32x4*>(p.P2 + 16 * s + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = xb[s][e] * rstd;
+                    xb[s][e] = (p.pro == PRO_ADALN) ? xh * (1.0f + a[e]) + b[e] : xh * a[e] + b[e];
+                }
+            }
+        } else if (p.pro == PRO_GELUGRAD) {
+            const float* ur = p.P1 + (live ? tok : 0) * (long long)p.ldp + 4 * g;
+#pragma unroll
+            for (int s = 0; s < KT; ++s) {
+                const f32x4 u = live ? *reinterpret_cast<const f32x4*>(ur + 16 * s) : f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xb[s][e] *= gelu_grad_f(u[e]);
+            }
+        } else if (p.pro == PRO_GELU) {
+#pragma unroll
+            for (int s = 0; s < KT; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xb[s][e] = gelu_f(xb[s][e]);
+        }
+        for (int nt = 0; nt < (p.N >> 4); ++nt) {
+            const int n0 = 16 * nt + 4 * g;
+            f32x4 addend = {0, 0, 0, 0};            // what the epilogue adds is requested before the MFMAs of this block
+            if (live) {
+                if (p.R) addend = *reinterpret_cast<const f32x4*>(p.R + tok * (long long)p.ldr + n0);
+                if (p.accumulate) addend += *reinterpret_cast<const f32x4*>(p.Y + tok * (long long)p.ldy + n0);
+            }
+            f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            const float* wa = Wl + (16 * nt + r16) * KS + 4 * g;
+#pragma unroll
+            for (int s = 0; s < KT; ++s) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(wa + 16 * s);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (s & 1) DTS_MMA(acc1, a[e], xb[s][e]);
+                    else DTS_MMA(acc0, a[e], xb[s][e]);
+                }
+            }
+            if (live) {
+                f32x4 v = acc0 + acc1;
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n0);
+                v += addend;
+                *reinterpret_cast<f32x4*>(p.Y + tok * (long long)p.ldy + n0) = v;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // LayerNorm / AdaLayerNorm backward w.r.t. the input:  dx (+)= rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))
 // 16 lanes per token, NPL = D/16 channels per lane
