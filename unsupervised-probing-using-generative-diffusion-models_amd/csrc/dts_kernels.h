@@ -387,11 +387,14 @@ __device__ __forceinline__ void load_frag(const float* p, float (&f)[E]) {
 template <int E>
 __device__ __forceinline__ void stage_head(const float* src, int ld, int n, int np, float* row_major, float* transposed) {
     constexpr int HD = 4 * E;
-    for (int i = threadIdx.x; i < np * HD; i += 256) {
-        const int r = i / HD, d = i - r * HD;
-        const float v = r < n ? src[(long long)r * ld + d] : 0.0f;
-        if (row_major) row_major[r * (HD + 4) + d] = v;
-        if (transposed) transposed[d * (np + 4) + r] = v;
+    for (int i = threadIdx.x; i < np * E; i += 256) {                    // one float4 (four head columns of a token) per thread and pass
+        const int r = i / E, d = 4 * (i - r * E);
+        const f32x4 v = r < n ? *reinterpret_cast<const f32x4*>(src + (long long)r * ld + d) : f32x4{0, 0, 0, 0};
+        if (row_major) *reinterpret_cast<f32x4*>(row_major + r * (HD + 4) + d) = v;
+        if (transposed) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) transposed[(d + e) * (np + 4) + r] = v[e];
+        }
     }
     if (transposed && HD < 16)
         for (int i = threadIdx.x; i < (16 - HD) * (np + 4); i += 256) transposed[HD * (np + 4) + i] = 0.0f;
