@@ -736,36 +736,42 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_bwd_kernel(const MlpBw
         f32x4 gb[DT];
 #pragma unroll
         for (int s = 0; s < DT; ++s) gb[s] = live ? *reinterpret_cast<const f32x4*>(gr + 16 * s) : f32x4{0, 0, 0, 0};
-        f32x4 e[MT];
+        // the hidden units in blocks of HB tiles: a block's gradient (HB x 4 registers) is formed, multiplied by gelu'(u) and consumed by the
+        // second product before the next block is started -- 64 + 16 live accumulator registers would spill at M = 256
+        constexpr int HB = MT < 8 ? MT : 8;
+        f32x4 out[DT];
 #pragma unroll
-        for (int nt = 0; nt < MT; ++nt) {
-            f32x4 acc = {0, 0, 0, 0};
-            const float* wa = W2l + (16 * nt + r16) * KS + 4 * g;
+        for (int mt = 0; mt < DT; ++mt) out[mt] = f32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int s = 0; s < DT; ++s) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(wa + 16 * s);
+        for (int hb = 0; hb < MT; hb += HB) {
+            f32x4 e[HB];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) DTS_MMA(acc, a[q], gb[s][q]);
-            }
-            const f32x4 u = live ? *reinterpret_cast<const f32x4*>(p.U + tok * (long long)M + 16 * nt + 4 * g) : f32x4{0, 0, 0, 0};
+            for (int j = 0; j < HB; ++j) {
+                const int nt = hb + j;
+                f32x4 acc = {0, 0, 0, 0};
+                const float* wa = W2l + (16 * nt + r16) * KS + 4 * g;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] *= gelu_grad_f(u[q]);
-            e[nt] = acc;
-        }
+                for (int s = 0; s < DT; ++s) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(wa + 16 * s);
 #pragma unroll
-        for (int mt = 0; mt < DT; ++mt) {
-            f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-            const float* wa = W0l + (16 * mt + r16) * MS + 4 * g;
-#pragma unroll
-            for (int nt = 0; nt < MT; nt += 2) {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(wa + 16 * nt), a1 = *reinterpret_cast<const f32x4*>(wa + 16 * nt + 16);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    DTS_MMA(acc0, a0[r], e[nt][r]);
-                    DTS_MMA(acc1, a1[r], e[nt + 1][r]);
+                    for (int q = 0; q < 4; ++q) DTS_MMA(acc, a[q], gb[s][q]);
                 }
+                const f32x4 u = live ? *reinterpret_cast<const f32x4*>(p.U + tok * (long long)M + 16 * nt + 4 * g) : f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] *= gelu_grad_f(u[q]);
+                e[j] = acc;
             }
-            if (live) *reinterpret_cast<f32x4*>(p.Y + tok * (long long)D + 16 * mt + 4 * g) = acc0 + acc1;
+#pragma unroll
+            for (int j = 0; j < HB; ++j)                              // DT independent accumulator chains side by side
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mt = 0; mt < DT; ++mt)
+                        DTS_MMA(out[mt], W0l[(16 * mt + r16) * MS + 16 * (hb + j) + 4 * g + r], e[j][r]);
+        }
+        if (live) {
+#pragma unroll
+            for (int mt = 0; mt < DT; ++mt) *reinterpret_cast<f32x4*>(p.Y + tok * (long long)D + 16 * mt + 4 * g) = out[mt];
         }
     }
 }
