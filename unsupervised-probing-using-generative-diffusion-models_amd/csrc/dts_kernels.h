@@ -662,38 +662,43 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_fwd_kernel(const MlpAr
         for (int s = 0; s < DT; ++s)
 #pragma unroll
             for (int e = 0; e < 4; ++e) xb[s][e] = xb[s][e] * rstd * lw[s][e] + lb[s][e];
-        f32x4 u[MT];
+        // hidden units in blocks of HB tiles, each consumed by the second product before the next is formed (see dts_mlp_bwd_kernel)
+        constexpr int HB = MT < 8 ? MT : 8;
+        f32x4 out[DT];
 #pragma unroll
-        for (int nt = 0; nt < MT; ++nt) {
-            f32x4 acc = *reinterpret_cast<const f32x4*>(p.b0 + 16 * nt + 4 * g);
-            const float* wa = W0l + (16 * nt + r16) * KS + 4 * g;
+        for (int mt = 0; mt < DT; ++mt) out[mt] = f32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int s = 0; s < DT; ++s) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(wa + 16 * s);
+        for (int hb = 0; hb < MT; hb += HB) {
+            f32x4 u[HB];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) DTS_MMA(acc, a[e], xb[s][e]);
-            }
-            if (p.U && live) *reinterpret_cast<f32x4*>(p.U + tok * (long long)M + 16 * nt + 4 * g) = acc;
+            for (int j = 0; j < HB; ++j) {
+                const int nt = hb + j;
+                f32x4 acc = *reinterpret_cast<const f32x4*>(p.b0 + 16 * nt + 4 * g);
+                const float* wa = W0l + (16 * nt + r16) * KS + 4 * g;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = gelu_f(acc[e]);
-            u[nt] = acc;
-        }
+                for (int s = 0; s < DT; ++s) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(wa + 16 * s);
 #pragma unroll
-        for (int mt = 0; mt < DT; ++mt) {
-            f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-            const float* wa = W2l + (16 * mt + r16) * MS + 4 * g;
-#pragma unroll
-            for (int nt = 0; nt < MT; nt += 2) {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(wa + 16 * nt), a1 = *reinterpret_cast<const f32x4*>(wa + 16 * nt + 16);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    DTS_MMA(acc0, a0[r], u[nt][r]);
-                    DTS_MMA(acc1, a1[r], u[nt + 1][r]);
+                    for (int e = 0; e < 4; ++e) DTS_MMA(acc, a[e], xb[s][e]);
                 }
+                if (p.U && live) *reinterpret_cast<f32x4*>(p.U + tok * (long long)M + 16 * nt + 4 * g) = acc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = gelu_f(acc[e]);
+                u[j] = acc;
             }
-            if (live) {
+#pragma unroll
+            for (int j = 0; j < HB; ++j)                              // DT independent accumulator chains side by side
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mt = 0; mt < DT; ++mt)
+                        DTS_MMA(out[mt], W2l[(16 * mt + r16) * MS + 16 * (hb + j) + 4 * g + r], u[j][r]);
+        }
+        if (live) {
+#pragma unroll
+            for (int mt = 0; mt < DT; ++mt) {
                 const int n0 = 16 * mt + 4 * g;
-                f32x4 v = (acc0 + acc1) + *reinterpret_cast<const f32x4*>(p.b2 + n0);
+                f32x4 v = out[mt] + *reinterpret_cast<const f32x4*>(p.b2 + n0);
                 v += *reinterpret_cast<const f32x4*>(p.X + tok * (long long)D + n0);
                 *reinterpret_cast<f32x4*>(p.Y + tok * (long long)D + n0) = v;
             }
