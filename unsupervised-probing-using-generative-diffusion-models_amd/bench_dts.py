@@ -35,16 +35,13 @@ def main_c3(args, log):
     from mpv_amd import synthetic
     from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
     from mpv_amd.models.models import diffusion_models
-    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
-        raise SystemExit("--config c3 is a single-GPU record")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm device: the path has no CPU implementation")
-    device = torch.device("cuda", 0)
-    torch.cuda.set_device(device)
+    from mpv_amd.bench_common import Ranks
+    rk = Ranks(args)                                   # N ranks: every rank samples windows of its own trajectory (weak scaling)
+    device = rk.device
     cfg = C3
     from mpv_amd import _native
     gen = _native.Context(device)
-    sampled, _ = synthetic.sis_trajectory_device(gen, cfg["nodes"], cfg["ticks"], seed=2000, sampling_stride=H.sampling_interval_from_t(cfg["sampling_t"]))
+    sampled, _ = synthetic.sis_trajectory_device(gen, cfg["nodes"], cfg["ticks"], seed=2000 + rk.rank, sampling_stride=H.sampling_interval_from_t(cfg["sampling_t"]))
     sampled = sampled.cpu()
     gen.close()
     log("c3: SIS trajectory generated on device: %s" % (tuple(sampled.shape),))
@@ -68,17 +65,17 @@ def main_c3(args, log):
         hist = series[:, idx, :].permute(1, 0, 2, 3).contiguous()                                 # [W, V, windows, F]
         samples = model.sample_windows(hist, seed=seed)
         mpv, pm, _ = ctx.reduce(samples, std_dev, mean_dev)
-        return torch.stack([mpv, pm]).cpu()
+        return rk.gather(torch.stack([mpv, pm]))
 
     for i in range(args.warmup):
         step(i, i)
         log("c3 warmup step %d done" % i)
-    torch.cuda.synchronize(device)
+    rk.fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        curve = step(i, 100 + i)
-    torch.cuda.synchronize(device)
-    elapsed = time.perf_counter() - t0
+        curve = step(i, 100 + i + 1000 * rk.rank)
+    rk.fence()
+    elapsed = rk.max_time(time.perf_counter() - t0)
     assert bool(torch.isfinite(curve).all())
     L, D, Hh, M = cfg["windows"] + cfg["pred_len"], cfg["d_model"], cfg["n_heads"], 4 * cfg["d_model"]
     ff, fb = flops_per_sequence(L, D, Hh, M, cfg["n_layer_enc"], cfg["n_layer_dec"], L // 2 - 1)
@@ -87,9 +84,9 @@ def main_c3(args, log):
     n_bwd = int(plan[:, 6].sum())
     seqs = cfg["nodes"] * cfg["n_z"]
     flop_per_window = seqs * (n_fwd * ff + n_bwd * fb)
-    achieved = flop_per_window * wps * args.steps / elapsed / 1e12
+    achieved = flop_per_window * wps * args.steps / elapsed / 1e12                       # per GPU
     out = {
-        "metric": "rolling windows/sec (N=32, T=100), DiffusionTS", "value": wps * args.steps / elapsed, "unit": "windows/s", "n_gpus": 1,
+        "metric": "rolling windows/sec (N=32, T=100), DiffusionTS", "value": rk.world * wps * args.steps / elapsed, "unit": "windows/s", "n_gpus": rk.world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 (every contraction on v_mfma_f32_16x16x4_f32)", "data": "synthetic",
         "config": {"workload": "DiffusionTS on 100-node BA-graph SIS trajectory (BASELINE configs[2]): windows=100, pred_len=100, d_model=64, "
@@ -103,9 +100,11 @@ def main_c3(args, log):
                      "peak_source": "fp32 matrix pipe (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md",
                      "note": "achieved = algorithmic FLOPs of the dense contractions / wall time of the timed steps (all kernels of the call)"},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and rk.world == 1:
         out["cpu_baseline"] = cpu_baseline(model, series, cfg, log)
-    print(json.dumps(out), flush=True)
+    if rk.rank == 0:
+        print(json.dumps(out), flush=True)
+    rk.close()
 
 
 def cpu_baseline(model, series, cfg, log):

@@ -58,12 +58,9 @@ def main_c5(args, log):
     from mpv_amd import synthetic
     from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
     from mpv_amd.models.models import diffusion_models
-    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
-        raise SystemExit("--config c5 is a single-GPU record (windows shard over ranks exactly as for c2)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm device: the path has no CPU implementation")
-    device = torch.device("cuda", 0)
-    torch.cuda.set_device(device)
+    from mpv_amd.bench_common import Ranks
+    rk = Ranks(args)                                   # N ranks: every rank samples windows of its own trajectory (weak scaling), graph replicated
+    device = rk.device
     cfg = C5
     from mpv_amd import _native
     adj = small_world(cfg["nodes"], seed=3000)
@@ -72,7 +69,7 @@ def main_c5(args, log):
     gen = _native.Context(device)
     x0 = np.random.default_rng(3000).uniform(0.0, 1.0, cfg["nodes"]).astype(np.float32)
     series = gen.biomass_simulate(torch.from_numpy(row_ptr).to(device), torch.from_numpy(col_idx).to(device), torch.from_numpy(x0).to(device).unsqueeze(0),
-                                  cfg["ticks"], 1000, stride, 0.7, 10.0, 0.5, 0.005, 0.1, 0.0, 2.7, 3000)[0]            # [V, L, 1]
+                                  cfg["ticks"], 1000, stride, 0.7, 10.0, 0.5, 0.005, 0.1, 0.0, 2.7, 3000 + rk.rank)[0]            # [V, L, 1]
     gen.close()
     log("c5: device biomass trajectory on a 200-node small-world graph: %s" % (tuple(series.shape),))
     n_total = H.sliding_window_count(series.shape[1], cfg["windows"], cfg["window_step"])
@@ -99,24 +96,24 @@ def main_c5(args, log):
         hist = scaled[:, idx, :].permute(1, 0, 2, 3).contiguous()                                  # [W, V, T_h, 1]
         samples = model.sample_windows(hist, edge_index, seed=seed)[:, :, -cfg["pred_len"]:].contiguous()
         mpv, pm, _ = ctx.reduce(samples, std_dev, mean_dev)
-        return torch.stack([mpv, pm]).cpu()
+        return rk.gather(torch.stack([mpv, pm]))
 
     for i in range(args.warmup):
         step(i, i)
         log("c5 warmup step %d done" % i)
-    torch.cuda.synchronize(device)
+    rk.fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        curve = step(i, 100 + i)
-    torch.cuda.synchronize(device)
-    elapsed = time.perf_counter() - t0
+        curve = step(i, 100 + i + 1000 * rk.rank)
+    rk.fence()
+    elapsed = rk.max_time(time.perf_counter() - t0)
     assert bool(torch.isfinite(curve).all())
     rows = cfg["nodes"] * cfg["parallel"] * cfg["sequential"]
     fpr = flops_per_row(model)
     flop_per_window = rows * cfg["steps"] * fpr
     achieved = flop_per_window * wps * args.steps / elapsed / 1e12
     out = {
-        "metric": "rolling windows/sec (N=32, 50 inference steps), DiffSTG", "value": wps * args.steps / elapsed, "unit": "windows/s", "n_gpus": 1,
+        "metric": "rolling windows/sec (N=32, 50 inference steps), DiffSTG", "value": rk.world * wps * args.steps / elapsed, "unit": "windows/s", "n_gpus": rk.world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 (k = T+1 convolutions and graph-conv Linear maps as two-term f16 splits on v_mfma_f32_32x32x16_f16 with fp32 accumulate, rest fp32 VALU)", "data": "synthetic",
         "config": {"workload": "DiffSTG on 200-node small-world biomass trajectory (BASELINE configs[4]): T_h=T_p=100, d_h=4, multipliers [2,2], "
@@ -129,7 +126,7 @@ def main_c5(args, log):
                      "note": "achieved = algorithmic FLOPs / wall time of the timed steps; the network is small (2.7e7 FLOP per node row per step), "
                              "so activation traffic through HBM between its ~60 kernels per step matters as much as the matrix pipe"},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and rk.world == 1:
         from oracle import diffstg_oracle as O
         import bench as B
         cores = B.cpu_share()
@@ -145,4 +142,6 @@ def main_c5(args, log):
         out["cpu_baseline"] = {"value": share / dt, "unit": "windows/s", "cores": cores, "kind": "port", "finite": bool(torch.isfinite(outs).all()),
                                "sample": "4 of the 32 graph copies (800 node rows) x all 50 inference steps = 1/8 of a window, oracle/diffstg_oracle.py "
                                          "(torch CPU fp32 port), {:.1f} s; value = (1/8 window) / time".format(dt)}
-    print(json.dumps(out), flush=True)
+    if rk.rank == 0:
+        print(json.dumps(out), flush=True)
+    rk.close()
