@@ -40,15 +40,8 @@ _T0 = time.perf_counter()
 
 
 def cpu_share() -> int:
-    """Usable host cores: the cgroup CPU quota when there is one, else the affinity mask."""
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            cores = min(cores, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return max(1, min(cores, int(os.environ.get("MPV_CPU_THREADS", cores))))
+    from mpv_amd.bench_common import cpu_share as share
+    return share()
 
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 flop/clk x 2.4 GHz
@@ -71,30 +64,62 @@ def build_model(device, series):
 
 def launch_workers(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh worker processes (one per GPU) BEFORE anything in this
-    process touches the GPU, relay rank 0's JSON line, fail if any worker fails.  Nothing is exec'd."""
+    process touches the GPU, relay rank 0's JSON line, fail if any worker fails.  Nothing is exec'd.  All children are polled: the
+    first non-zero exit (or the overall deadline, MPV_BENCH_LAUNCH_TIMEOUT seconds) terminates the rest, so a rank that dies before
+    the rendezvous shows up as a failure instead of a hang; every rank's stderr is relayed."""
     import socket
     import subprocess
-    with socket.socket() as sk:
+    import tempfile
+    deadline = time.monotonic() + float(os.environ.get("MPV_BENCH_LAUNCH_TIMEOUT", "3000"))
+    with socket.socket() as sk:                 # a free port now; the workers' rendezvous carries its own timeout should it be taken meanwhile
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    procs, outs = [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), MPV_BENCH_WORKER="1")
+        outs.append(tempfile.TemporaryFile(mode="w+") if r == 0 else None)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    for line in (out or "").splitlines():               # rank 0 prints exactly one JSON record; drop library banners (gloo)
+                                      stdout=outs[r] if r == 0 else subprocess.DEVNULL))          # stderr: inherited, every rank
+    codes = [None] * len(procs)
+    failed = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0) and failed is None:
+                    failed = "rank %d exited with code %d" % (r, codes[r])
+        if failed is None and time.monotonic() > deadline:
+            failed = "workers still running at the launch deadline"
+        if failed is not None:
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+            break
+        time.sleep(0.2)
+    outs[0].seek(0)
+    for line in outs[0].read().splitlines():            # rank 0 prints exactly one JSON record; drop library banners (gloo)
         if line.startswith("{"):
             print(line, flush=True)
         elif line.strip():
             print(line, file=sys.stderr)
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        print("bench workers failed: " + ", ".join("rank %d rc %d" % rc for rc in bad), file=sys.stderr)
+    outs[0].close()
+    if failed is not None:
+        print("bench workers failed: %s (exit codes %s)" % (failed, codes), file=sys.stderr)
         return 1
     return 0
+
+
+def init_group(backend, rank, world, device):
+    from mpv_amd.bench_common import init_group as init
+    init(backend, rank, world, device)
 
 
 def main():
@@ -114,7 +139,10 @@ def main():
     ap.add_argument("--host-data", action="store_true",
                     help="generate the synthetic trajectory with the numpy Euler-Maruyama on the host instead of the HIP kernel")
     ap.add_argument("--no-other-modes", action="store_true",
-                    help="skip the extra, separately reported runs (other GEMM modes, sample-writing path, trained checkpoints; N=1 only)")
+                    help="skip the extra, separately reported runs (other GEMM modes, sample-writing path, trained checkpoints, "
+                         "the other BASELINE configs; N=1 only)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` records (BASELINE configs[2..4] = c3, c4, c5 at full size, each with its roofline and CPU baseline)")
     ap.add_argument("--store-samples", action="store_true",
                     help="headline step writes the [W,V,O,F,S] sample tensor and reduces it in a second kernel (the round-1 path)")
     ap.add_argument("--max-windows", type=int, default=None, help="profiling aid: cut the trajectory to this many windows "
@@ -153,10 +181,7 @@ def main():
             del os.environ["NCCL_DEBUG"]                             # exactly one line there, the JSON record
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        init_group(args.backend, rank, world, device)
 
     from mpv_amd import synthetic
     from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
@@ -257,6 +282,8 @@ def main():
                    "parallelism": "windows sharded over %d rank(s), one all-gather of the curve" % world},
         "roofline": roofline(args.gemm, achieved, kernel_ms, launches, flop_per_launch, n_windows, args.store_samples),
     }
+    if use_dist:
+        out["collective"] = {"backend": dist.get_backend(), "forced_world_of_one": world == 1}
 
     # ---- separately reported runs: the other GEMM modes, the sample-writing path; never the headline
     extras = world == 1 and not args.no_other_modes
@@ -290,6 +317,8 @@ def main():
         if "value" in out["full_nsdiff"]:
             log("full NsDiff (f + g + sampler): %.1f windows/s" % out["full_nsdiff"]["value"])
 
+    if extras and not args.no_other_configs and args.max_windows is None:
+        out["other_configs"] = other_config_records(args, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         parity = cpu_baseline_and_parity(model, sampled, args.cpu_windows, [args.gemm] + others)
         for g, err in parity.pop("per_mode").items():
@@ -302,6 +331,31 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def other_config_records(args, device):
+    """Secondary records: the other BASELINE configs that fit one GPU, each at FULL size through its own bench module (the same code
+    `--config c3|c4|c5` runs), with its roofline, PMC traffic (profiles/*/pmc_traffic_<cfg>.json) and bounded CPU baseline.  Cheapest
+    first; a failure is recorded and never takes the headline line down."""
+    import types
+    from mpv_amd.bench_common import Ranks
+    recs = {}
+    plan = (("c5", "mpv_amd.bench_stg", "record_c5", dict(steps=3, warmup=1)),
+            ("c4", "mpv_amd.bench_c4", "record_c4", dict(steps=1, warmup=1)),
+            ("c3", "mpv_amd.bench_dts", "record_c3", dict(steps=1, warmup=1)))
+    for key, mod, fn, kw in plan:
+        sub = types.SimpleNamespace(gpus=1, backend=args.backend, gemm="f16x3", no_cpu_baseline=args.no_cpu_baseline, dts_windows=1,
+                                    stg_windows=4, **kw)
+        t0 = time.perf_counter()
+        try:
+            import importlib
+            recs[key] = getattr(importlib.import_module(mod), fn)(sub, log, Ranks.single(device, args.backend))
+            log("other config %s: %.4g %s (%.1f s in all)" % (key, recs[key]["value"], recs[key]["unit"], time.perf_counter() - t0))
+        except Exception as exc:                   # noqa: BLE001
+            recs[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            log("other config %s failed: %s" % (key, recs[key]["error"]))
+        torch.cuda.empty_cache()
+    return recs
 
 
 def full_nsdiff_record(device, sampled, n_windows):
@@ -343,7 +397,11 @@ def full_nsdiff_record(device, sampled, n_windows):
     flop = (4 * enc + 2 * dec) * CFG["nodes"] * n_windows
     return {"value": n_windows / dt, "unit": "windows/s", "ms_per_step": dt * 1e3, "finite": bool(torch.isfinite(curve).all()),
             "fx_ms_per_step": fx_ms, "fx_gflop_per_node": (4 * enc + 2 * dec) / 1e9, "fx_tflops_fp32_equivalent": flop / fx_ms / 1e9,
-            "fx_gemm": model.cond_pred_model.gemm_mode, "fx_frac_of_fp32_matrix_peak": flop / fx_ms / 1e9 / FP32_MATRIX_PEAK_TFLOPS,
+            "fx_gemm": model.cond_pred_model.gemm_mode,
+            "fx_frac": flop / fx_ms / 1e9 / (FP32_MATRIX_PEAK_TFLOPS if model.cond_pred_model.gemm_mode == "f32" else F16_MATRIX_PEAK_TFLOPS / 3.0),
+            "fx_peak": "fp32 matrix pipe 157.3 TFLOP/s" if model.cond_pred_model.gemm_mode == "f32" else
+                       "dense f16 MFMA peak 2500 TFLOP/s / 3 products per algorithmic product (split-f16 GEMMs)",
+            "fx_vs_fp32_matrix_peak": flop / fx_ms / 1e9 / FP32_MATRIX_PEAK_TFLOPS,
             "parity": "f(x) layers restated from the published ns-Transformer (torch-timeseries absent): parity unpinned"}
 
 

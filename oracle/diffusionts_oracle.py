@@ -186,9 +186,13 @@ def q_sample(tb, x_start, t, noise):                                            
     return tb["sqrt_alphas_cumprod"][t].view(-1, 1, 1) * x_start + tb["sqrt_one_minus_alphas_cumprod"][t].view(-1, 1, 1) * noise
 
 
-def langevin(sd, cfg, tb, sample, mean, sigma, t, target, mask, noise: NoiseFn, record):    # :359-407
+def langevin(sd, cfg, tb, sample, mean, sigma, t, target, mask, noise: NoiseFn, record, batch_of: Optional[int] = None):    # :359-407
     """K Adagrad steps (K from the time index) on the un-masked part of `sample`; each step also draws an `epsilon`
-    that is multiplied by coef_ = 0 (drawn all the same: the draw order matters for noise replay)."""
+    that is multiplied by coef_ = 0 (drawn all the same: the draw order matters for noise replay).
+
+    `batch_of` (test aid): the rows are a SUBSET of a reference batch of that many sequences -- the reference's two batch means
+    (`.mean(dim=0)` over the batch, and over all masked elements of the batch) then divide the subset's sums by the FULL batch's
+    counts, which is what these rows see inside the full batch (sequences couple through nothing else)."""
     t0 = int(t[0].item())
     lr = cfg.infill_learning_rate
     if t0 < cfg.timesteps * 0.05:
@@ -205,7 +209,10 @@ def langevin(sd, cfg, tb, sample, mean, sigma, t, target, mask, noise: NoiseFn, 
         with torch.enable_grad():
             x_start = model_output(sd, cfg, p, t)
             infill = (x_start[mask] - target[mask]) ** 2
-            if float(sigma.mean()) == 0:
+            if float(sigma.mean()) == 0 and batch_of is not None:
+                logp = cfg.infill_coef * (((mean - p) ** 2 / 1.0).sum(dim=0) / float(batch_of)).sum()
+                infill = infill.sum() / float(batch_of * int(mask[0].sum()))
+            elif float(sigma.mean()) == 0:
                 logp = cfg.infill_coef * ((mean - p) ** 2 / 1.0).mean(dim=0).sum()
                 infill = infill.mean(dim=0).sum()
             else:
@@ -223,7 +230,8 @@ def langevin(sd, cfg, tb, sample, mean, sigma, t, target, mask, noise: NoiseFn, 
     return out
 
 
-def fast_sample_infill(sd, cfg: DTSConfig, tb, target, mask, noise: NoiseFn, record: Optional[List[torch.Tensor]] = None):
+def fast_sample_infill(sd, cfg: DTSConfig, tb, target, mask, noise: NoiseFn, record: Optional[List[torch.Tensor]] = None,
+                       batch_of: Optional[int] = None):
     """DDIM sampler with infilling (DiffusionTS.py:277-310).  Draw order per pair with time_next >= 0: `noise`, then
     K Langevin `epsilon`s, then q_sample's noise."""
     def draw(shape):
@@ -247,7 +255,7 @@ def fast_sample_infill(sd, cfg: DTSConfig, tb, target, mask, noise: NoiseFn, rec
         c = (1 - alpha_next - sigma ** 2).sqrt()
         pred_mean = x_start * alpha_next.sqrt() + c * pred_noise
         img = pred_mean + sigma * draw(tuple(img.shape))
-        img = langevin(sd, cfg, tb, img, pred_mean, sigma, t, target, mask, noise, record)
+        img = langevin(sd, cfg, tb, img, pred_mean, sigma, t, target, mask, noise, record, batch_of=batch_of)
         target_t = q_sample(tb, target, t, draw(tuple(target.shape)))
         img = torch.where(mask, target_t, img)
     return torch.where(mask, target, img)

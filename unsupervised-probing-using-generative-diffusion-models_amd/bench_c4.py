@@ -17,30 +17,23 @@ C4 = dict(nodes=500, ticks=100_000, sampling_t=10, windows=100, pred_len=100, ro
 
 
 def main_c4(args, log):
+    from mpv_amd.bench_common import Ranks
+    rk = Ranks(args)
+    out = record_c4(args, log, rk)
+    if rk.rank == 0:
+        print(json.dumps(out), flush=True)
+    rk.close()
+
+
+def record_c4(args, log, rk):
+    """One bench record of BASELINE configs[3] (dict; printed by `--config c4`, embedded as other_configs.c4 by the default run)."""
     import bench as B
     from mpv_amd import _native, synthetic
     from mpv_amd import distributed as D
     from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
     from mpv_amd.models.models import diffusion_models
     cfg = C4
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm device: the path has no CPU implementation")
-    if args.backend == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29534")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+    world, rank, device = rk.world, rk.rank, rk.device
     stride = H.sampling_interval_from_t(cfg["sampling_t"])
     gen = _native.Context(device)
     series, _ = synthetic.neuronal_trajectory_device(gen, cfg["nodes"], cfg["ticks"], seed=4000, sampling_stride=stride)     # the SAME trajectory on every rank
@@ -68,10 +61,7 @@ def main_c4(args, log):
             mpv = pm = torch.zeros(0, device=device)
         return D.gather_curve(n_windows, lo, hi, mpv, pm)                     # every rank: the whole curve (host)
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
+    fence = rk.fence
 
     for i in range(args.warmup):
         step(i)
@@ -85,15 +75,14 @@ def main_c4(args, log):
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = ctx.timing()
     ctx.timing_enable(False)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = rk.max_time(elapsed)
     assert len(mpv_curve) == n_windows and bool(torch.isfinite(torch.as_tensor(mpv_curve)).all()), "bad MPV curve"
     flop_per_launch = (hi - lo) * cfg["nodes"] * cfg["pred_len"] * S * cfg["steps"] * 256 * (256 + 5 * cfg["nf"])
     achieved = flop_per_launch / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
     products = {"f16x3": 3, "f16x2": 2, "f16": 1, "f32": 0}[args.gemm]
     peak = B.FP32_MATRIX_PEAK_TFLOPS if args.gemm == "f32" else B.F16_MATRIX_PEAK_TFLOPS / products
+    from mpv_amd.bench_common import measured_traffic
+    tr = measured_traffic("c4") if world == 1 else None
     out = {
         "metric": "rolling windows/sec (N=64, T=50), NsDiff 500-node Wilson-Cowan", "value": n_windows * args.steps / elapsed, "unit": "windows/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -103,11 +92,41 @@ def main_c4(args, log):
                                "blocks over {} rank(s), one all-gather of the curve".format(n_windows, world),
                    "windows_per_step": n_windows, "windows_of_rank0": hi - lo, "noise": "on-device Philox4x32-10", "weights": "seeded default init",
                    "summary": "MPV reduction fused into the sampler epilogue, no sample tensor"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak if peak else None, "traffic": None,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak if peak else None,
+                     "traffic": (tr or {}).get("bytes_per_launch"), "traffic_detail": tr,
                      "kernel": "nsdiff_chain_f16_kernel<1,true> (rank 0's block)", "kernel_avg_ms": kernel_ms, "launches": launches,
                      "flop_per_launch": flop_per_launch},
     }
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(model, sampled, cfg, log)
+    return out
+
+
+def cpu_baseline(model, sampled, cfg, log, nodes=25):
+    """The CPU oracle on a bounded sample of the same workload: the first window, the first `nodes` of the 500 nodes (NsDiff treats nodes
+    as independent batch rows), full N = 64 x T = 50; windows/s scaled by the node share.  Also the MPV of exactly those rows from the HIP
+    path on the oracle's own noise."""
+    from oracle import nsdiff_oracle as O
+    from mpv_amd.bench_common import cpu_share
+    cores = cpu_share()
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ocfg = O.NsDiffConfig(cfg["windows"], cfg["pred_len"], cfg["nf"], cfg["rolling"], cfg["steps"], n_z_samples=cfg["n_z"], parallel_sample=cfg["parallel_sample"])
+    x = O.scale(sampled[:nodes, : cfg["windows"], :], sd["scaler_mean"], sd["scaler_std"])
+    rec = []
+    torch.manual_seed(2025)
+    log("c4 cpu baseline: %d of the %d nodes of one window on %d threads" % (nodes, cfg["nodes"], cores))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        outs = O.evaluation_step(sd, ocfg, x, record=rec)
+    dt = time.perf_counter() - t0
+    cpu_mpv = O.mpv_network(outs, sd["scaler_mean"], sd["scaler_std"])[1]
+    noise = torch.cat([z.reshape(-1) for z in rec])
+    z6 = noise.reshape(1, -1, cfg["steps"], nodes * cfg["parallel_sample"], cfg["pred_len"], cfg["nf"])
+    _, _, mpv, _ = model.sample_windows(x, 1, 0, 1, noise=z6, summary=True, want_samples=False)
+    gpu_mpv = float(mpv[0])
+    share = float(nodes) / cfg["nodes"]
+    return {"value": share / dt, "unit": "windows/s", "cores": cores, "kind": "port", "mpv_cpu": float(cpu_mpv), "mpv_gpu_same_noise": gpu_mpv,
+            "mpv_abs_err": abs(gpu_mpv - float(cpu_mpv)), "mpv_rel_err": abs(gpu_mpv - float(cpu_mpv)) / abs(float(cpu_mpv)),
+            "sample": "first window, first {} of the {} nodes, full N={} x T={}, oracle/nsdiff_oracle.py (torch CPU fp32 port of the reference eager "
+                      "path), {:.1f} s; value = ({}/{} window) / time".format(nodes, cfg["nodes"], cfg["n_z"], cfg["steps"], dt, nodes, cfg["nodes"])}

@@ -8,8 +8,56 @@ import torch
 import torch.distributed as dist
 
 
+def cpu_share() -> int:
+    """Usable host cores: the cgroup CPU quota when there is one, else the affinity mask."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(cores, int(os.environ.get("MPV_CPU_THREADS", cores))))
+
+
+def init_group(backend, rank, world, device):
+    """One process group per worker; the rendezvous and every collective give up after MPV_BENCH_DIST_TIMEOUT seconds."""
+    import datetime
+    timeout = datetime.timedelta(seconds=float(os.environ.get("MPV_BENCH_DIST_TIMEOUT", "600")))
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=timeout)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timeout)
+
+
+def measured_traffic(key, repo_root=None):
+    """Per-kernel HBM traffic of one bench step from the committed PMC passes (profiles/*/pmc_traffic_<key>.json, written by
+    tools/pmc_traffic.py: separate FETCH_SIZE and WRITE_SIZE passes, FETCH doubled as the guide prescribes for gfx950); newest round
+    first, None when there is none."""
+    import glob
+    import json
+    root = repo_root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "*", "pmc_traffic_%s.json" % key)), reverse=True):
+        try:
+            with open(f) as fh:
+                rec = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        rec["source"] = os.path.relpath(f, root)
+        return rec
+    return None
+
+
 class Ranks:
+    @classmethod
+    def single(cls, device, backend="nccl"):
+        """In-process secondary record of the default bench run: one rank, no process group."""
+        self = cls.__new__(cls)
+        self.world, self.rank, self.backend, self.device, self.own_group = 1, 0, backend, device, False
+        return self
+
     def __init__(self, args):
+        self.own_group = True
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -25,10 +73,7 @@ class Ranks:
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29535")
-            if self.backend == "nccl":
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
-            else:
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            init_group(self.backend, self.rank, self.world, self.device)
 
     def fence(self):
         if self.world > 1:
@@ -55,5 +100,5 @@ class Ranks:
         return float(t.item())
 
     def close(self):
-        if self.world > 1:
+        if self.world > 1 and self.own_group:
             dist.destroy_process_group()

@@ -32,13 +32,25 @@ def flops_per_sequence(L, D, H, M, n_enc, n_dec, NF):
 
 
 def main_c3(args, log):
+    from mpv_amd.bench_common import Ranks
+    rk = Ranks(args)                                   # N ranks: every rank samples windows of its own trajectory (weak scaling)
+    out = record_c3(args, log, rk)
+    if rk.rank == 0:
+        print(json.dumps(out), flush=True)
+    rk.close()
+
+
+def record_c3(args, log, rk):
+    """One bench record of BASELINE configs[2] (dict; printed by `--config c3`, embedded as other_configs.c3 by the default run)."""
     from mpv_amd import synthetic
     from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
     from mpv_amd.models.models import diffusion_models
-    from mpv_amd.bench_common import Ranks
-    rk = Ranks(args)                                   # N ranks: every rank samples windows of its own trajectory (weak scaling)
+    from mpv_amd.bench_common import measured_traffic
     device = rk.device
-    cfg = C3
+    cfg = dict(C3)
+    short = int(os.environ.get("MPV_BENCH_DTS_STEPS", "0"))              # profiling aid (PMC passes): fewer DDIM steps, flagged in the record
+    if short > 0:
+        cfg["diffusion_steps"] = short
     from mpv_amd import _native
     gen = _native.Context(device)
     sampled, _ = synthetic.sis_trajectory_device(gen, cfg["nodes"], cfg["ticks"], seed=2000 + rk.rank, sampling_stride=H.sampling_interval_from_t(cfg["sampling_t"]))
@@ -93,38 +105,50 @@ def main_c3(args, log):
                                "4 heads, 3 enc + 6 dec blocks, N=32 samples in one chunk (3200 sequences x 200 tokens), T=100 DDIM steps with "
                                "Langevin infill; {} window(s) per step of the {} of the trajectory".format(wps, n_total),
                    "windows_per_step_per_gpu": wps, "noise": "on-device Philox4x32-10", "weights": "seeded default init",
+                   "truncated_for_profiling": short > 0, "sampling_steps": cfg["diffusion_steps"],
                    "passes_per_window": {"forward": n_fwd, "backward": n_bwd}},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
-                     "traffic": None, "kernel": "dts_lin_kernel + dts_attn_* + dts_seqmix_kernel (whole sampler call)",
+                     "traffic": traffic_per_window(measured_traffic("c3"), n_fwd, n_bwd),
+                     "traffic_detail": measured_traffic("c3"),
+                     "kernel": "dts_attn_{fwd,dq,dkv} + dts_lin_wave + dts_mlp_{fwd,bwd} + dts_seqmix (whole sampler call)",
                      "flop_per_window": flop_per_window, "flop_per_sequence_forward": ff, "flop_per_sequence_backward": fb,
                      "peak_source": "fp32 matrix pipe (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md",
                      "note": "achieved = algorithmic FLOPs of the dense contractions / wall time of the timed steps (all kernels of the call)"},
     }
     if not args.no_cpu_baseline and rk.world == 1:
         out["cpu_baseline"] = cpu_baseline(model, series, cfg, log)
-    if rk.rank == 0:
-        print(json.dumps(out), flush=True)
-    rk.close()
+    return out
 
 
-def cpu_baseline(model, series, cfg, log):
-    """The CPU oracle (torch fp32 port of the reference sampler) on a bounded sample of the same workload: 2 nodes x 2 samples of
-    the first window, all T = 100 steps; windows/s scaled by the share of the window's 3200 sequences that was computed."""
+def traffic_per_window(rec, n_fwd, n_bwd):
+    """HBM bytes of one window's sampler call = the PMC pass's bytes per forward / backward pass x the passes of the full plan."""
+    if not rec or "bytes_per_forward_pass" not in rec:
+        return None
+    return rec["bytes_per_forward_pass"] * n_fwd + rec["bytes_per_backward_pass"] * n_bwd
+
+
+def cpu_baseline(model, series, cfg, log, nodes=4, par=4):
+    """The CPU oracle (torch fp32 port of the reference sampler) on a bounded sample of the same workload: `nodes` x `par` sequences of
+    the first window, all T = 100 steps; windows/s scaled by the share of the window's 3200 sequences that was computed.  16 sequences is
+    where the per-sequence time stops falling with the batch (measured on 8 cores: 1.00 / 0.22 / 0.22 / 0.29 s per sequence at 4 / 16 /
+    32 / 64 sequences), so the linear scaling to 3200 does not overstate the CPU cost."""
     from oracle import diffusionts_oracle as O
-    import bench as B
-    cores = B.cpu_share()
+    from mpv_amd.bench_common import cpu_share
+    cores = cpu_share()
     torch.set_num_threads(cores)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ocfg = O.DTSConfig(cfg["windows"], cfg["pred_len"], cfg["nf"], cfg["d_model"], cfg["n_layer_enc"], cfg["n_layer_dec"], cfg["n_heads"],
-                       cfg["timesteps"], cfg["diffusion_steps"], n_z_samples=2, parallel_sample=2)
-    batch = series[:2, : cfg["windows"], :].cpu()
+                       cfg["timesteps"], cfg["diffusion_steps"], n_z_samples=par, parallel_sample=par)
+    batch = series[:nodes, : cfg["windows"], :].cpu()
     g = torch.Generator().manual_seed(1)
-    log("c3 cpu baseline: 4 of the 3200 sequences of one window on %d threads" % cores)
+    n = nodes * par
+    log("c3 cpu baseline: %d of the 3200 sequences of one window on %d threads" % (n, cores))
     t0 = time.perf_counter()
     outs = O.evaluation_step(sd, ocfg, batch, lambda shape: torch.randn(shape, generator=g))
     dt = time.perf_counter() - t0
     log("c3 cpu baseline done in %.1f s" % dt)
-    share = 4.0 / (cfg["nodes"] * cfg["n_z"])
+    share = float(n) / (cfg["nodes"] * cfg["n_z"])
     return {"value": share / dt, "unit": "windows/s", "cores": cores, "kind": "port", "finite": bool(torch.isfinite(outs).all()),
-            "sample": "2 nodes x 2 samples (4 of the 3200 sequences of one window), all T=100 steps, oracle/diffusionts_oracle.py "
-                      "(torch CPU fp32 port of the reference sampler incl. autograd for the Langevin infill), {:.1f} s; value = (4/3200 window) / time".format(dt)}
+            "sample": "{} nodes x {} samples ({} of the 3200 sequences of one window: the batch at which the CPU's per-sequence time has "
+                      "plateaued), all T={} steps, oracle/diffusionts_oracle.py (torch CPU fp32 port of the reference sampler incl. autograd "
+                      "for the Langevin infill), {:.1f} s; value = ({}/3200 window) / time".format(nodes, par, n, cfg["diffusion_steps"], dt, n)}

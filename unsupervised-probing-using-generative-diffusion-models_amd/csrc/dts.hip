@@ -718,7 +718,7 @@ int mpv_dts_sample(mpv_ctx* ctx, const mpv_dts_sample_shape* s, const float* his
         MPV_HIP_TRY(ctx, hipGetLastError());
         for (int c = 0; c < s->n_samples / par; ++c) {
             long long draw = (long long)c * draws_per_chunk;
-            unsigned stream_id = (unsigned)c * 65536u;
+            unsigned stream_id = (unsigned)((long long)c * draws_per_chunk);   // chunks never share a Philox stream, however long the Langevin plan
             auto next_noise = [&](bool used, float* dst) -> int {        // consume one draw of the reference's stream
                 if (noise) {
                     if (used) MPV_HIP_TRY(ctx, hipMemcpyAsync(dst, noise + draw * n_full + e0, sizeof(float) * n, hipMemcpyDeviceToDevice, st));

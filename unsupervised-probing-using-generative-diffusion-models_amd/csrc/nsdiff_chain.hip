@@ -319,11 +319,17 @@ static int run_chain(mpv_ctx* ctx, const NsdiffModel& m, bool tmdm, const mpv_sa
         return mpv_fail(ctx, MPV_EINVAL, "device LDS too small for the resident-weight chain kernel");
     const bool philox = (noise == nullptr);
 
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct EventPair {                                                   // destroyed on every early return; handed to ctx->events on success
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~EventPair() {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } ev;
     if (ctx->timing) {
-        MPV_HIP_TRY(ctx, hipEventCreate(&e0));
-        MPV_HIP_TRY(ctx, hipEventCreate(&e1));
-        MPV_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+        MPV_HIP_TRY(ctx, hipEventCreate(&ev.e0));
+        MPV_HIP_TRY(ctx, hipEventCreate(&ev.e1));
+        MPV_HIP_TRY(ctx, hipEventRecord(ev.e0, ctx->stream));
     }
     const int group = fused ? cap : s.n_windows;
     for (int w0 = 0; w0 < s.n_windows; w0 += group) {
@@ -382,8 +388,9 @@ static int run_chain(mpv_ctx* ctx, const NsdiffModel& m, bool tmdm, const mpv_sa
         if (rc != MPV_OK) return rc;
     }
     if (ctx->timing) {
-        MPV_HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
-        ctx->events.emplace_back(e0, e1);
+        MPV_HIP_TRY(ctx, hipEventRecord(ev.e1, ctx->stream));
+        ctx->events.emplace_back(ev.e0, ev.e1);
+        ev.e0 = ev.e1 = nullptr;
     }
     if (!want_summary) return MPV_OK;
     const long long R = (long long)s.nodes * s.pred_len;

@@ -415,6 +415,16 @@ __global__ void stg_posterior_kernel(const float* __restrict__ eps, const float*
     xt[i] = ddpm ? a + c3 * z[i] : a + c3 * pred;
 }
 
+// eps [N][F][T] (the network's channel-major output) -> [N][T][F] (the layout of x_t and of the reference's return value)
+__global__ void stg_eps_transpose_kernel(const float* __restrict__ eps, int T, int F, long long n, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // (node*T + t)*F + f
+    if (i >= n) return;
+    const int f = (int)(i % F);
+    const int t = (int)((i / F) % T);
+    const long long node = i / ((long long)F * T);
+    out[i] = eps[(node * F + f) * T + t];
+}
+
 // x_masked rows: r = (w*P + p)*V + v  <-  history[w][v][t][f] for t < T_h, 0 after
 __global__ void stg_build_masked_kernel(const float* __restrict__ hist, int V, int P, int T, int T_h, int F, long long n, float* xm) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -840,8 +850,9 @@ int mpv_stg_forward(mpv_ctx* ctx, const float* xt, const float* x_masked, int64_
     if (F == 1) {
         MPV_HIP_TRY(ctx, hipMemcpyAsync(eps_out, e.eps, sizeof(float) * n_rows * T, hipMemcpyDeviceToDevice, ctx->stream));
     } else {
-        MPV_HIP_TRY(ctx, hipMemcpy2DAsync(eps_out, sizeof(float) * F, e.eps, sizeof(float), sizeof(float), 1, hipMemcpyDeviceToDevice, ctx->stream));
-        return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_forward: F > 1 output transposition is not built (the reference's evaluation_step assumes F = 1)");
+        const long long n = (long long)n_rows * T * F;
+        hipLaunchKernelGGL(stg_eps_transpose_kernel, g1d(n), dim3(256), 0, ctx->stream, e.eps, T, F, n, eps_out);
+        MPV_HIP_TRY(ctx, hipGetLastError());
     }
     return MPV_OK;
 }
@@ -865,7 +876,7 @@ int mpv_stg_sample(mpv_ctx* ctx, const mpv_stg_sample_shape* s, const float* his
     MPV_HIP_TRY(ctx, hipGetLastError());
     for (int pass = 0; pass < s->sequential; ++pass) {
         long long draw = (long long)pass * draws;
-        unsigned stream_id = (unsigned)pass * 4096u;
+        unsigned stream_id = (unsigned)pass * (unsigned)draws;            // passes never share a Philox stream, whatever the number of DDPM steps
         auto next_noise = [&](float* dst) -> int {
             if (noise) MPV_HIP_TRY(ctx, hipMemcpyAsync(dst, noise + draw * n, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
             else {

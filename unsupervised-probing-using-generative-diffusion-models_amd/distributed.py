@@ -16,6 +16,7 @@ the per-row (mean, M2) pairs with Chan's parallel update after one all-gather.
 """
 from __future__ import annotations
 
+import os
 from typing import Tuple
 
 import numpy as np
@@ -24,7 +25,12 @@ import torch.distributed as dist
 
 
 def active() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """A process group with more than one rank -- or, with MPV_FORCE_DIST=1, any initialised group: a world of ONE then takes the very
+    collective branches (RCCL on device tensors under `nccl`) that N ranks take, which is how a one-GPU box exercises them
+    (tests/test_rccl_world1_gpu.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("MPV_FORCE_DIST") == "1"
 
 
 def rank() -> int:
