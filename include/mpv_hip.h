@@ -322,6 +322,49 @@ typedef struct {
 int mpv_stg_sample(mpv_ctx* ctx, const mpv_stg_sample_shape* shape, const float* history, const double* plan, const float* noise, float* samples);
 
 /* ------------------------------------------------------------------------------------
+ * NsDiff_spatial: NsDiff's graph U-Net epsilon / sigma network + the NsDiff reverse loop
+ * replaces: UGnet.forward of models/Diffusion_model/NsDiff/ugnet.py:194-292 (x_proj over cat(y_t, y_0_hat, g), the ResidualBlock / Down /
+ *           Upsample sequence of mpv_stg_step at time length pred_len, out = Conv2d(d_h, d_h, 1x1) + Linear(T, T), eps = lin4(.),
+ *           sigma = softplus(sigma_lin(softplus(.)))), NsDiff_net_spatial.forward (NsDiff_net.py:175-260), and the sampling part of
+ *           NsDiff_model_spatial.evaluation_step (NsDiff_model.py:695-790): node-major row tiling (row v*P + p) against the copy-major
+ *           duplicated edge index (copy r / V, node r % V: reproduced as the reference has it), p_sample_loop with p_sample /
+ *           p_sample_t_1to0 (nsdiff_utils.py:111-158, 209-239, 271-284).  f(x) (Model_spatial) is an input: y0hat.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t pred_len;      /* T = O: the sampled horizon, a multiple of 4 (and even at every U-Net resolution) */
+    int32_t nf;            /* F                                                                    */
+    int32_t d_h;           /* base channels = time-embedding width                                 */
+    int32_t Td_h;          /* taps the k = T+1 convolution reduces the time axis to (even)         */
+    int32_t steps;         /* diffusion_steps: timesteps 0..steps-1                                */
+    int32_t gemm;          /* as mpv_stg_desc.gemm                                                 */
+} mpv_nss_desc;
+
+/* steps: as mpv_stg_load (time length pred_len at the top resolution).  head: host { x_proj.weight [d_h][3F], x_proj.bias, out.0.weight
+ * [d_h][d_h], out.0.bias, out.1.weight [T][T], out.1.bias, lin4.weight [F][d_h], lin4.bias, sigma_lin.weight [F][d_h], sigma_lin.bias,
+ * coef [steps][MPV_COEF_COLS] (the rows of mpv_nsdiff_load) }.  temb: host [steps][d_h] = TimeEmbedding(t, d_h), t = 0..steps-1. */
+int mpv_nss_load(mpv_ctx* ctx, const mpv_nss_desc* desc, const mpv_stg_step* steps, int32_t n_steps, const float* const* head, const float* temb);
+
+/* The graph of ONE window, as mpv_stg_set_graph. */
+int mpv_nss_set_graph(mpv_ctx* ctx, int32_t n_nodes, int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst);
+
+/* (eps, sigma) = UGnet(y_t, y_0_hat, g, t, edges): all dev [n_rows][T][F], n_rows a multiple of the graph's node count (consecutive
+ * blocks of n_nodes rows are the graph copies). */
+int mpv_nss_forward(mpv_ctx* ctx, const float* y, const float* y0hat, const float* gx, int64_t n_rows, int32_t t, float* eps_out, float* sigma_out);
+
+typedef struct {
+    int32_t n_windows;     /* W evaluation_step calls batched                                       */
+    int32_t nodes;         /* V = the graph's node count                                            */
+    int32_t n_samples;     /* S = n_z_samples                                                       */
+    int32_t chunk;         /* P = parallel_sample: graph copies per window in one pass; S % P == 0  */
+    uint64_t seed;
+} mpv_nss_sample_shape;
+
+/* y0hat, gx: dev [W][V][O][F] (f(x) and the sigma head's g(x) per node).  noise: dev or NULL: the reference's draws in its order, laid out as
+ * for mpv_nsdiff_sample: [W][S/P][steps][V*P][O][F] (draw 0 = z_T, then one per step t = steps-1 .. 1, each AFTER the model call);
+ * NULL: Philox4x32-10.  samples: dev [W][V][O][F][S], sample index c*P + p; window w's slice is the reference's `outs`. */
+int mpv_nss_sample(mpv_ctx* ctx, const mpv_nss_sample_shape* shape, const float* y0hat, const float* gx, const float* noise, float* samples);
+
+/* ------------------------------------------------------------------------------------
  * Synthetic input generation on device (the step before the path)
  * replaces: the harvested-biomass network simulator dataset/spdata_sde_biomass_dynamic_gene.py:53-68 (drift f, noise g;
  *           there integrated by torchsde) + normalize_time_series / sample_time_series of the harness

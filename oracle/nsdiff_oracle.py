@@ -187,9 +187,10 @@ def _y0_reparam(tb, t, y, mean_T, eps, noise):
     return 1 / r * (y - (1 - r) * mean_T - eps * torch.sqrt(noise))
 
 
-def reverse_step(sd, tb, y, y0hat, gx, mean_T, t: int, z: torch.Tensor) -> torch.Tensor:
-    """One p_sample step t>=1 with the noise z supplied (nsdiff_utils.py:111-158)."""
-    eps, sig = eps_network(sd, y, y0hat, gx, t)
+def reverse_step(sd, tb, y, y0hat, gx, mean_T, t: int, z: torch.Tensor, net=None) -> torch.Tensor:
+    """One p_sample step t>=1 with the noise z supplied (nsdiff_utils.py:111-158).  `net(sd, y, y0hat, gx, t) -> (eps, sigma)`: the
+    epsilon network, the pointwise MLP by default (NsDiff_spatial passes its graph U-Net, oracle/nsdiff_spatial_oracle.py)."""
+    eps, sig = (net or eps_network)(sd, y, y0hat, gx, t)
     sigma_y0, noise = _sigma_y0_and_noise(tb, t, gx, sig)
     y0r = _y0_reparam(tb, t, y, mean_T, eps, noise)
     # calc_gammas / cal_sigma12 (nsdiff_utils.py:40-56, 80-92)
@@ -206,9 +207,9 @@ def reverse_step(sd, tb, y, y0hat, gx, mean_T, t: int, z: torch.Tensor) -> torch
     return g0 * y0r + g1 * y + g2 * mean_T + torch.sqrt(sig) * z
 
 
-def final_step(sd, tb, y, y0hat, gx, mean_T) -> torch.Tensor:
+def final_step(sd, tb, y, y0hat, gx, mean_T, net=None) -> torch.Tensor:
     """p_sample_t_1to0: returns the y0 re-parameterisation at t=0, no noise (:209-239)."""
-    eps, sig = eps_network(sd, y, y0hat, gx, 0)
+    eps, sig = (net or eps_network)(sd, y, y0hat, gx, 0)
     _, noise = _sigma_y0_and_noise(tb, 0, gx, sig)
     return _y0_reparam(tb, 0, y, mean_T, eps, noise)
 
@@ -228,7 +229,7 @@ def replay_noise(draws: Sequence[torch.Tensor]) -> NoiseFn:
 
 
 def sample_loop(sd, tb, y0hat, gx, mean_T, steps: int, noise: NoiseFn,
-                record: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+                record: Optional[List[torch.Tensor]] = None, net=None) -> torch.Tensor:
     """p_sample_loop (:271-284).  Draw order: z_T, then one z per step t=T-1..1 taken
     AFTER that step's network call; the final step draws nothing."""
     z = noise(tuple(mean_T.shape))
@@ -239,8 +240,8 @@ def sample_loop(sd, tb, y0hat, gx, mean_T, steps: int, noise: NoiseFn,
         z = noise(tuple(y.shape))
         if record is not None:
             record.append(z)
-        y = reverse_step(sd, tb, y, y0hat, gx, mean_T, t, z)
-    return final_step(sd, tb, y, y0hat, gx, mean_T)
+        y = reverse_step(sd, tb, y, y0hat, gx, mean_T, t, z, net=net)
+    return final_step(sd, tb, y, y0hat, gx, mean_T, net=net)
 
 
 # --------------------------------------------------------------------------------------

@@ -46,16 +46,19 @@ def main():
     fetch, write, dur = counters(os.path.join(root, "pmc_FETCH_SIZE"), "FETCH_SIZE"), counters(os.path.join(root, "pmc_WRITE_SIZE"), "WRITE_SIZE"), durations(os.path.join(root, "stats"))
     kernels, total = {}, 0.0
     for k in sorted(set(fetch) | set(write)):
-        fb = 2.0 * 1024.0 * sum(fetch.get(k, []))          # gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes
-        wb = 1024.0 * sum(write.get(k, []))
-        rec = {"launches": max(len(fetch.get(k, [])), len(write.get(k, []))), "fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
+        nf, nw = max(len(fetch.get(k, [])), 1), max(len(write.get(k, [])), 1)
+        fb = 2.0 * 1024.0 * sum(fetch.get(k, [])) / nf     # per launch; gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes
+        wb = 1024.0 * sum(write.get(k, [])) / nw
+        # the step's launches of this kernel come from the stats pass: the PMC passes may run a SHORTER plan of the same launches (c3:
+        # MPV_BENCH_DTS_STEPS) -- bytes per launch do not depend on the plan length, the number of launches does
+        calls = dur[k]["calls"] if k in dur else max(len(fetch.get(k, [])), len(write.get(k, [])))
+        rec = {"launches": calls, "pmc_launches": max(len(fetch.get(k, [])), len(write.get(k, []))), "fetch_bytes_per_launch": fb,
+               "write_bytes_per_launch": wb, "hbm_bytes": (fb + wb) * calls}
         if k in dur and dur[k]["total_ms"] > 0:
-            # the stats pass may hold a different number of launches (warm-up): scale bytes per launch x its calls
-            per_launch = (fb + wb) / max(rec["launches"], 1)
-            rec.update(avg_us=dur[k]["avg_us"], share_pct=dur[k]["share_pct"], GBps=per_launch / (dur[k]["avg_us"] * 1e-6) / 1e9,
-                       frac_of_8TBps=per_launch / (dur[k]["avg_us"] * 1e-6) / 8e12)
+            rec.update(avg_us=dur[k]["avg_us"], share_pct=dur[k]["share_pct"], GBps=(fb + wb) / (dur[k]["avg_us"] * 1e-6) / 1e9,
+                       frac_of_8TBps=(fb + wb) / (dur[k]["avg_us"] * 1e-6) / 8e12)
         kernels[k] = rec
-        total += fb + wb
+        total += rec["hbm_bytes"]
     top = sorted(kernels.items(), key=lambda kv: -kv[1].get("share_pct", 0.0))
     res = {"_how": how, "_correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KB) x 1024 x 2 (gfx950 reports half of wide coalesced reads), "
                                        "WRITE_SIZE (KB) x 1024 exact; separate --pmc passes, durations from a third --kernel-trace --stats pass",

@@ -10,8 +10,13 @@ case $CFG in
   c3) ARGS="--config c3 --steps 1 --warmup 0 --dts-windows 1 --no-cpu-baseline"; WIN=1 ;;
   c4) ARGS="--config c4 --steps 1 --warmup 0 --no-cpu-baseline"; WIN=181 ;;
 esac
+PMCENV=""
+[ $CFG = c3 ] && PMCENV=10      # c3: the counter passes run a 10-step plan (same launches, 10x fewer: a counter pass of the 36 k launches of the full plan takes > 7 min)
+if [ -z "$SKIP_STATS" ]; then
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/stats.json 2> $OUT/stats.err || exit 1
+fi
 echo "stats pass done"
+[ -n "$PMCENV" ] && export MPV_BENCH_DTS_STEPS=$PMCENV
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 700 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o run -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err || exit 1
   echo "$c pass done"

@@ -26,6 +26,7 @@ EXPORTS = (
     "mpv_nsdiff_load", "mpv_nsdiff_sample", "mpv_chain_stats", "mpv_nsdiff_philox_normals", "mpv_sigma_load", "mpv_sigma_head",
     "mpv_reduce", "mpv_chain_timing", "mpv_chain_timing_enable", "mpv_tmdm_load", "mpv_tmdm_sample",
     "mpv_stg_load", "mpv_stg_set_graph", "mpv_stg_forward", "mpv_stg_sample",
+    "mpv_nss_load", "mpv_nss_set_graph", "mpv_nss_forward", "mpv_nss_sample",
     "mpv_biomass_simulate", "mpv_network_sde_simulate", "mpv_dts_load", "mpv_dts_forward", "mpv_dts_vjp", "mpv_dts_debug_tensor", "mpv_dts_sample",
     "mpv_nst_load", "mpv_nst_forward", "mpv_nst_debug_tensor", "mpv_slbp_simulate",
 )
@@ -82,6 +83,14 @@ class StgSampleShape(C.Structure):
 
 
 STG_PLAN_COLS = 6
+
+
+class NssDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("pred_len", "nf", "d_h", "Td_h", "steps", "gemm")]
+
+
+class NssSampleShape(C.Structure):
+    _fields_ = [("n_windows", C.c_int32), ("nodes", C.c_int32), ("n_samples", C.c_int32), ("chunk", C.c_int32), ("seed", C.c_uint64)]
 
 
 class NstDesc(C.Structure):
@@ -157,6 +166,10 @@ def load_library():
         "mpv_stg_set_graph": (C.c_int, [vp, i32, i64, C.POINTER(i64), C.POINTER(i64)]),
         "mpv_stg_forward": (C.c_int, [vp, vp, vp, i64, i32, vp]),
         "mpv_stg_sample": (C.c_int, [vp, C.POINTER(StgSampleShape), vp, C.POINTER(C.c_double), vp, vp]),
+        "mpv_nss_load": (C.c_int, [vp, C.POINTER(NssDesc), C.POINTER(StgStep), i32, C.POINTER(_F), _F]),
+        "mpv_nss_set_graph": (C.c_int, [vp, i32, i64, C.POINTER(i64), C.POINTER(i64)]),
+        "mpv_nss_forward": (C.c_int, [vp, vp, vp, vp, i64, i32, vp, vp]),
+        "mpv_nss_sample": (C.c_int, [vp, C.POINTER(NssSampleShape), vp, vp, vp, vp]),
         "mpv_dts_load": (C.c_int, [vp, C.POINTER(DtsDesc), C.POINTER(_F), i32, _F, _F, _F]),
         "mpv_dts_forward": (C.c_int, [vp, vp, i32, i32, vp, vp]),
         "mpv_dts_vjp": (C.c_int, [vp, vp, i32, i32, vp, vp]),
@@ -220,6 +233,8 @@ class Context:
         self.dts = None        # DtsDesc fields
         self.stg = None        # (T_h, T_p, F, graph nodes | None)
         self._stg_graph = None
+        self.nss = None        # (pred_len, F, steps) of the loaded NsDiff_spatial network
+        self._nss_graph = None
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -497,10 +512,10 @@ class Context:
         self._check(self.lib.mpv_nst_debug_tensor(self._h, idx, _dev_ptr(out, self.device, "out"), out.numel()), "mpv_nst_debug_tensor")
         return out
 
-    def load_stg(self, ugnet):
-        """Upload a UGnet holder (models/Diffusion_model/DiffSTG/ugnet.py): its layout() gives the step sequence."""
+    def _stg_steps(self, ugnet, T_top: int, n_temb: int, keep: list):
+        """Marshal a UGnet holder's layout() into mpv_stg_step records (+ the TimeEmbedding table for t = 0..n_temb-1, reference
+        ugnet.py:15-33); `keep` collects the host tensors the pointers refer to."""
         import math
-        keep = []
 
         def h(t):
             if t is None:
@@ -534,7 +549,7 @@ class Context:
             for k, t in enumerate(tensors):
                 arr[i].w[k] = h(t)
         # time lengths of the resampling steps follow from the sequence
-        T_cur = 2 * ugnet.T
+        T_cur = T_top
         for i, st in enumerate(steps):
             if st["kind"] == "res":
                 if arr[i].T != T_cur:
@@ -542,15 +557,21 @@ class Context:
             else:
                 arr[i].T = T_cur
                 T_cur = (T_cur - 1) // 2 + 1 if st["kind"] == "down" else 2 * T_cur
-        T_steps = int(ugnet.net_param["diffusion_steps"])
         d_h = ugnet.d_h
         half = d_h // 2                                                            # TimeEmbedding, reference ugnet.py:15-33
         freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
-        emb = torch.arange(T_steps + 1).float()[:, None] * freq[None, :]
+        emb = torch.arange(n_temb).float()[:, None] * freq[None, :]
         temb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
         if d_h % 2 == 1:
             temb = torch.nn.functional.pad(temb, (0, 1, 0, 0))
-        temb = _host_f32(temb)
+        return arr, len(steps), _host_f32(temb)
+
+    def load_stg(self, ugnet):
+        """Upload a UGnet holder (models/Diffusion_model/DiffSTG/ugnet.py): its layout() gives the step sequence."""
+        keep = []
+        T_steps = int(ugnet.net_param["diffusion_steps"])
+        arr, n_steps, temb = self._stg_steps(ugnet, 2 * ugnet.T, T_steps + 1, keep)
+        d_h = ugnet.d_h
         head = [_host_f32(t) for t in (ugnet.x_proj.weight, ugnet.x_proj.bias, ugnet.out[0].weight, ugnet.out[0].bias, ugnet.out[1].weight,
                                         ugnet.out[1].bias)]
         head_arr = (_F * 6)(*[_fptr(t) for t in head])
@@ -559,9 +580,75 @@ class Context:
             raise MpvError("DiffSTG supports gemm_mode 'f16x3' and 'f32'")
         desc = StgDesc(ugnet.T_h, ugnet.T_p, ugnet.F, d_h, int(ugnet.net_param["Td_h"]), T_steps, GEMM_MODES[gemm])
         self._bind_stream()
-        self._check(self.lib.mpv_stg_load(self._h, C.byref(desc), arr, len(steps), head_arr, _fptr(temb)), "mpv_stg_load")
+        self._check(self.lib.mpv_stg_load(self._h, C.byref(desc), arr, n_steps, head_arr, _fptr(temb)), "mpv_stg_load")
         self.stg = (ugnet.T_h, ugnet.T_p, ugnet.F)
         self._stg_graph = None
+
+    # ---- NsDiff_spatial --------------------------------------------------------------------
+    def load_nss(self, ugnet, coef: torch.Tensor, steps: int, gemm: str = "f16x3"):
+        """Upload NsDiff's UGnet holder (models/Diffusion_model/NsDiff/ugnet.py) with the per-step posterior coefficient rows."""
+        keep = []
+        arr, n_steps, temb = self._stg_steps(ugnet, ugnet.T, int(steps), keep)
+        coef = _host_f32(coef)
+        if tuple(coef.shape) != (int(steps), COEF_COLS):
+            raise MpvError("coef must be [{}, {}]".format(steps, COEF_COLS))
+        head = [_host_f32(t) for t in (ugnet.x_proj.weight, ugnet.x_proj.bias, ugnet.out[0].weight, ugnet.out[0].bias, ugnet.out[1].weight, ugnet.out[1].bias,
+                                        ugnet.lin4.weight, ugnet.lin4.bias, ugnet.sigma_lin.weight, ugnet.sigma_lin.bias, coef)]
+        head_arr = (_F * 11)(*[_fptr(t) for t in head])
+        if gemm not in ("f16x3", "f32"):
+            raise MpvError("NsDiff_spatial supports gemm_mode 'f16x3' and 'f32'")
+        desc = NssDesc(ugnet.T, ugnet.F, ugnet.d_h, int(ugnet.Td_h), int(steps), GEMM_MODES[gemm])
+        self._bind_stream()
+        self._check(self.lib.mpv_nss_load(self._h, C.byref(desc), arr, n_steps, head_arr, _fptr(temb)), "mpv_nss_load")
+        self.nss = (ugnet.T, ugnet.F, int(steps))
+        self._nss_graph = None
+
+    def nss_set_graph(self, edge_index: torch.Tensor, num_nodes: int):
+        if self.nss is None:
+            raise MpvError("NsDiff_spatial weights not loaded")
+        e = torch.as_tensor(edge_index).detach().to("cpu", torch.int64).reshape(2, -1).contiguous()
+        key = (int(num_nodes), e.shape[1], hash(e.numpy().tobytes()))
+        if self._nss_graph == key:
+            return
+        src, dst = e[0].contiguous(), e[1].contiguous()
+        P64 = C.POINTER(C.c_int64)
+        self._check(self.lib.mpv_nss_set_graph(self._h, int(num_nodes), e.shape[1], C.cast(src.data_ptr(), P64), C.cast(dst.data_ptr(), P64)),
+                    "mpv_nss_set_graph")
+        self._nss_graph = key
+
+    def nss_forward(self, y: torch.Tensor, y0hat: torch.Tensor, gx: torch.Tensor, t: int):
+        """(eps, sigma) = UGnet(y_t, y_0_hat, g, t) over the graph set by nss_set_graph; all [rows, pred_len, F] on device."""
+        if self.nss is None:
+            raise MpvError("NsDiff_spatial weights not loaded")
+        if not (tuple(y.shape) == tuple(y0hat.shape) == tuple(gx.shape)) or y.dim() != 3 or y.shape[1] != self.nss[0] or y.shape[2] != self.nss[1]:
+            raise MpvError("y, y0hat and gx must all be [rows, {}, {}]".format(self.nss[0], self.nss[1]))
+        eps, sig = torch.empty_like(y), torch.empty_like(y)
+        self._bind_stream()
+        self._check(self.lib.mpv_nss_forward(self._h, _dev_ptr(y, self.device, "y"), _dev_ptr(y0hat, self.device, "y0hat"), _dev_ptr(gx, self.device, "gx"),
+                                             y.shape[0], int(t), _dev_ptr(eps, self.device, "eps"), _dev_ptr(sig, self.device, "sigma")), "mpv_nss_forward")
+        return eps, sig
+
+    def nss_sample(self, y0hat: torch.Tensor, gx: torch.Tensor, edge_index: torch.Tensor, n_samples: int, chunk: int,
+                   noise: Optional[torch.Tensor] = None, seed: int = 0) -> torch.Tensor:
+        """y0hat, gx [W, V, pred_len, F] on device -> samples [W, V, pred_len, F, n_samples] on device."""
+        if self.nss is None:
+            raise MpvError("NsDiff_spatial weights not loaded")
+        if tuple(y0hat.shape) != tuple(gx.shape) or y0hat.dim() != 4 or y0hat.shape[2] != self.nss[0] or y0hat.shape[3] != self.nss[1]:
+            raise MpvError("y0hat and gx must both be [W, V, {}, {}]".format(self.nss[0], self.nss[1]))
+        W, V, O, F = y0hat.shape
+        if chunk < 1 or n_samples < 1 or n_samples % chunk != 0:
+            raise MpvError("n_samples must be a positive multiple of chunk (parallel_sample)")
+        self.nss_set_graph(edge_index, V)
+        if noise is not None:
+            need = W * (n_samples // chunk) * self.nss[2] * V * chunk * O * F
+            if noise.numel() != need:
+                raise MpvError("noise has {} elements, the draw order needs {}".format(noise.numel(), need))
+        out = torch.empty((W, V, O, F, n_samples), device=self.device, dtype=torch.float32)
+        shape = NssSampleShape(W, V, n_samples, chunk, seed & (2 ** 64 - 1))
+        self._bind_stream()
+        self._check(self.lib.mpv_nss_sample(self._h, C.byref(shape), _dev_ptr(y0hat, self.device, "y0hat"), _dev_ptr(gx, self.device, "gx"),
+                                            _dev_ptr(noise, self.device, "noise"), _dev_ptr(out, self.device, "samples")), "mpv_nss_sample")
+        return out
 
     def stg_set_graph(self, edge_index: torch.Tensor, num_nodes: int):
         if self.stg is None:

@@ -97,6 +97,7 @@ def record_c3(args, log, rk):
     seqs = cfg["nodes"] * cfg["n_z"]
     flop_per_window = seqs * (n_fwd * ff + n_bwd * fb)
     achieved = flop_per_window * wps * args.steps / elapsed / 1e12                       # per GPU
+    tr = measured_traffic("c3")
     out = {
         "metric": "rolling windows/sec (N=32, T=100), DiffusionTS", "value": rk.world * wps * args.steps / elapsed, "unit": "windows/s", "n_gpus": rk.world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -108,8 +109,7 @@ def record_c3(args, log, rk):
                    "truncated_for_profiling": short > 0, "sampling_steps": cfg["diffusion_steps"],
                    "passes_per_window": {"forward": n_fwd, "backward": n_bwd}},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
-                     "traffic": traffic_per_window(measured_traffic("c3"), n_fwd, n_bwd),
-                     "traffic_detail": measured_traffic("c3"),
+                     "traffic": (tr or {}).get("bytes_per_window") if short == 0 else None, "traffic_detail": slim_traffic(tr),
                      "kernel": "dts_attn_{fwd,dq,dkv} + dts_lin_wave + dts_mlp_{fwd,bwd} + dts_seqmix (whole sampler call)",
                      "flop_per_window": flop_per_window, "flop_per_sequence_forward": ff, "flop_per_sequence_backward": fb,
                      "peak_source": "fp32 matrix pipe (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md",
@@ -120,11 +120,13 @@ def record_c3(args, log, rk):
     return out
 
 
-def traffic_per_window(rec, n_fwd, n_bwd):
-    """HBM bytes of one window's sampler call = the PMC pass's bytes per forward / backward pass x the passes of the full plan."""
-    if not rec or "bytes_per_forward_pass" not in rec:
+def slim_traffic(rec, top=8):
+    """The committed PMC record without its long tail of tiny kernels (the JSON line stays readable)."""
+    if not rec:
         return None
-    return rec["bytes_per_forward_pass"] * n_fwd + rec["bytes_per_backward_pass"] * n_bwd
+    out = {k: v for k, v in rec.items() if k != "kernels"}
+    out["kernels"] = dict(list(rec.get("kernels", {}).items())[:top])
+    return out
 
 
 def cpu_baseline(model, series, cfg, log, nodes=4, par=4):

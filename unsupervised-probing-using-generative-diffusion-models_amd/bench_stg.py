@@ -69,6 +69,7 @@ def record_c5(args, log, rk):
     from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
     from mpv_amd.models.models import diffusion_models
     from mpv_amd.bench_common import measured_traffic, cpu_share
+    from mpv_amd.bench_dts import slim_traffic
     device = rk.device
     cfg = C5
     from mpv_amd import _native
@@ -131,7 +132,7 @@ def record_c5(args, log, rk):
                                "{} window(s) per step of the {} of the trajectory".format(wps, n_total),
                    "windows_per_step_per_gpu": wps, "noise": "on-device Philox4x32-10", "weights": "seeded default init"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
-                     "traffic": (tr or {}).get("bytes_per_window"), "traffic_detail": tr,
+                     "traffic": (tr or {}).get("bytes_per_window"), "traffic_detail": slim_traffic(tr),
                      "kernel": "nst_gemm_h3_kernel + stg_tcn_ln_kernel + stg_gate_kernel (whole sampler call)",
                      "flop_per_window": flop_per_window, "flop_per_row_forward": fpr,
                      "note": "achieved = algorithmic FLOPs / wall time of the timed steps; the network is small (2.7e7 FLOP per node row per step), "

@@ -243,6 +243,7 @@ void mpv_ctx_destroy(mpv_ctx* ctx) {
     if (ctx->sample_ws) (void)hipFree(ctx->sample_ws);
     dts_engine_destroy(ctx->dts);
     stg_engine_destroy(ctx->stg);
+    stg_engine_destroy(ctx->nss);
     nst_engine_destroy(ctx->nst);
     delete ctx;
 }

@@ -58,6 +58,7 @@ struct mpv_ctx {
     SigmaModel sg;
     DtsEngine* dts = nullptr;
     StgEngine* stg = nullptr;
+    StgEngine* nss = nullptr;          // NsDiff_spatial: the same engine type in mode 1 (stg.hip)
     NstEngine* nst = nullptr;
     double* reduce_ws = nullptr;   // partial sums of mpv_reduce
     unsigned long long* tile_counter = nullptr;   // work queue head of the split-f16 chain kernel (zeroed per launch)

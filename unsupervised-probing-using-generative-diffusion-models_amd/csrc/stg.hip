@@ -457,6 +457,102 @@ __global__ void stg_philox_kernel(unsigned seed_lo, unsigned seed_hi, unsigned s
     for (int e = 0; e < 4 && 4 * q + e < n; ++e) out[4 * q + e] = z[e];
 }
 
+// ---- NsDiff_spatial (NsDiff/ugnet.py:257-292, NsDiff/nsdiff_utils.py:111-158, 209-239, 271-284) ----------------------------------------
+// x_proj over cat(y_t, y_0_hat, g) on the feature axis: out [N][d_h][T] from three [N][T][F] tensors, w [d_h][3F]
+__global__ void nss_xproj_kernel(const float* __restrict__ y, const float* __restrict__ mu, const float* __restrict__ g, const float* __restrict__ w,
+                                 const float* __restrict__ b, int T, int F, int d_h, long long n, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // (node*d_h + c)*T + t
+    if (i >= n) return;
+    const int t = (int)(i % T);
+    const int c = (int)((i / T) % d_h);
+    const long long at = ((i / ((long long)T * d_h)) * T + t) * F;
+    float a = b[c];
+    for (int f = 0; f < F; ++f) a += w[c * 3 * F + f] * y[at + f];
+    for (int f = 0; f < F; ++f) a += w[c * 3 * F + F + f] * mu[at + f];
+    for (int f = 0; f < F; ++f) a += w[c * 3 * F + 2 * F + f] * g[at + f];
+    out[i] = a;
+}
+
+// the two heads over the d_h channels of a (row, time) position: eps = lin4(h), sigma = softplus(sigma_lin(softplus(h)))   (:291)
+__global__ void nss_heads_kernel(const float* __restrict__ h /*[N][d_h][T]*/, const float* __restrict__ w4, const float* __restrict__ b4,
+                                 const float* __restrict__ wsg, const float* __restrict__ bsg, int T, int F, int d_h, long long n /*N*T*/,
+                                 float* eps /*[N][T][F]*/, float* sig) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // node*T + t
+    if (i >= n) return;
+    const int t = (int)(i % T);
+    const long long node = i / T;
+    for (int f = 0; f < F; ++f) {
+        float a = b4[f], q = bsg[f];
+        for (int c = 0; c < d_h; ++c) {
+            const float v = h[(node * d_h + c) * T + t];
+            a += w4[f * d_h + c] * v;
+            q += wsg[f * d_h + c] * chain::softplus_dev(v);
+        }
+        eps[i * F + f] = a;
+        sig[i * F + f] = chain::softplus_dev(q);
+    }
+}
+
+// rows of one pass: R = w*(P*V) + r, r = v*P + p  (node-major tiling of NsDiff_model.py:756-763)  <-  src [W][V][O][F]
+__global__ void nss_tile_kernel(const float* __restrict__ src, int V, int P, long long OF, long long n, float* dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long R = i / OF, rem = i - R * OF;
+    const long long w = R / ((long long)P * V);
+    const int v = (int)((R - w * P * V) / P);
+    dst[i] = src[(w * V + v) * OF + rem];
+}
+
+// draw k of chunk c for the rows of one pass: injected (the reference's stream, [W][C][T][P*V][O][F]) or Philox keyed by the element's
+// position in [W][C][P*V][O][F] with the draw index as the stream
+__global__ void nss_noise_kernel(const float* __restrict__ inj, int C, int c, int Tn, int k, long long PV, long long OF, unsigned seed_lo, unsigned seed_hi,
+                                 long long n, float* z) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // (w*PV + r)*OF + rem
+    if (i >= n) return;
+    const long long per = PV * OF, w = i / per, rest = i - w * per;
+    if (inj) {
+        z[i] = inj[((w * C + c) * Tn + k) * per + rest];
+        return;
+    }
+    const unsigned long long id = (unsigned long long)((w * C + c) * per + rest);
+    float zz[4];
+    chain::philox_normals(id >> 2, (unsigned)k, seed_lo, seed_hi, 0x4E535300u, zz);
+    const unsigned e = (unsigned)(id & 3ull);
+    z[i] = e == 0u ? zz[0] : (e == 1u ? zz[1] : (e == 2u ? zz[2] : zz[3]));
+}
+
+// y_T = sqrt(g) z + mu   (p_sample_loop, nsdiff_utils.py:273-274)
+__global__ void nss_init_kernel(const float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ mu, long long n, float* y) {
+#pragma clang fp contract(off)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    y[i] = sqrtf(g[i]) * z[i] + mu[i];
+}
+
+// one reverse step on every element (p_sample / p_sample_t_1to0): the arithmetic of the pointwise sampler (chain_common.h::posterior)
+__global__ void nss_posterior_kernel(const float* __restrict__ coef_row, const float* __restrict__ mu, const float* __restrict__ g,
+                                     const float* __restrict__ eps, const float* __restrict__ sig, const float* __restrict__ z, int last, long long n,
+                                     float* y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    chain::StepCoef c;
+    float* cf = reinterpret_cast<float*>(&c);
+#pragma unroll
+    for (int j = 0; j < 18; ++j) cf[j] = coef_row[j];
+    y[i] = chain::posterior(c, y[i], mu[i], g[i], eps[i], sig[i], last ? 0.0f : z[i], last != 0);
+}
+
+// rows of one pass -> samples [W][V][O][F][S] at sample index c*P + p
+__global__ void nss_gather_kernel(const float* __restrict__ y, int V, int P, long long OF, int S, int c, long long n, float* samples) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long R = i / OF, rem = i - R * OF;
+    const long long w = R / ((long long)P * V);
+    const long long r = R - w * P * V;
+    const int v = (int)(r / P), pp = (int)(r - (long long)v * P);
+    samples[((w * V + v) * OF + rem) * S + (long long)c * P + pp] = y[i];
+}
+
 struct ResW {
     const float *w1, *b1, *ws1, *bs1, *wt, *bt, *w2, *b2, *lnw, *lnb, *wdown, *bdown, *wg, *bg4, *gbias, *wup, *bup, *ws, *bs;
 };
@@ -487,6 +583,13 @@ struct StgEngine {
     std::vector<float*> act;         // one output buffer per step (+ input projection at [0])
     float *hn = nullptr, *z = nullptr, *kqvs = nullptr, *sp = nullptr, *up = nullptr, *e1 = nullptr, *eps = nullptr, *xt = nullptr, *xm = nullptr,
           *noise = nullptr;
+    // mode 1 = NsDiff_spatial (NsDiff/ugnet.py:194-292): the same U-Net over cat(y_t, y0hat, g) at time length pred_len, a d_h-wide output head
+    // with an eps and a softplus sigma projection, stepped by the NsDiff posterior instead of DDIM
+    int mode = 0;
+    int T0 = 0;                      // time length at the top resolution: 2 (T_h + T_p) for DiffSTG, pred_len for NsDiff_spatial
+    int steps_T = 0;                 // NsDiff_spatial: diffusion steps (rows of coef)
+    const float *w4 = nullptr, *b4 = nullptr, *wsg = nullptr, *bsg = nullptr, *coef = nullptr;
+    float *sig = nullptr, *e2 = nullptr, *gg = nullptr;
 };
 
 void stg_engine_destroy(StgEngine* e) {
@@ -529,7 +632,7 @@ int gemm(mpv_ctx* ctx, const StgEngine& e, const float* X, long long ldx, const 
 
 int carve(mpv_ctx* ctx, StgEngine& e, long long N) {
     if (N <= e.cap_N) return MPV_OK;
-    const int T2 = 2 * (e.d.T_h + e.d.T_p), F = e.d.nf;
+    const int T2 = e.T0, F = e.d.nf, Ts = e.mode ? T2 : T2 / 2, Fo = e.mode ? e.d.d_h : F;      // Ts: length of the sampled sequence
     size_t total = 0;
     auto take = [&](size_t n) { const size_t at = total; total += (n + 3) & ~size_t(3); return at; };
     std::vector<size_t> o_act(e.steps.size() + 1);
@@ -544,8 +647,9 @@ int carve(mpv_ctx* ctx, StgEngine& e, long long N) {
     }
     const size_t C = (size_t)e.d.Td_h * max_c;
     const size_t o_hn = take((size_t)N * max_ct), o_z = take((size_t)N * C), o_kqvs = take((size_t)N * 4 * C), o_sp = take((size_t)N * C),
-                 o_up = take((size_t)N * max_ct), o_e1 = take((size_t)N * F * T2), o_eps = take((size_t)N * F * (T2 / 2)),
-                 o_xt = take((size_t)N * (T2 / 2) * F), o_xm = take((size_t)N * (T2 / 2) * F), o_nz = take((size_t)N * (T2 / 2) * F);
+                 o_up = take((size_t)N * max_ct), o_e1 = take((size_t)N * Fo * T2), o_eps = take((size_t)N * F * Ts),
+                 o_xt = take((size_t)N * Ts * F), o_xm = take((size_t)N * Ts * F), o_nz = take((size_t)N * Ts * F),
+                 o_sig = take(e.mode ? (size_t)N * Ts * F : 0), o_e2 = take(e.mode ? (size_t)N * Fo * T2 : 0), o_gg = take(e.mode ? (size_t)N * Ts * F : 0);
     if (e.ws) {
         MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(e.ws);
@@ -559,16 +663,15 @@ int carve(mpv_ctx* ctx, StgEngine& e, long long N) {
     for (size_t i = 0; i < o_act.size(); ++i) e.act[i] = e.ws + o_act[i];
     e.hn = e.ws + o_hn; e.z = e.ws + o_z; e.kqvs = e.ws + o_kqvs; e.sp = e.ws + o_sp; e.up = e.ws + o_up; e.e1 = e.ws + o_e1; e.eps = e.ws + o_eps;
     e.xt = e.ws + o_xt; e.xm = e.ws + o_xm; e.noise = e.ws + o_nz;
+    e.sig = e.ws + o_sig; e.e2 = e.ws + o_e2; e.gg = e.ws + o_gg;
     return MPV_OK;
 }
 
-// UGnet.forward (ugnet.py:252-295): xt, xm [N][T][F], timestep t -> e.eps [N][F][T]
-int forward(mpv_ctx* ctx, StgEngine& e, const float* xt, const float* xm, long long N, int t) {
-    const int T = e.d.T_h + e.d.T_p, T2 = 2 * T, F = e.d.nf, d_h = e.d.d_h, Td = e.d.Td_h;
+// The U-Net body shared by both modes (down path, middle, up path of UGnet.forward): e.act[0] [N][d_h][T0] -> *out_cur [N][d_h][T0]
+int unet(mpv_ctx* ctx, StgEngine& e, long long N, int t, const float** out_cur) {
+    const int d_h = e.d.d_h, Td = e.d.Td_h;
     hipStream_t st = ctx->stream;
     const float* temb = e.temb + (size_t)t * d_h;
-    hipLaunchKernelGGL(stg_xproj_kernel, g1d(N * d_h * T2), dim3(256), 0, st, xt, xm, e.wx, e.bx, T, F, d_h, N * d_h * T2, e.act[0]);
-    MPV_HIP_TRY(ctx, hipGetLastError());
     std::vector<std::pair<const float*, int>> skips;                    // (buffer, channels)
     skips.push_back({e.act[0], d_h});
     const float* cur = e.act[0];
@@ -654,30 +757,65 @@ int forward(mpv_ctx* ctx, StgEngine& e, const float* xt, const float* xm, long l
         cur_c = s.c_out;
         if (s.push) skips.push_back({out, s.c_out});
     }
+    *out_cur = cur;
+    return MPV_OK;
+}
+
+// UGnet.forward (DiffSTG/ugnet.py:252-295): xt, xm [N][T][F], timestep t -> e.eps [N][F][T]
+int forward(mpv_ctx* ctx, StgEngine& e, const float* xt, const float* xm, long long N, int t) {
+    const int T = e.d.T_h + e.d.T_p, T2 = 2 * T, F = e.d.nf, d_h = e.d.d_h;
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(stg_xproj_kernel, g1d(N * d_h * T2), dim3(256), 0, st, xt, xm, e.wx, e.bx, T, F, d_h, N * d_h * T2, e.act[0]);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    const float* cur = nullptr;
+    STG_TRY(unet(ctx, e, N, t, &cur));
     hipLaunchKernelGGL(stg_outconv_kernel, g1d(N * F * T2), dim3(256), 0, st, cur, e.wo, e.bo, T2, F, d_h, N * F * T2, e.e1);
     MPV_HIP_TRY(ctx, hipGetLastError());
     return gemm(ctx, e, e.e1, T2, e.wl, e.bl, T2, T, N * F, e.eps, T);
+}
+
+// NsDiff's UGnet.forward (NsDiff/ugnet.py:257-292): y, mu (= y_0_hat), g [N][T][F], timestep t -> e.eps, e.sig [N][T][F]
+int forward_nss(mpv_ctx* ctx, StgEngine& e, const float* y, const float* mu, const float* g, long long N, int t) {
+    const int T = e.T0, F = e.d.nf, d_h = e.d.d_h;
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(nss_xproj_kernel, g1d(N * d_h * T), dim3(256), 0, st, y, mu, g, e.wx, e.bx, T, F, d_h, N * d_h * T, e.act[0]);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    const float* cur = nullptr;
+    STG_TRY(unet(ctx, e, N, t, &cur));
+    hipLaunchKernelGGL(stg_outconv_kernel, g1d(N * d_h * T), dim3(256), 0, st, cur, e.wo, e.bo, T, d_h, d_h, N * d_h * T, e.e1);    // out.0: Conv2d(d_h, d_h, 1x1)
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    STG_TRY(gemm(ctx, e, e.e1, T, e.wl, e.bl, T, T, N * d_h, e.e2, T));                                                             // out.1: Linear(T, T) over time
+    hipLaunchKernelGGL(nss_heads_kernel, g1d(N * T), dim3(256), 0, st, e.e2, e.w4, e.b4, e.wsg, e.bsg, T, F, d_h, N * T, e.eps, e.sig);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
 }
 
 }  // namespace
 
 extern "C" {
 
-int mpv_stg_load(mpv_ctx* ctx, const mpv_stg_desc* d, const mpv_stg_step* steps, int32_t n_steps, const float* const* head /*6*/, const float* temb) {
-    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_stg_load: ctx is NULL");
-    if (!d || !steps || !head || !temb || n_steps < 1) return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_load: NULL argument");
-    const int T = d->T_h + d->T_p, F = d->nf, d_h = d->d_h, Td = d->Td_h;
-    if (T < 2 || (T & 1) || F < 1 || d_h < 2 || Td < 2 || (Td & 1) || d->timesteps < 1)
-        return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_load: need an even T_h + T_p, F >= 1, d_h >= 2, an even Td_h >= 2");
-    for (int i = 0; i < 6; ++i)
-        if (!head[i]) return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_load: NULL head tensor");
+}  // extern "C"
+
+namespace {
+
+// Shared loader of both modes.  head[] (host): mode 0 { x_proj.weight [d_h][F], x_proj.bias, out.0.weight [F][d_h], out.0.bias, out.1.weight
+// [T][2T], out.1.bias }; mode 1 { x_proj.weight [d_h][3F], x_proj.bias, out.0.weight [d_h][d_h], out.0.bias, out.1.weight [T][T], out.1.bias,
+// lin4.weight [F][d_h], lin4.bias, sigma_lin.weight [F][d_h], sigma_lin.bias, coef [steps][MPV_COEF_COLS] }.
+int load_engine(mpv_ctx* ctx, const std::string& who, int mode, const mpv_stg_desc* d, int T0, int steps_T, const mpv_stg_step* steps, int32_t n_steps,
+                const float* const* head, const float* temb, StgEngine** slot) {
+    const int T = d->T_h + d->T_p, F = d->nf, d_h = d->d_h, Td = d->Td_h, n_head = mode ? 11 : 6;
+    for (int i = 0; i < n_head; ++i)
+        if (!head[i]) return mpv_fail(ctx, MPV_EINVAL, who + ": NULL head tensor");
     DeviceGuard dg(ctx->device);
     MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    stg_engine_destroy(ctx->stg);
-    ctx->stg = nullptr;
+    stg_engine_destroy(*slot);
+    *slot = nullptr;
     StgEngine* e = new (std::nothrow) StgEngine();
-    if (!e) return mpv_fail(ctx, MPV_ENOMEM, "mpv_stg_load: out of host memory");
+    if (!e) return mpv_fail(ctx, MPV_ENOMEM, who + ": out of host memory");
     e->d = *d;
+    e->mode = mode;
+    e->T0 = T0;
+    e->steps_T = steps_T;
     std::vector<float> host;
     auto put = [&](const float* p, size_t n) { const size_t at = host.size(); host.insert(host.end(), p, p + n); host.resize((host.size() + 3) & ~size_t(3)); return at; };
     auto putv = [&](const std::vector<float>& v) { return put(v.data(), v.size()); };
@@ -687,12 +825,12 @@ int mpv_stg_load(mpv_ctx* ctx, const mpv_stg_desc* d, const mpv_stg_step* steps,
         const mpv_stg_step& s = steps[i];
         Step st;
         st.kind = s.kind; st.c_in = s.c_in; st.c_out = s.c_out; st.T = s.T; st.pop = s.pop; st.push = s.push;
-        if (s.c_in < 1 || s.c_out < 1 || s.T < 2 || ((s.c_out * s.T) & 3) || ((Td * s.c_out) & 3)) { delete e; return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_load: bad step shape"); }
+        if (s.c_in < 1 || s.c_out < 1 || s.T < 2 || ((s.c_out * s.T) & 3) || ((Td * s.c_out) & 3)) { delete e; return mpv_fail(ctx, MPV_EINVAL, who + ": bad step shape"); }
         std::vector<size_t>& o = offs[i];
         if (s.kind == 0) {
             const int ci = s.c_in, co = s.c_out, Ts = s.T, C = Td * co;
             for (int k : {0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21})
-                if (!s.w[k]) { delete e; return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_load: NULL tensor in a residual block"); }
+                if (!s.w[k]) { delete e; return mpv_fail(ctx, MPV_EINVAL, who + ": NULL tensor in a residual block"); }
             auto mid = [&](const float* w, int o_, int i_) {            // [o][i][3][3] -> middle row [o][i][3]
                 std::vector<float> m((size_t)o_ * i_ * 3);
                 for (int a = 0; a < o_ * i_; ++a)
@@ -736,18 +874,24 @@ int mpv_stg_load(mpv_ctx* ctx, const mpv_stg_desc* d, const mpv_stg_step* steps,
             o.push_back(putv(wu)); o.push_back(putv(bu));
             o.push_back(s.w[22] ? put(s.w[22], (size_t)co * ci) : (size_t)-1); o.push_back(s.w[23] ? put(s.w[23], co) : (size_t)-1);
         } else {
-            if (!s.w[0] || !s.w[1] || s.c_in != s.c_out) { delete e; return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_load: bad resampling step"); }
+            if (!s.w[0] || !s.w[1] || s.c_in != s.c_out) { delete e; return mpv_fail(ctx, MPV_EINVAL, who + ": bad resampling step"); }
             o.push_back(put(s.w[0], (size_t)s.c_out * s.c_out * (s.kind == 1 ? 3 : 4)));
             o.push_back(put(s.w[1], s.c_out));
         }
         e->steps.push_back(st);
     }
-    const size_t o_wx = put(head[0], (size_t)d_h * F), o_bx = put(head[1], d_h), o_wo = put(head[2], (size_t)F * d_h), o_bo = put(head[3], F),
-                 o_wl = put(head[4], (size_t)T * 2 * T), o_bl = put(head[5], T), o_temb = put(temb, (size_t)(d->timesteps + 1) * d_h);
-    if (hipMalloc(&e->blob, host.size() * sizeof(float)) != hipSuccess) { delete e; return mpv_fail(ctx, MPV_ENOMEM, "mpv_stg_load: weight blob"); }
+    const int Fi = mode ? 3 * F : F, Fo = mode ? d_h : F, Tk = mode ? T : 2 * T;
+    const size_t o_wx = put(head[0], (size_t)d_h * Fi), o_bx = put(head[1], d_h), o_wo = put(head[2], (size_t)Fo * d_h), o_bo = put(head[3], Fo),
+                 o_wl = put(head[4], (size_t)T * Tk), o_bl = put(head[5], T), o_temb = put(temb, (size_t)(d->timesteps + 1) * d_h);
+    size_t o_w4 = 0, o_b4 = 0, o_wsg = 0, o_bsg = 0, o_coef = 0;
+    if (mode) {
+        o_w4 = put(head[6], (size_t)F * d_h); o_b4 = put(head[7], F); o_wsg = put(head[8], (size_t)F * d_h); o_bsg = put(head[9], F);
+        o_coef = put(head[10], (size_t)steps_T * MPV_COEF_COLS);
+    }
+    if (hipMalloc(&e->blob, host.size() * sizeof(float)) != hipSuccess) { delete e; return mpv_fail(ctx, MPV_ENOMEM, who + ": weight blob"); }
     if (hipMemcpy(e->blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         stg_engine_destroy(e);
-        return mpv_fail(ctx, MPV_EHIP, "mpv_stg_load: upload failed");
+        return mpv_fail(ctx, MPV_EHIP, who + ": upload failed");
     }
     auto P = [&](size_t off) { return off == (size_t)-1 ? (const float*)nullptr : (const float*)(e->blob + off); };
     for (int i = 0; i < n_steps; ++i) {
@@ -762,6 +906,7 @@ int mpv_stg_load(mpv_ctx* ctx, const mpv_stg_desc* d, const mpv_stg_step* steps,
         }
     }
     e->wx = P(o_wx); e->bx = P(o_bx); e->wo = P(o_wo); e->bo = P(o_bo); e->wl = P(o_wl); e->bl = P(o_bl); e->temb = P(o_temb);
+    if (mode) { e->w4 = P(o_w4); e->b4 = P(o_b4); e->wsg = P(o_wsg); e->bsg = P(o_bsg); e->coef = P(o_coef); }
     // two-term f16 split (power-of-two scaled so the low term stays a normal f16) of the three big GEMM weights of every block
     {
         std::vector<_Float16> host16;
@@ -802,38 +947,70 @@ int mpv_stg_load(mpv_ctx* ctx, const mpv_stg_desc* d, const mpv_stg_step* steps,
             if (hipMalloc(&e->blob16, host16.size() * sizeof(_Float16)) != hipSuccess ||
                 hipMemcpy(e->blob16, host16.data(), host16.size() * sizeof(_Float16), hipMemcpyHostToDevice) != hipSuccess) {
                 stg_engine_destroy(e);
-                return mpv_fail(ctx, MPV_ENOMEM, "mpv_stg_load: f16 weight blob");
+                return mpv_fail(ctx, MPV_ENOMEM, who + ": f16 weight blob");
             }
             for (const Pending& pd : pend) e->split[pd.key] = SplitW{e->blob16 + pd.at, e->blob16 + pd.at + pd.n, pd.inv, pd.ldw};
         }
     }
-    ctx->stg = e;
+    *slot = e;
     return MPV_OK;
 }
 
-int mpv_stg_set_graph(mpv_ctx* ctx, int32_t n_nodes, int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst) {
-    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_stg_set_graph: ctx is NULL");
-    if (!ctx->stg) return mpv_fail(ctx, MPV_ESTATE, "mpv_stg_set_graph: call mpv_stg_load first");
-    if (n_nodes < 1 || n_edges < 0 || (n_edges > 0 && (!edge_src || !edge_dst))) return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_set_graph: bad argument");
+int set_graph(mpv_ctx* ctx, StgEngine& e, const char* who, int32_t n_nodes, int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst) {
+    if (n_nodes < 1 || n_edges < 0 || (n_edges > 0 && (!edge_src || !edge_dst))) return mpv_fail(ctx, MPV_EINVAL, std::string(who) + ": bad argument");
     std::vector<int> row_ptr(n_nodes + 1, 0), col(n_edges);
     for (int64_t k = 0; k < n_edges; ++k) {
-        if (edge_src[k] < 0 || edge_src[k] >= n_nodes || edge_dst[k] < 0 || edge_dst[k] >= n_nodes) return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_set_graph: node index out of range");
+        if (edge_src[k] < 0 || edge_src[k] >= n_nodes || edge_dst[k] < 0 || edge_dst[k] >= n_nodes) return mpv_fail(ctx, MPV_EINVAL, std::string(who) + ": node index out of range");
         ++row_ptr[edge_dst[k] + 1];
     }
     for (int v = 0; v < n_nodes; ++v) row_ptr[v + 1] += row_ptr[v];
     std::vector<int> fill(row_ptr.begin(), row_ptr.end() - 1);
     for (int64_t k = 0; k < n_edges; ++k) col[fill[edge_dst[k]]++] = (int)edge_src[k];        // edge order kept within a target: the sum order of index_add_
-    StgEngine& e = *ctx->stg;
     DeviceGuard dg(ctx->device);
     MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (e.graph) (void)hipFree(e.graph);
     e.graph = nullptr;
-    if (hipMalloc(&e.graph, sizeof(int) * (size_t)(n_nodes + 1 + std::max<int64_t>(n_edges, 1))) != hipSuccess) return mpv_fail(ctx, MPV_ENOMEM, "mpv_stg_set_graph");
+    if (hipMalloc(&e.graph, sizeof(int) * (size_t)(n_nodes + 1 + std::max<int64_t>(n_edges, 1))) != hipSuccess) return mpv_fail(ctx, MPV_ENOMEM, who);
     MPV_HIP_TRY(ctx, hipMemcpy(e.graph, row_ptr.data(), sizeof(int) * (n_nodes + 1), hipMemcpyHostToDevice));
     if (n_edges) MPV_HIP_TRY(ctx, hipMemcpy(e.graph + n_nodes + 1, col.data(), sizeof(int) * n_edges, hipMemcpyHostToDevice));
     e.V = n_nodes;
     e.E = (int)n_edges;
     return MPV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mpv_stg_load(mpv_ctx* ctx, const mpv_stg_desc* d, const mpv_stg_step* steps, int32_t n_steps, const float* const* head /*6*/, const float* temb) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_stg_load: ctx is NULL");
+    if (!d || !steps || !head || !temb || n_steps < 1) return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_load: NULL argument");
+    const int T = d->T_h + d->T_p;
+    if (T < 2 || (T & 1) || d->nf < 1 || d->d_h < 2 || d->Td_h < 2 || (d->Td_h & 1) || d->timesteps < 1)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_stg_load: need an even T_h + T_p, F >= 1, d_h >= 2, an even Td_h >= 2");
+    return load_engine(ctx, "mpv_stg_load", 0, d, 2 * T, 0, steps, n_steps, head, temb, &ctx->stg);
+}
+
+int mpv_nss_load(mpv_ctx* ctx, const mpv_nss_desc* d, const mpv_stg_step* steps, int32_t n_steps, const float* const* head /*11*/, const float* temb) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nss_load: ctx is NULL");
+    if (!d || !steps || !head || !temb || n_steps < 1) return mpv_fail(ctx, MPV_EINVAL, "mpv_nss_load: NULL argument");
+    if (d->pred_len < 4 || (d->pred_len & 3) || d->nf < 1 || d->d_h < 2 || d->Td_h < 2 || (d->Td_h & 1) || d->steps < 1)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nss_load: need pred_len a multiple of 4, F >= 1, d_h >= 2, an even Td_h >= 2, steps >= 1");
+    mpv_stg_desc sd{};
+    sd.T_h = 0; sd.T_p = d->pred_len; sd.nf = d->nf; sd.d_h = d->d_h; sd.Td_h = d->Td_h; sd.timesteps = d->steps - 1; sd.gemm = d->gemm;
+    return load_engine(ctx, "mpv_nss_load", 1, &sd, d->pred_len, d->steps, steps, n_steps, head, temb, &ctx->nss);
+}
+
+int mpv_stg_set_graph(mpv_ctx* ctx, int32_t n_nodes, int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_stg_set_graph: ctx is NULL");
+    if (!ctx->stg) return mpv_fail(ctx, MPV_ESTATE, "mpv_stg_set_graph: call mpv_stg_load first");
+    return set_graph(ctx, *ctx->stg, "mpv_stg_set_graph", n_nodes, n_edges, edge_src, edge_dst);
+}
+
+int mpv_nss_set_graph(mpv_ctx* ctx, int32_t n_nodes, int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nss_set_graph: ctx is NULL");
+    if (!ctx->nss) return mpv_fail(ctx, MPV_ESTATE, "mpv_nss_set_graph: call mpv_nss_load first");
+    return set_graph(ctx, *ctx->nss, "mpv_nss_set_graph", n_nodes, n_edges, edge_src, edge_dst);
 }
 
 int mpv_stg_forward(mpv_ctx* ctx, const float* xt, const float* x_masked, int64_t n_rows, int32_t t, float* eps_out) {
@@ -899,6 +1076,54 @@ int mpv_stg_sample(mpv_ctx* ctx, const mpv_stg_sample_shape* s, const float* his
             MPV_HIP_TRY(ctx, hipGetLastError());
         }
         hipLaunchKernelGGL(stg_gather_kernel, g1d(n), dim3(256), 0, st, e.xt, V, P, T, F, P * s->sequential, pass, n, samples);
+        MPV_HIP_TRY(ctx, hipGetLastError());
+    }
+    return MPV_OK;
+}
+
+int mpv_nss_forward(mpv_ctx* ctx, const float* y, const float* y0hat, const float* gx, int64_t n_rows, int32_t t, float* eps_out, float* sigma_out) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nss_forward: ctx is NULL");
+    if (!ctx->nss || !ctx->nss->graph) return mpv_fail(ctx, MPV_ESTATE, "mpv_nss_forward: call mpv_nss_load and mpv_nss_set_graph first");
+    StgEngine& e = *ctx->nss;
+    if (!y || !y0hat || !gx || !eps_out || !sigma_out || n_rows < 1 || n_rows % e.V != 0 || t < 0 || t >= e.steps_T)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nss_forward: need rows = a multiple of the graph's node count and 0 <= t < diffusion_steps");
+    DeviceGuard dg(ctx->device);
+    STG_TRY(carve(ctx, e, n_rows));
+    STG_TRY(forward_nss(ctx, e, y, y0hat, gx, n_rows, t));
+    const size_t bytes = sizeof(float) * (size_t)n_rows * e.T0 * e.d.nf;
+    MPV_HIP_TRY(ctx, hipMemcpyAsync(eps_out, e.eps, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    MPV_HIP_TRY(ctx, hipMemcpyAsync(sigma_out, e.sig, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return MPV_OK;
+}
+
+int mpv_nss_sample(mpv_ctx* ctx, const mpv_nss_sample_shape* s, const float* y0hat, const float* gx, const float* noise, float* samples) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nss_sample: ctx is NULL");
+    if (!ctx->nss || !ctx->nss->graph) return mpv_fail(ctx, MPV_ESTATE, "mpv_nss_sample: call mpv_nss_load and mpv_nss_set_graph first");
+    if (!s || !y0hat || !gx || !samples) return mpv_fail(ctx, MPV_EINVAL, "mpv_nss_sample: NULL argument");
+    StgEngine& e = *ctx->nss;
+    if (s->n_windows < 1 || s->nodes != e.V || s->chunk < 1 || s->n_samples < 1 || s->n_samples % s->chunk != 0)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nss_sample: need n_windows >= 1, nodes = the graph's node count, n_samples a positive multiple of chunk");
+    DeviceGuard dg(ctx->device);
+    const int O = e.T0, F = e.d.nf, P = s->chunk, V = e.V, C = s->n_samples / P, Tn = e.steps_T;
+    const long long PV = (long long)P * V, N = (long long)s->n_windows * PV, OF = (long long)O * F, n = N * OF;
+    STG_TRY(carve(ctx, e, N));
+    hipStream_t st = ctx->stream;
+    const unsigned seed_lo = (unsigned)s->seed, seed_hi = (unsigned)(s->seed >> 32);
+    float *mu = e.xm, *g = e.gg, *y = e.xt, *z = e.noise;
+    hipLaunchKernelGGL(nss_tile_kernel, g1d(n), dim3(256), 0, st, y0hat, V, P, OF, n, mu);
+    hipLaunchKernelGGL(nss_tile_kernel, g1d(n), dim3(256), 0, st, gx, V, P, OF, n, g);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    for (int c = 0; c < C; ++c) {                                                  // chunks of parallel_sample graph copies (NsDiff_model.py:755)
+        hipLaunchKernelGGL(nss_noise_kernel, g1d(n), dim3(256), 0, st, noise, C, c, Tn, 0, PV, OF, seed_lo, seed_hi, n, z);
+        hipLaunchKernelGGL(nss_init_kernel, g1d(n), dim3(256), 0, st, g, z, mu, n, y);
+        MPV_HIP_TRY(ctx, hipGetLastError());
+        for (int t = Tn - 1; t >= 0; --t) {                                        // p_sample for t = T-1 .. 1, p_sample_t_1to0 at t = 0
+            STG_TRY(forward_nss(ctx, e, y, mu, g, N, t));
+            if (t > 0) hipLaunchKernelGGL(nss_noise_kernel, g1d(n), dim3(256), 0, st, noise, C, c, Tn, Tn - t, PV, OF, seed_lo, seed_hi, n, z);   // drawn after the model call (:130)
+            hipLaunchKernelGGL(nss_posterior_kernel, g1d(n), dim3(256), 0, st, e.coef + (size_t)t * MPV_COEF_COLS, mu, g, e.eps, e.sig, z, t == 0 ? 1 : 0, n, y);
+            MPV_HIP_TRY(ctx, hipGetLastError());
+        }
+        hipLaunchKernelGGL(nss_gather_kernel, g1d(n), dim3(256), 0, st, y, V, P, OF, s->n_samples, c, n, samples);
         MPV_HIP_TRY(ctx, hipGetLastError());
     }
     return MPV_OK;

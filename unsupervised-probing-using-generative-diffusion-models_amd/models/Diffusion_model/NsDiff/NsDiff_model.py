@@ -28,7 +28,7 @@ import torch.nn as nn
 
 from . import g_backbone as G
 from . import mu_backbone as ns_Transformer
-from .NsDiff_net import NsDiff_net
+from .NsDiff_net import NsDiff_net, NsDiff_net_spatial
 from .native_handle import NativeHandle
 
 _F_BACKBONE_MSG = (
@@ -311,3 +311,110 @@ class NsDiff_model(_NsDiffBase):
         if y0hat is None and self.cond_pred_model is None:
             raise NotImplementedError(_F_BACKBONE_MSG.format(self.train_model_select))
         return self._evaluation_step(batch, y0hat, noise)
+
+
+_F_SPATIAL_MSG = (
+    "NsDiff_spatial's mean backbone f(x) is the reference's `Model_spatial` (NsDiff/mu_backbone.py:186-340: torch-timeseries encoder / decoder "
+    "layers interleaved with graph convolutions), which has no native implementation here.  Pass a precomputed y_0_hat [V, pred_len, F] "
+    "(`y0hat=`), or attach your own module with the reference's call signature `(batch_x, dec_inp, edge_index) -> (y_0_hat, _)` via "
+    "`attach_backbone(module)`.")
+
+
+class NsDiff_model_spatial(_NsDiffBase):
+    """NsDiff over a graph (reference NsDiff_model.py:497-790): g(x) by the sigma-head kernel, the graph U-Net eps / sigma network and the
+    NsDiff reverse loop by csrc/stg.hip (engine mode 1) behind mpv_nss_*; f(x) (`Model_spatial`) is an input (`y0hat=` / attach_backbone).
+
+    `evaluation_step(gdata)` takes the reference's graph batch (`.x` [V, >= windows, F], `.edge_index` [2, E], `.num_nodes`) and returns
+    (outs [V, pred_len, F, n_z_samples] on the CPU, batch_y | None).  Two reference behaviours are kept as they are: rows are tiled
+    node-major (row v*P + p, :756-763) while the duplicated edge index is copy-major (copy r // V, :783-790), and with parallel_sample = 1
+    the reference never defines the edge index it passes on (UnboundLocalError, :751-753) -- here that case uses the plain edge index."""
+
+    def __init__(self, net_param, train_model_select, pretrain_f_path="results/pre_model_F", pretrain_g_path="results/pre_model_G"):
+        super().__init__()
+        self._init_common(net_param)
+        self.train_model_select = train_model_select
+        self.load_pretrain = net_param.get("load_pretrain", False)
+        self.freeze_pretrain = net_param.get("freeze_pretrain", False)
+        self.cond_pred_model = None
+        if train_model_select == "NsDiff_model":
+            self.needs_backbone = True
+            self.model = NsDiff_net_spatial(self.configs, self.device)
+            self.cond_pred_model_g = G.SigmaEstimation(self.windows, self.pred_len, self.dataset_nf, 512, self.rolling_length, native=self._native)
+        elif train_model_select == "pretrain_g":
+            self.cond_pred_model_g = G.SigmaEstimation(self.windows, self.pred_len, self.dataset_nf, 512, self.rolling_length, native=self._native)
+        elif train_model_select == "pretrain_f":
+            raise NotImplementedError(_F_SPATIAL_MSG)
+        else:
+            raise ValueError("train_model_select should be in ['NsDiff_model', 'pretrain_f', 'pretrain_g']")
+
+    def scaler_fit(self, data):                                     # reference :588-593: statistics over nodes AND time
+        std = data.std(axis=(0, 1))
+        std[std == 0] = 1
+        self.scaler_mean = data.mean(axis=(0, 1))
+        self.scaler_std = std
+
+    def _upload_native(self, ctx):
+        if getattr(self, "model", None) is not None:
+            ctx.load_nss(self.model.diffussion_model, self.model.coef_rows, self.diffusion_steps, gemm=self.gemm_mode if self.gemm_mode in ("f16x3", "f32") else "f16x3")
+        g = getattr(self, "cond_pred_model_g", None)
+        if g is not None:
+            ctx.load_sigma(g.seq_len, g.kernel_size, g.pred_len, g.enc_in, g.hidden_size, g.native_weights())
+
+    @staticmethod
+    def duplicate_edge_index(parallel_sampling, edge_index, num_nodes, device):
+        """Reference :783-790 (kept for callers; the library stores ONE graph and offsets every copy)."""
+        edge_index = edge_index.reshape((2, 1, -1))
+        indent = torch.arange(0, parallel_sampling).view(1, -1, 1).to(device) * num_nodes
+        return (edge_index + indent).reshape((2, -1))
+
+    def _spatial_mean(self, batch_x, edge_index):
+        if self.cond_pred_model is None:
+            raise NotImplementedError(_F_SPATIAL_MSG)
+        dev = next(self.cond_pred_model.parameters(), torch.zeros(0, device=self.scaler_mean.device)).device
+        with torch.no_grad():
+            y0hat, _ = self.cond_pred_model(batch_x.to(dev), self._decoder_input(batch_x.to(dev)), edge_index.to(dev))
+        return y0hat
+
+    def sample_windows(self, history: torch.Tensor, edge_index: torch.Tensor, y0hat: torch.Tensor, *, noise: Optional[torch.Tensor] = None,
+                       seed: Optional[int] = None) -> torch.Tensor:
+        """history [W, V, windows, F] (scaled), the ONE graph's edge_index [2, E], y0hat [W, V, pred_len, F] -> samples
+        [W, V, pred_len, F, n_z_samples] on device: one sigma-head launch over all W*V rows, then every window's parallel_sample graph
+        copies side by side through the T-step loop, n_z_samples / parallel_sample passes."""
+        if getattr(self, "model", None) is None:
+            raise RuntimeError("train_model_select={!r} has no diffusion network to sample from".format(self.train_model_select))
+        S, P = self._check_sampling_config()
+        ctx = self._native.context()
+        hist = history.to(device=ctx.device, dtype=torch.float32).contiguous()
+        if hist.dim() != 4 or hist.shape[2] != self.windows or hist.shape[3] != self.dataset_nf:
+            raise ValueError("history must be [W, V, {}, {}], got {}".format(self.windows, self.dataset_nf, tuple(hist.shape)))
+        W, V = hist.shape[0], hist.shape[1]
+        gx = ctx.sigma_head(hist.reshape(W * V, self.windows, self.dataset_nf), 1, 0, 1)[0].reshape(W, V, self.pred_len, self.dataset_nf).contiguous()   # no EPS (:748)
+        y0 = y0hat.to(device=ctx.device, dtype=torch.float32).reshape(W, V, self.pred_len, self.dataset_nf).contiguous()
+        if noise is None and self.noise_source == "torch_cpu":
+            noise = self.host_noise(W, V)
+        if noise is not None:
+            noise = noise.to(device=ctx.device, dtype=torch.float32).contiguous()
+        elif seed is None:
+            seed = _draw_seed()
+        return ctx.nss_sample(y0, gx, edge_index, S, P, noise=noise, seed=seed or 0)
+
+    def evaluation_step(self, gdata, y0hat: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
+        batch = gdata.x
+        edge_index = torch.as_tensor(gdata.edge_index).reshape(2, -1)
+        if batch.dim() != 3 or batch.shape[1] < self.windows:
+            raise ValueError("gdata.x must be [V, >= windows ({}), F], got {}".format(self.windows, tuple(batch.shape)))
+        if int(gdata.num_nodes) != batch.shape[0]:
+            raise ValueError("gdata.num_nodes ({}) does not match gdata.x ({} rows)".format(gdata.num_nodes, batch.shape[0]))
+        batch_y = None
+        if batch.shape[1] - self.windows >= self.pred_len:
+            batch_y = batch[:, self.windows:, :].to(self.device)
+            assert batch_y.size(1) == self.pred_len, "pred_len is not equal to the length of the prediction"
+        x = batch[:, : self.windows, :]
+        if y0hat is None:
+            y0hat = self._spatial_mean(x, edge_index)
+        if noise is not None and noise.dim() != 6:
+            noise = noise.reshape(1, -1, self.diffusion_steps, x.shape[0] * int(self.configs.parallel_sample), self.pred_len, self.dataset_nf)
+        samples = self.sample_windows(x.unsqueeze(0), edge_index, y0hat.unsqueeze(0), noise=noise)
+        outs = samples[0].cpu()                                   # [V, O, F, S], the reference's `outs`
+        assert tuple(outs.shape[1:]) == (self.pred_len, self.dataset_nf, int(self.configs.n_z_samples))
+        return outs, batch_y

@@ -155,3 +155,30 @@ class NsDiff_net(nn.Module):
 
     def forward(self, *args, **kwargs):
         return self.diffussion_model(*args, **kwargs)
+
+
+class NsDiff_net_spatial(nn.Module):
+    """Schedule tables + graph U-Net container of NsDiff_spatial (reference NsDiff_net.py:175-260): the same tables and attribute names as
+    `NsDiff_net`, `diffussion_model` (sic) = NsDiff's UGnet, and the edge index the reference stores on the module (`set_edge_index`)."""
+
+    def __init__(self, configs, device):
+        super().__init__()
+        from .ugnet import UGnet
+        self.args = configs
+        self.device = device
+        self.num_timesteps = int(configs.diffusion_steps)
+        tb = nsdiff_tables(self.num_timesteps, configs.diffusion_schedule, configs.beta_start, configs.beta_end)
+        if not bool((tb["betas_tilde"] >= 0).all()) or not bool(((tb["betas_bar"] - tb["betas_tilde"]) >= 0).all()):
+            raise AssertionError("schedule violates betas_bar >= betas_tilde >= 0")      # NsDiff_net.py:209-211
+        self._tables = tb
+        for name, val in tb.items():
+            setattr(self, name, val)
+        self.coef_rows = posterior_coef_rows(tb)
+        self.diffussion_model = UGnet(configs)
+        self.edge_index = None
+
+    def set_edge_index(self, edge_index):
+        self.edge_index = edge_index
+
+    def forward(self, *args, **kwargs):
+        return self.diffussion_model(*args, **kwargs)

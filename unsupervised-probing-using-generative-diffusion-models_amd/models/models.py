@@ -19,8 +19,9 @@ def diffusion_models(task_model, net_param, **kwargs):
     if task_model == "DiffSTG":
         from .Diffusion_model.DiffSTG.graph_diffusion_model import DiffSTG
         return DiffSTG(net_param=net_param)
-    if task_model in ("NsDiff_spatial",):
-        raise NotImplementedError(
-            "task_model {!r} is a later row of the hot-path scope table (SURVEY.md section 8): the NsDiff "
-            "pointwise sampler is built first; this model family has no HIP path yet".format(task_model))
+    if task_model == "NsDiff_spatial":
+        from .Diffusion_model.NsDiff.NsDiff_model import NsDiff_model_spatial
+        return NsDiff_model_spatial(net_param=net_param, train_model_select=kwargs["train_model_select"],
+                                    pretrain_f_path=net_param.get("pretrain_f_path") or None,
+                                    pretrain_g_path=net_param.get("pretrain_g_path") or None)
     raise ValueError("the definition  don't exit\n\tyou can define it before using it")
