@@ -167,9 +167,8 @@ def test_factory_and_config_errors(ckpt_wofx):
     from mpv_amd.models.models import diffusion_models
     with pytest.raises(ValueError, match="don't exit"):
         diffusion_models("nope", {})
-    for later in ("NsDiff_spatial",):
-        with pytest.raises(NotImplementedError):
-            diffusion_models(later, {})
+    with pytest.raises(KeyError):                                                   # NsDiff_spatial is built (tests/test_nsdiff_spatial_oracle.py);
+        diffusion_models("NsDiff_spatial", {})                                      # like the reference it needs train_model_select
     dts = diffusion_models("DiffusionTS", dict(device="cpu", dataset_nf=1, windows=12, pred_len=8, d_model=16, n_layer_enc=1, n_layer_dec=1,
                                                n_heads=2, timesteps=20, diffusion_steps=5, n_z_samples=5, parallel_sample=2))
     with pytest.raises(ValueError, match="divisible by parallel_sample"):          # reference DiffusionTS_model.py:83-84
