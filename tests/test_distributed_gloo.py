@@ -231,3 +231,76 @@ def test_sample_axis_split_equals_unsplit(tmp_path, world, n_windows, keep):
         from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
         cache = H._load_tensor_list(tmp_path / ("s%d_cache.pt" % world))
         assert len(cache) == n_windows and tuple(cache[0].shape) == (3, 12, 1, 4)
+
+
+# ---- sample-axis split of the other families: dispatch and the whole-chunk rule -----------------------------------------------------------
+def _dts_split_worker(rank, world, port, out_dir):
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import GOLDEN
+    from mpv_amd import distributed as D
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+    from mpv_amd.models.models import diffusion_models
+    from oracle import diffusionts_oracle as O
+    try:
+        z = np.load(GOLDEN / "diffusionts_cases.npz")
+        keys = ("windows", "pred_len", "dataset_nf", "d_model", "n_layer_enc", "n_layer_dec", "n_heads", "timesteps", "diffusion_steps", "n_z_samples", "parallel_sample")
+        par = dict(zip(keys, [int(v) for v in z["cfg_small"]]))
+        par.update(n_z_samples=4, parallel_sample=2)
+        m = diffusion_models("DiffusionTS", dict(par, device="cpu", scaler_type="StandardScaler", noise_source="torch_cpu"))
+        pre = "sd_small_"
+        sd = {k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}
+        m.load_state_dict(sd, strict=True)
+        m.scaler_mean, m.scaler_std = torch.tensor([0.1, -0.2]), torch.tensor([1.5, 0.7])
+        sd = {k: v.detach() for k, v in m.state_dict().items()}
+        assert H._sample_axis(m) == (4, 2, True)
+        assert D.sample_split(1, 4, 2, whole_chunks_only=True) == (world == 2)
+        assert not D.sample_split(1, 4, 4, whole_chunks_only=True) or world == 1      # a DiffusionTS chunk is never cut
+
+        def chunk_run(model, windows, pred_len, scale, c_lo, c_hi):
+            """The oracle over the chunks [c_lo, c_hi) of every window, drawing the reference's whole stream (the device path's slicing)."""
+            V = int(windows[0].shape[0])
+            outs = []
+            for w in windows:
+                x = torch.as_tensor(w).float()
+                if scale:
+                    x = (x - sd["scaler_mean"]) / sd["scaler_std"]
+                zs = model.host_noise(1, V)[:, :, 0]                              # [C, draws, par*V, L, F]
+                it = iter([zs[c, k] for c in range(c_lo, c_hi) for k in range(zs.shape[1])])
+                cfg = O.DTSConfig(par["windows"], par["pred_len"], par["dataset_nf"], par["d_model"], par["n_layer_enc"], par["n_layer_dec"], par["n_heads"],
+                                  par["timesteps"], par["diffusion_steps"], n_z_samples=2 * (c_hi - c_lo), parallel_sample=2)
+                outs.append(O.evaluation_step(sd, cfg, x, lambda shape: next(it))[:, -pred_len:])
+            return torch.stack(outs)
+
+        def shard(model, windows, pred_len, scale, keep_samples=True, graph=None):
+            o = chunk_run(model, windows, pred_len, scale, 0, 2)
+            x = o.double() * sd["scaler_std"].double().view(1, 1, 1, -1, 1) + sd["scaler_mean"].double().view(1, 1, 1, -1, 1)
+            return o, x.var(dim=-1, unbiased=False).flatten(1).mean(dim=1).float(), x.mean(dim=-1).flatten(1).mean(dim=1).float()
+
+        H.SHARD_COMPUTE = shard
+        H.SAMPLE_SHARD_COMPUTE = lambda model, windows, pred_len, scale, s_lo, s_hi: chunk_run(model, windows, pred_len, scale, s_lo // 2, s_hi // 2)
+        g = torch.Generator().manual_seed(3)
+        windows = [torch.cumsum(torch.randn(2, par["windows"], 2, generator=g) * 0.1, dim=1)]
+        torch.manual_seed(5)
+        preds = H.run_evaluation_cache(m, windows, par["pred_len"], os.path.join(out_dir, "d%d_cache.pt" % world), "cpu", force_recompute=True)
+        torch.save({"ews": np.asarray(preds.ews, dtype=np.float64), "preds": list(preds)}, os.path.join(out_dir, "d%d_r%d.pt" % (world, rank)))
+        if world > 1:
+            dist.barrier()
+    finally:
+        H.SHARD_COMPUTE = H.SAMPLE_SHARD_COMPUTE = None
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_sample_axis_split_of_a_batched_history_family(tmp_path):
+    """DiffusionTS with one window on two ranks: each rank runs one whole chunk of the reference's stream; the merged curve and the gathered
+    cache equal the single-process run."""
+    _dts_split_worker(0, 1, 0, str(tmp_path))
+    mp.spawn(_dts_split_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    one = torch.load(tmp_path / "d1_r0.pt", weights_only=False)
+    for r in range(2):
+        got = torch.load(tmp_path / ("d2_r%d.pt" % r), weights_only=False)
+        np.testing.assert_allclose(got["ews"], one["ews"], rtol=2e-6)
+        assert len(got["preds"]) == 1 and tuple(got["preds"][0].shape) == tuple(one["preds"][0].shape)
+        torch.testing.assert_close(got["preds"][0], one["preds"][0], rtol=1e-5, atol=1e-6)

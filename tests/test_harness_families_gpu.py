@@ -97,3 +97,77 @@ def test_uncertainty_ews_diffusionts(tmp_path, monkeypatch):
         want.append(float((outs * sd["scaler_std"].view(1, 1, -1, 1) + sd["scaler_mean"].view(1, 1, -1, 1)).var(dim=-1, unbiased=False).mean()))
     print("DiffusionTS harness curve", res["ews"], want)
     np.testing.assert_allclose(np.array(res["ews"], dtype=np.float64), np.array(want), rtol=1e-4)
+
+
+# ---- sample-axis split (fewer windows than ranks) of the DiffusionTS / DiffSTG / TMDM families: the device side -------------------------
+def _union(H, model, windows, pred_len, S, world, graph=None):
+    parts = []
+    for r in range(world):
+        torch.manual_seed(31)
+        parts.append(H._native_sample_shard_other(model, windows, pred_len, True, r * (S // world), (r + 1) * (S // world), seed=0, graph=graph).cpu())
+    return torch.cat(parts, dim=-1)
+
+
+def test_sample_axis_shards_union_diffusionts():
+    """Rank r samples ALL windows with the chunks [r C/world, (r+1) C/world) of the reference's stream; side by side = the unsplit run."""
+    from conftest import GOLDEN
+    from mpv_amd.models.models import diffusion_models
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+    z = np.load(GOLDEN / "diffusionts_cases.npz")
+    keys = ("windows", "pred_len", "dataset_nf", "d_model", "n_layer_enc", "n_layer_dec", "n_heads", "timesteps", "diffusion_steps", "n_z_samples", "parallel_sample")
+    par = dict(zip(keys, [int(v) for v in z["cfg_small"]]))
+    par.update(n_z_samples=8, parallel_sample=2)                                 # 4 chunks of 2
+    m = diffusion_models("DiffusionTS", dict(par, device="cpu", scaler_type="StandardScaler", noise_source="torch_cpu"))
+    pre = "sd_small_"
+    m.load_state_dict({k[len(pre):]: T(z[k]) for k in z.files if k.startswith(pre)}, strict=True)
+    m.scaler_mean, m.scaler_std = torch.tensor([0.1, -0.2]), torch.tensor([1.5, 0.7])
+    m = m.to(dev()).eval()
+    g = torch.Generator().manual_seed(3)
+    windows = [torch.cumsum(torch.randn(3, par["windows"], 2, generator=g) * 0.1, dim=1) for _ in range(2)]
+    assert H._sample_axis(m) == (8, 2, True)
+    torch.manual_seed(31)
+    whole, _, _ = H._native_shard(m, windows, par["pred_len"], True)              # [2, 3, O, 2, 8]
+    for world in (2, 4):
+        got = _union(H, m, windows, par["pred_len"], 8, world)
+        assert tuple(got.shape) == tuple(whole.shape) and m.n_z_samples == 8
+        assert rel_err(got, whole.cpu()) < 1e-5
+
+
+def test_sample_axis_shards_union_diffstg():
+    from conftest import GOLDEN
+    from test_diffstg_oracle import case, state
+    from mpv_amd.models.models import diffusion_models
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+    z = np.load(GOLDEN / "diffstg_cases.npz")
+    net, V = case(z, "tiny")
+    net = dict(net, sequential_sampling=4, noise_source="torch_cpu")             # 4 passes of 2 copies
+    m = diffusion_models("DiffSTG", dict(net, device="cpu"))
+    m.load_state_dict(state(z, "tiny", net), strict=True)
+    m = m.to(dev()).eval()
+    graph = H._Graph(T(z["edge_tiny"]), V)
+    g = torch.Generator().manual_seed(4)
+    windows = [torch.randn(V, net["T_h"], 1, generator=g) * 0.7 for _ in range(2)]
+    assert H._sample_axis(m, graph) == (8, 2, True)
+    torch.manual_seed(31)
+    whole, _, _ = H._native_shard(m, windows, net["T_p"], True, graph=graph)
+    for world in (2, 4):
+        got = _union(H, m, windows, net["T_p"], 8, world, graph=graph)
+        assert tuple(got.shape) == tuple(whole.shape) and m.sequential_sampling == 4
+        assert rel_err(got, whole.cpu()) < 1e-5
+
+
+def test_sample_axis_shards_union_tmdm(golden_tmdm):
+    """TMDM samples pointwise: whole chunks (world 2) or a slice of one chunk's parallel_sample axis (world 4, 8)."""
+    from test_tmdm import _model
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+    m = _model(golden_tmdm, "f2t10", 2, 10, device="cuda:0", noise_source="torch_cpu", n_z_samples=8, parallel_sample=4)
+    net = dict(windows=m.windows, pred_len=m.pred_len, dataset_nf=2)
+    g = torch.Generator().manual_seed(5)
+    windows = [torch.cumsum(torch.randn(3, net["windows"], net["dataset_nf"], generator=g) * 0.1, dim=1) for _ in range(2)]
+    assert H._sample_axis(m) == (8, 4, False)
+    torch.manual_seed(31)
+    whole, _, _ = H._native_shard(m, windows, net["pred_len"], True)
+    for world in (2, 4, 8):
+        got = _union(H, m, windows, net["pred_len"], 8, world)
+        assert tuple(got.shape) == tuple(whole.shape) and (m.n_z_samples, m.parallel_sample) == (8, 4)
+        assert rel_err(got, whole.cpu()) < 1e-5

@@ -108,14 +108,16 @@ def barrier():
         dist.barrier()
 
 
-def sample_split(n_windows: int, n_samples: int, chunk: int) -> bool:
+def sample_split(n_windows: int, n_samples: int, chunk: int, whole_chunks_only: bool = False) -> bool:
     """True when the sample axis, not the window axis, should be sharded: fewer windows than ranks, and each rank's
-    n_samples / world samples are either whole `parallel_sample` chunks or a whole fraction of one chunk."""
+    n_samples / world samples are either whole `parallel_sample` chunks or (pointwise samplers only: not `whole_chunks_only`) a whole
+    fraction of one chunk.  The chunk of DiffusionTS (one batch with shared loss normalisers) and of DiffSTG (one sequential pass of
+    parallel graph copies) is not cut."""
     world = world_size()
     if not (active() and 0 < n_windows < world and n_samples % world == 0):
         return False
     per, chunk = n_samples // world, max(1, min(chunk, n_samples))
-    return per % chunk == 0 or chunk % per == 0
+    return per % chunk == 0 or (not whole_chunks_only and chunk % per == 0)
 
 
 def sample_bounds(n_samples: int) -> Tuple[int, int]:

@@ -441,19 +441,92 @@ def _native_sample_shard(model, windows, pred_len, scale, s_lo, s_hi, seed):
     return samples.reshape(len(windows), V, model.pred_len, model.dataset_nf, per)[:, :, -pred_len:].contiguous()
 
 
-def _sample_split(model, window_list, pred_len, scale, keep_samples):
+def _sample_axis(model, graph=None):
+    """(n_samples, chunk, whole_chunks_only) of a model family's sample axis: NsDiff and TMDM sample pointwise in chunks of
+    `parallel_sample` (a chunk may be cut); a DiffusionTS chunk is one batch with shared normalisers and a DiffSTG chunk one sequential pass
+    of `parallel_sampling` graph copies (whole chunks only)."""
+    if graph is not None:
+        return int(model.parallel_sampling) * int(model.sequential_sampling), int(model.parallel_sampling), True
+    if hasattr(model, "_prior_variance") and hasattr(model, "configs"):
+        return int(model.configs.n_z_samples), int(model.configs.parallel_sample), False
+    if hasattr(model, "_chunking"):
+        S, P = model._chunking()
+        return S, P, bool(getattr(model, "batched_history", False))
+    return None
+
+
+def _native_sample_shard_other(model, windows, pred_len, scale, s_lo, s_hi, seed, graph=None):
+    """Sample-axis shard of the DiffusionTS / DiffSTG / TMDM families: ALL windows, this rank's samples [s_lo, s_hi) -- whole chunks
+    (TMDM: also a slice of one chunk's parallel_sample axis).  torch_cpu noise: every rank draws the reference's full stream and keeps the
+    draws of its own chunks, so the union over ranks is the single-process result; Philox: the shared seed + the rank."""
+    S, P, _ = _sample_axis(model, graph)
+    per = s_hi - s_lo
+    V = int(windows[0].shape[0])
+    ctx = model.native_context()
+    torch_cpu = getattr(model, "noise_source", "philox") == "torch_cpu"
+    is_stg, is_dts = graph is not None, graph is None and getattr(model, "batched_history", False)
+    if is_stg or is_dts:
+        hist_len = model.T_h if is_stg else model.windows
+        hist = torch.stack([torch.as_tensor(w).float()[:, :hist_len, :] for w in windows]).to(ctx.device)          # [W, V, hist, F]
+        if scale:
+            hist = (hist - model.scaler_mean.to(ctx.device)) / model.scaler_std.to(ctx.device)
+        noise = model.host_noise(len(windows), V)[s_lo // P: s_hi // P].contiguous() if torch_cpu else None      # chunk axis first in both layouts
+        if is_stg:
+            keep = model.sequential_sampling
+            model.sequential_sampling = per // P
+            try:
+                samples = model.sample_windows(hist, graph.edge_index, noise=noise, seed=None if torch_cpu else seed + dist_utils.rank())
+            finally:
+                model.sequential_sampling = keep
+        else:
+            keep = model.n_z_samples
+            model.n_z_samples = per
+            try:
+                samples = model.sample_windows(hist, noise=noise, seed=None if torch_cpu else seed + dist_utils.rank())
+            finally:
+                model.n_z_samples = keep
+        return samples[:, :, -pred_len:].contiguous()
+    # TMDM: the prior over all rows once, then this rank's share of the chains
+    rows = _stack_windows(windows).to(ctx.device)
+    if scale:
+        rows = model.scaler_transform(rows)
+    if getattr(model, "cond_pred_model", None) is None:
+        raise NotImplementedError("TMDM without a prior network: assign one to `cond_pred_model`")
+    with torch.no_grad():
+        _, y0, _, _ = model.cond_pred_model(rows, None, model._decoder_input(rows), None)
+    prior = y0[:, -model.pred_len:, :].reshape(len(windows), V, model.pred_len, model.dataset_nf)
+    noise, p_loc = None, (P if per % P == 0 else per)
+    if torch_cpu:
+        z = model.host_noise(len(windows), V)                                 # [W, C, T, V*P, O, F]
+        W_, C_, T_, _, O_, F_ = z.shape
+        z = z.reshape(W_, C_, T_, V, P, O_, F_)
+        z = z[:, s_lo // P: s_hi // P] if per % P == 0 else z[:, s_lo // P: s_lo // P + 1, :, :, s_lo % P: s_lo % P + per]
+        noise = z.reshape(W_, z.shape[1], T_, V * p_loc, O_, F_).contiguous()
+    keep = (model.n_z_samples, model.parallel_sample)
+    model.n_z_samples, model.parallel_sample = per, p_loc
+    try:
+        samples = model.sample_windows(prior, noise=noise, seed=None if torch_cpu else seed + dist_utils.rank())
+    finally:
+        model.n_z_samples, model.parallel_sample = keep
+    return samples[:, :, -pred_len:].contiguous()
+
+
+def _sample_split(model, window_list, pred_len, scale, keep_samples, graph=None):
     """More ranks than windows: shard the SAMPLE axis.  Every rank samples all windows with n_z_samples / world samples; per-row
     (mean, M2) of the inverse-scaled samples are merged with `distributed.merge_row_moments` (one all-gather, Chan's update in rank
     order: every rank gets the same curve), and when the caller keeps the samples they are all-gathered along the sample axis."""
-    S = int(model.configs.n_z_samples)
+    S = _sample_axis(model, graph)[0]
     s_lo, s_hi = dist_utils.sample_bounds(S)
     seed = 0
     if getattr(model, "noise_source", "philox") != "torch_cpu":              # (torch_cpu: the shared CPU stream must stay untouched)
         seed = dist_utils.broadcast_int(int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()))
+    stacked = graph is None and hasattr(model, "_prior_variance") and hasattr(model, "configs")
     if SAMPLE_SHARD_COMPUTE is not None:
         local = SAMPLE_SHARD_COMPUTE(model, list(window_list), pred_len, scale, s_lo, s_hi)
-    else:
+    elif stacked:
         local = _native_sample_shard(model, list(window_list), pred_len, scale, s_lo, s_hi, seed)
+    else:
+        local = _native_sample_shard_other(model, list(window_list), pred_len, scale, s_lo, s_hi, seed, graph=graph)
     x = local.double()
     if _uses_scaler(model):                                                   # summarize_pred_future_list inverse-scales first (:286-303)
         x = x * model.scaler_std.to(x.device).double().view(1, 1, 1, -1, 1) + model.scaler_mean.to(x.device).double().view(1, 1, 1, -1, 1)
@@ -504,9 +577,9 @@ def _sample_stacked(model, window_list, pred_len, scale: bool, keep_samples: boo
     n = len(window_list)
     if n == 0:
         return [], np.zeros(0, np.float32), np.zeros(0, np.float32)
-    if graph is None and hasattr(model, "_prior_variance") and hasattr(model, "configs") and dist_utils.sample_split(
-            n, int(model.configs.n_z_samples), int(model.configs.parallel_sample)):
-        return _sample_split(model, window_list, pred_len, scale, keep_samples)
+    axis = _sample_axis(model, graph) if dist_utils.active() else None
+    if axis is not None and dist_utils.sample_split(n, axis[0], axis[1], whole_chunks_only=axis[2]):
+        return _sample_split(model, window_list, pred_len, scale, keep_samples or getattr(model, "batched_history", False), graph=graph)
     lo, hi = dist_utils.shard_bounds(n)
     V = int(window_list[0].shape[0])
     compute = SHARD_COMPUTE or _native_shard
