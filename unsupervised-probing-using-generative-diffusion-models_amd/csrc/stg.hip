@@ -20,6 +20,7 @@
 
 #include "chain_common.h"
 #include "nst_gemm.h"
+#include "stg_tcn_mfma.h"
 
 namespace {
 
@@ -556,11 +557,47 @@ __global__ void nss_gather_kernel(const float* __restrict__ y, int V, int P, lon
 struct ResW {
     const float *w1, *b1, *ws1, *bs1, *wt, *bt, *w2, *b2, *lnw, *lnb, *wdown, *bdown, *wg, *bg4, *gbias, *wup, *bup, *ws, *bs;
 };
+struct TcnFrag {                                     // matrix-pipe TCN (stg_tcn_mfma.h): A fragments and scales of one residual block
+    const th8 *a1 = nullptr, *a2 = nullptr, *asb = nullptr;
+    float inv1 = 1.0f, inv2 = 1.0f, invsb = 1.0f;
+    const float* b1s = nullptr;                      // tcn1.conv.bias + tcn1.shortcut.bias
+    int cip1 = 0, cip2 = 0, nc1 = 0, nc2 = 0;
+    bool ok = false;
+};
 struct Step {
     int kind = 0, c_in = 0, c_out = 0, T = 0, pop = 0, push = 0;
     ResW r{};
     const float *cw = nullptr, *cb = nullptr;        // down / up sample conv
+    TcnFrag f{};
 };
+
+// A fragments of D[co][t] = sum_k A[co][k] B[k][t] for v_mfma_f32_16x16x32_f16: lane l holds A[row l & 15][k = 32 chunk + 8 (l >> 4) + j], j = 0..7,
+// with k = tap * cip + channel (taps = 3: the causal convolution; taps = 1: a 1x1 convolution).  w: [co][ci][taps] fp32.  Appends
+// [chunks][hi, lo][64 lanes][8] halves of w * 2^s to `dst` and returns 2^-s.
+inline float tcn_fragments(const std::vector<float>& w, int co, int ci, int cip, int taps, int chunks, std::vector<_Float16>& dst) {
+    float mx = 0.0f;
+    for (float v : w) mx = std::max(mx, std::fabs(v));
+    int ex = 0;
+    if (mx > 0.0f && std::isfinite(mx)) { (void)std::frexp(mx, &ex); ex = 14 - ex; }
+    const float sc = std::ldexp(1.0f, ex);
+    const size_t at = dst.size();
+    dst.resize(at + (size_t)chunks * 2 * 64 * 8, (_Float16)0.0f);
+    for (int c = 0; c < chunks; ++c)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int row = lane & 15, k = 32 * c + 8 * (lane >> 4) + j, tap = k / cip, ch = k - tap * cip;
+                if (row >= co || tap >= taps || ch >= ci) continue;
+                const float v = w[((size_t)row * ci + ch) * taps + tap] * sc;
+                uint32_t bits;
+                std::memcpy(&bits, &v, 4);
+                bits &= 0xFFFFE000u;
+                float hi;
+                std::memcpy(&hi, &bits, 4);
+                dst[at + ((size_t)(c * 2 + 0) * 64 + lane) * 8 + j] = (_Float16)hi;
+                dst[at + ((size_t)(c * 2 + 1) * 64 + lane) * 8 + j] = (_Float16)(v - hi);
+            }
+    return std::ldexp(1.0f, -ex);
+}
 
 inline dim3 g1d(long long n) { return dim3((unsigned)((n + 255) / 256)); }
 
@@ -571,6 +608,7 @@ struct SplitW { const _Float16* h; const _Float16* l; float inv_scale; int ldw; 
 struct StgEngine {
     mpv_stg_desc d{};
     _Float16* blob16 = nullptr;
+    _Float16* frag16 = nullptr;                         // A fragments of the matrix-pipe TCN blocks
     std::unordered_map<const float*, SplitW> split;     // fp32 weight pointer -> its split copy
     std::vector<Step> steps;
     float* blob = nullptr;
@@ -596,6 +634,7 @@ void stg_engine_destroy(StgEngine* e) {
     if (!e) return;
     if (e->blob) (void)hipFree(e->blob);
     if (e->blob16) (void)hipFree(e->blob16);
+    if (e->frag16) (void)hipFree(e->frag16);
     if (e->ws) (void)hipFree(e->ws);
     if (e->graph) (void)hipFree(e->graph);
     delete e;
@@ -712,37 +751,80 @@ int unet(mpv_ctx* ctx, StgEngine& e, long long N, int t, const float** out_cur) 
             }
             if (cur_c + c2 != s.c_in) return mpv_fail(ctx, MPV_ESTATE, "DiffSTG: block input channels do not match the layout");
             const int co = s.c_out, C = Td * co;
-            TcnArgs a{cur, cur_c, src2, c2, s.r.w1, s.r.b1, s.r.ws1, s.r.bs1, s.r.wt, s.r.bt, temb, s.r.w2, s.r.b2, s.r.lnw, s.r.lnb, e.hn, co, s.T, d_h,
-                      s.r.ws, s.r.bs, e.up, N, 0, 1};
-            // segments of the time axis (256 steps keep every thread busy in one pass) until at least two workgroups fit a CU
-            static const int seg_env = getenv("MPV_STG_TCN_SEG") ? atoi(getenv("MPV_STG_TCN_SEG")) : 0;
-            auto lds_of = [&](int tseg) { return sizeof(float) * ((size_t)s.c_in * (tseg + 4) + (size_t)co * (tseg + 2) + (size_t)s.c_in * co * 5 + (size_t)co * co * 4 + co); };
-            a.nseg = seg_env > 0 ? seg_env : 1;
-            a.tseg = (s.T + a.nseg - 1) / a.nseg;
-            while (seg_env == 0 && a.tseg > 64 && (lds_of(a.tseg) > ctx->max_lds / 2 || a.tseg > 256)) {
-                ++a.nseg;
+            static const bool tcn_valu = getenv("MPV_STG_TCN_VALU") != nullptr;      // the round-2 vector kernel, kept for A/B measurements
+            if (s.f.ok && !tcn_valu) {
+                // front half of the block on the f16 matrix pipe (stg_tcn_mfma.h): time segments sized so that four workgroups share a CU
+                const TcnFrag& f = s.f;
+                auto lds_of = [&](int tseg) {
+                    const size_t nt1 = (size_t)(tseg + 2 + 15) / 16;
+                    return 2 * sizeof(_Float16) * ((16 * nt1 + 2) * (size_t)(f.cip1 + 8) + (16 * nt1 + 16) * (size_t)(f.cip2 + 8)) + 64;
+                };
+                static const int seg_env = getenv("MPV_STG_TCN_SEG") ? atoi(getenv("MPV_STG_TCN_SEG")) : 0;
+                int tseg = (s.T + 15) & ~15;
+                if (seg_env > 0) tseg = std::max(16, (seg_env + 15) & ~15);
+                else
+                    while (tseg > 64 && lds_of(tseg) > ctx->max_lds / 4) tseg -= 16;
+                const int nseg = (s.T + tseg - 1) / tseg;
+                const size_t lds = lds_of(tseg);
+                if (lds > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "DiffSTG: a time segment does not fit the LDS");
+                TcnMArgs a{cur, cur_c, src2, c2, f.a1, f.a2, f.asb, f.inv1, f.inv2, f.invsb, f.b1s, s.r.wt, s.r.bt, temb, s.r.b2, s.r.lnw, s.r.lnb, s.r.bs,
+                           e.hn, e.up, co, s.T, d_h, f.cip1, f.cip2, N, tseg, nseg};
+                const long long per_cu = std::max<long long>(1, std::min<long long>(8, (long long)ctx->max_lds / (long long)lds));
+                const unsigned grid = (unsigned)std::min<long long>(N * nseg, per_cu * ctx->cu_count);
+#define STG_TCNM(N1_, N2_)                                                                                                                      \
+    do {                                                                                                                                      \
+        if (f.asb) {                                                                                                                          \
+            MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(stg_tcn_mfma_kernel<N1_, N2_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((stg_tcn_mfma_kernel<N1_, N2_, true>), dim3(grid), dim3(256), lds, st, a);                                     \
+        } else {                                                                                                                              \
+            MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(stg_tcn_mfma_kernel<N1_, N2_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((stg_tcn_mfma_kernel<N1_, N2_, false>), dim3(grid), dim3(256), lds, st, a);                                    \
+        }                                                                                                                                     \
+    } while (0)
+                switch (f.nc1 * 10 + f.nc2) {
+                    case 11: STG_TCNM(1, 1); break;
+                    case 12: STG_TCNM(1, 2); break;
+                    case 21: STG_TCNM(2, 1); break;
+                    case 22: STG_TCNM(2, 2); break;
+                    case 31: STG_TCNM(3, 1); break;
+                    case 32: STG_TCNM(3, 2); break;
+                    default: return mpv_fail(ctx, MPV_ESTATE, "DiffSTG: unexpected TCN chunk counts");
+                }
+#undef STG_TCNM
+                MPV_HIP_TRY(ctx, hipGetLastError());
+            } else {
+                TcnArgs a{cur, cur_c, src2, c2, s.r.w1, s.r.b1, s.r.ws1, s.r.bs1, s.r.wt, s.r.bt, temb, s.r.w2, s.r.b2, s.r.lnw, s.r.lnb, e.hn, co, s.T, d_h,
+                          s.r.ws, s.r.bs, e.up, N, 0, 1};
+                // segments of the time axis (256 steps keep every thread busy in one pass) until at least two workgroups fit a CU
+                static const int seg_env = getenv("MPV_STG_TCN_SEG") ? atoi(getenv("MPV_STG_TCN_SEG")) : 0;
+                auto lds_of = [&](int tseg) { return sizeof(float) * ((size_t)s.c_in * (tseg + 4) + (size_t)co * (tseg + 2) + (size_t)s.c_in * co * 5 + (size_t)co * co * 4 + co); };
+                a.nseg = seg_env > 0 ? seg_env : 1;
                 a.tseg = (s.T + a.nseg - 1) / a.nseg;
-            }
-            const size_t lds = lds_of(a.tseg);
-            // a workgroup stages the weights once and walks over its items: as many workgroups as fit the chip at this LDS footprint
-            const long long per_cu = std::max<long long>(1, std::min<long long>(4, (long long)ctx->max_lds / (long long)lds));
-            const unsigned tcn_grid = (unsigned)std::min<long long>(N * a.nseg, per_cu * ctx->cu_count);
-            if (lds > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "DiffSTG: a node row does not fit the LDS (sequence too long)");
+                while (seg_env == 0 && a.tseg > 64 && (lds_of(a.tseg) > ctx->max_lds / 2 || a.tseg > 256)) {
+                    ++a.nseg;
+                    a.tseg = (s.T + a.nseg - 1) / a.nseg;
+                }
+                const size_t lds = lds_of(a.tseg);
+                // a workgroup stages the weights once and walks over its items: as many workgroups as fit the chip at this LDS footprint
+                const long long per_cu = std::max<long long>(1, std::min<long long>(4, (long long)ctx->max_lds / (long long)lds));
+                const unsigned tcn_grid = (unsigned)std::min<long long>(N * a.nseg, per_cu * ctx->cu_count);
+                if (lds > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "DiffSTG: a node row does not fit the LDS (sequence too long)");
 #define STG_TCN(CO_)                                                                                                                          \
     do {                                                                                                                                      \
         MPV_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(stg_tcn_ln_kernel<CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(stg_tcn_ln_kernel<CO_>, dim3(tcn_grid), dim3(256), lds, st, a);                                                 \
     } while (0)
-            switch (co) {
-                case 2: STG_TCN(2); break;
-                case 4: STG_TCN(4); break;
-                case 8: STG_TCN(8); break;
-                case 16: STG_TCN(16); break;
-                case 32: STG_TCN(32); break;
-                default: return mpv_fail(ctx, MPV_EINVAL, "DiffSTG: block channel counts must be 2, 4, 8, 16 or 32 (d_h times the channel multipliers)");
-            }
+                switch (co) {
+                    case 2: STG_TCN(2); break;
+                    case 4: STG_TCN(4); break;
+                    case 8: STG_TCN(8); break;
+                    case 16: STG_TCN(16); break;
+                    case 32: STG_TCN(32); break;
+                    default: return mpv_fail(ctx, MPV_EINVAL, "DiffSTG: block channel counts must be 2, 4, 8, 16 or 32 (d_h times the channel multipliers)");
+                }
 #undef STG_TCN
-            MPV_HIP_TRY(ctx, hipGetLastError());
+                MPV_HIP_TRY(ctx, hipGetLastError());
+            }
             STG_TRY(gemm(ctx, e, e.hn, (long long)co * s.T, s.r.wdown, s.r.bdown, co * s.T, C, N, e.z, C));
             STG_TRY(gemm(ctx, e, e.z, C, s.r.wg, s.r.bg4, C, 4 * C, N, e.kqvs, 4 * C));
             hipLaunchKernelGGL(stg_gate_kernel, g1d(N * C), dim3(256), 0, st, e.kqvs, s.r.gbias, e.graph, e.graph + e.V + 1, e.V, C, N * C, e.sp);
@@ -820,6 +902,9 @@ int load_engine(mpv_ctx* ctx, const std::string& who, int mode, const mpv_stg_de
     auto put = [&](const float* p, size_t n) { const size_t at = host.size(); host.insert(host.end(), p, p + n); host.resize((host.size() + 3) & ~size_t(3)); return at; };
     auto putv = [&](const std::vector<float>& v) { return put(v.data(), v.size()); };
     std::vector<std::vector<size_t>> offs(n_steps);
+    std::vector<_Float16> frag_host;                                  // matrix-pipe TCN fragments of every residual block
+    struct FragOff { size_t a1 = 0, a2 = 0, asb = 0, b1s = 0; bool sb = false; };
+    std::vector<FragOff> frag_off(n_steps);
     const int pad = Td / 2;
     for (int i = 0; i < n_steps; ++i) {
         const mpv_stg_step& s = steps[i];
@@ -838,6 +923,30 @@ int load_engine(mpv_ctx* ctx, const std::string& who, int mode, const mpv_stg_de
                 return m;
             };
             o.push_back(putv(mid(s.w[0], co, ci))); o.push_back(put(s.w[1], co));
+            if (ci <= 32 && co <= 16) {                              // the block's front half on the f16 matrix pipe (stg_tcn_mfma.h)
+                TcnFrag& f = st.f;
+                f.cip1 = (ci + 7) & ~7; f.cip2 = (co + 7) & ~7;
+                f.nc1 = (3 * f.cip1 + 31) / 32; f.nc2 = (3 * f.cip2 + 31) / 32;
+                std::vector<float> w1 = mid(s.w[0], co, ci), w2 = mid(s.w[6], co, co), b1s(s.w[1], s.w[1] + co);
+                for (int oc = 0; oc < co; ++oc) {
+                    for (int ic = 0; ic < ci; ++ic)                  // tcn1's 1x1 skip (or the identity) rides in the current-time tap
+                        w1[((size_t)oc * ci + ic) * 3 + 2] += s.w[2] ? s.w[2][(size_t)oc * ci + ic] : (oc == ic ? 1.0f : 0.0f);
+                    w2[((size_t)oc * co + oc) * 3 + 2] += 1.0f;      // tcn2's skip is the identity (c_in == c_out)
+                    if (s.w[3]) b1s[oc] += s.w[3][oc];
+                }
+                FragOff& fo = frag_off[i];
+                fo.a1 = frag_host.size();
+                f.inv1 = tcn_fragments(w1, co, ci, f.cip1, 3, f.nc1, frag_host);
+                fo.a2 = frag_host.size();
+                f.inv2 = tcn_fragments(w2, co, co, f.cip2, 3, f.nc2, frag_host);
+                if (s.w[22]) {
+                    fo.sb = true;
+                    fo.asb = frag_host.size();
+                    f.invsb = tcn_fragments(std::vector<float>(s.w[22], s.w[22] + (size_t)co * ci), co, ci, f.cip1, 1, 1, frag_host);
+                }
+                fo.b1s = putv(b1s);
+                f.ok = (s.w[2] != nullptr) || ci == co;             // (an identity skip needs c_in == c_out, as in the reference)
+            }
             o.push_back(s.w[2] ? put(s.w[2], (size_t)co * ci) : (size_t)-1); o.push_back(s.w[3] ? put(s.w[3], co) : (size_t)-1);
             o.push_back(put(s.w[4], (size_t)co * d_h)); o.push_back(put(s.w[5], co));
             o.push_back(putv(mid(s.w[6], co, co))); o.push_back(put(s.w[7], co));
@@ -903,6 +1012,21 @@ int load_engine(mpv_ctx* ctx, const std::string& who, int mode, const mpv_stg_de
         } else {
             st.cw = P(o[0]);
             st.cb = P(o[1]);
+        }
+    }
+    if (!frag_host.empty()) {
+        if (hipMalloc(&e->frag16, frag_host.size() * sizeof(_Float16)) != hipSuccess ||
+            hipMemcpy(e->frag16, frag_host.data(), frag_host.size() * sizeof(_Float16), hipMemcpyHostToDevice) != hipSuccess) {
+            stg_engine_destroy(e);
+            return mpv_fail(ctx, MPV_ENOMEM, who + ": TCN fragment blob");
+        }
+        for (int i = 0; i < n_steps; ++i) {
+            TcnFrag& f = e->steps[i].f;
+            if (!f.ok) continue;
+            f.a1 = reinterpret_cast<const th8*>(e->frag16 + frag_off[i].a1);
+            f.a2 = reinterpret_cast<const th8*>(e->frag16 + frag_off[i].a2);
+            f.asb = frag_off[i].sb ? reinterpret_cast<const th8*>(e->frag16 + frag_off[i].asb) : nullptr;
+            f.b1s = P(frag_off[i].b1s);
         }
     }
     e->wx = P(o_wx); e->bx = P(o_bx); e->wo = P(o_wo); e->bo = P(o_bo); e->wl = P(o_wl); e->bl = P(o_bl); e->temb = P(o_temb);
