@@ -760,11 +760,17 @@ int unet(mpv_ctx* ctx, StgEngine& e, long long N, int t, const float** out_cur) 
                     return 2 * sizeof(_Float16) * ((16 * nt1 + 2) * (size_t)(f.cip1 + 8) + (16 * nt1 + 16) * (size_t)(f.cip2 + 8)) + 64;
                 };
                 static const int seg_env = getenv("MPV_STG_TCN_SEG") ? atoi(getenv("MPV_STG_TCN_SEG")) : 0;
-                int tseg = (s.T + 15) & ~15;
-                if (seg_env > 0) tseg = std::max(16, (seg_env + 15) & ~15);
-                else
-                    while (tseg > 64 && lds_of(tseg) > ctx->max_lds / 4) tseg -= 16;
-                const int nseg = (s.T + tseg - 1) / tseg;
+                // as few, equally long segments (multiples of 16 steps) as keep `wg_target` workgroups on a CU: the kernel has no software
+                // pipeline of its own -- other workgroups' MFMA phases cover a workgroup's loads (measured: register prefetch of the next
+                // segment, +60 VGPRs and two workgroups per CU, and 16-byte loads with a register transpose were both slower)
+                static const int wg_target = getenv("MPV_STG_TCN_WGS") ? std::max(1, atoi(getenv("MPV_STG_TCN_WGS"))) : 4;
+                int nseg = seg_env > 0 ? seg_env : 1;
+                int tseg = ((s.T + nseg - 1) / nseg + 15) & ~15;
+                while (seg_env <= 0 && tseg > 16 && lds_of(tseg) > ctx->max_lds / wg_target) {
+                    ++nseg;
+                    tseg = ((s.T + nseg - 1) / nseg + 15) & ~15;
+                }
+                nseg = (s.T + tseg - 1) / tseg;
                 const size_t lds = lds_of(tseg);
                 if (lds > ctx->max_lds) return mpv_fail(ctx, MPV_EINVAL, "DiffSTG: a time segment does not fit the LDS");
                 TcnMArgs a{cur, cur_c, src2, c2, f.a1, f.a2, f.asb, f.inv1, f.inv2, f.invsb, f.b1s, s.r.wt, s.r.bt, temb, s.r.b2, s.r.lnw, s.r.lnb, s.r.bs,

@@ -55,6 +55,10 @@ __device__ __forceinline__ void tcn_split4(const float (&v)[4], th4& hi, th4& lo
     lo = th4{(_Float16)l01[0], (_Float16)l01[1], (_Float16)l23[0], (_Float16)l23[1]};
 }
 
+#ifndef TCN_BATCH
+#define TCN_BATCH 4                 // staging items (4 channels x 1 step) whose global loads a thread issues back to back
+#endif
+
 #define TCN_MMA(acc, a, b) (acc) = __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (acc), 0, 0, 0)
 
 // NC1 / NC2: 32-wide k chunks of conv1 / conv2 (ceil(3 cip / 32)); SB: the block shortcut is a 1x1 convolution
@@ -120,21 +124,36 @@ __global__ __launch_bounds__(256) void stg_tcn_mfma_kernel(const TcnMArgs p) {
         const int t0 = (int)(item - n * p.nseg) * p.tseg, t1 = min(T, t0 + p.tseg), tl = t1 - t0;
         __syncthreads();                                              // (the previous item is done with the images; first item: tvs is written)
         // ---- stage x[t0 - 4 .. ) transposed: thread -> (channel quad, time step); zeros before the row starts, after t1 and in padded channels ----
-        for (int i = tid; i < cq * XR; i += 256) {
-            const int q = i / XR, row = i - q * XR, t = t0 - 4 + row;
-            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (t >= 0 && t < t1) {
+        for (int i0 = tid; i0 < cq * XR; i0 += 256 * TCN_BATCH) {    // TCN_BATCH thread items' loads are issued before the first LDS write
+            float v[TCN_BATCH][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = 4 * q + j;
-                    if (c < p.c1) v[j] = p.src1[(n * p.c1 + c) * T + t];
-                    else if (c < ci) v[j] = p.src2[(n * p.c2 + (c - p.c1)) * T + t];
+            for (int u = 0; u < TCN_BATCH; ++u) {
+                const int i = i0 + 256 * u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[u][j] = 0.0f;
+                if (i < cq * XR) {
+                    const int q = i / XR, row = i - q * XR, t = t0 - 4 + row;
+                    if (t >= 0 && t < t1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int c = 4 * q + j;
+                            if (c < p.c1) v[u][j] = p.src1[(n * p.c1 + c) * T + t];
+                            else if (c < ci) v[u][j] = p.src2[(n * p.c2 + (c - p.c1)) * T + t];
+                        }
+                    }
                 }
             }
-            th4 hi, lo;
-            tcn_split4(v, hi, lo);
-            *reinterpret_cast<th4*>(xh + row * P1 + 4 * q) = hi;
-            *reinterpret_cast<th4*>(xl + row * P1 + 4 * q) = lo;
+#pragma unroll
+            for (int u = 0; u < TCN_BATCH; ++u) {
+                const int i = i0 + 256 * u;
+                if (i < cq * XR) {
+                    const int q = i / XR, row = i - q * XR;
+                    th4 hi, lo;
+                    tcn_split4(v[u], hi, lo);
+                    *reinterpret_cast<th4*>(xh + row * P1 + 4 * q) = hi;
+                    *reinterpret_cast<th4*>(xl + row * P1 + 4 * q) = lo;
+                }
+            }
         }
         __syncthreads();
         // ---- h1 on [t0 - 2, t1): tile i covers times t0 - 2 + 16 i + n16; x rows 16 i + n16 + tap ----
