@@ -212,6 +212,8 @@ typedef struct {
     int32_t mlp_times;     /* mlp_hidden_times                                                     */
     int32_t timesteps;     /* rows of the AdaLayerNorm table                                       */
     int32_t combine_taps;  /* kernel size of combine_s (1 or 5; circular 'same' convolution)       */
+    int32_t gemm;          /* MPV_GEMM_F16X3 (0, default): attention products (head width 16) as two-term f16 splits on the f16 matrix pipe,
+                              fp32-equivalent; MPV_GEMM_F32: every contraction on the exact-fp32 pipe (ABI v3 field) */
 } mpv_dts_desc;
 
 /* tensors: host pointers, PyTorch layouts, state_dict()["model.model.*"] in this order

@@ -43,9 +43,10 @@ def build(tag, **over):
     return m.to(dev()).eval(), par
 
 
+@pytest.mark.parametrize("gemm", ["f16x3", "f32"])
 @pytest.mark.parametrize("tag", ["small", "wide", "c3"])
-def test_transformer_forward_matches_reference(tag):
-    m, par = build(tag)
+def test_transformer_forward_matches_reference(tag, gemm):
+    m, par = build(tag, gemm_mode=gemm)
     z = gold()
     ctx = m.native_context()
     x = T(z["x_%s" % tag]).to(dev())
@@ -57,11 +58,13 @@ def test_transformer_forward_matches_reference(tag):
         assert e1 < RTOL and e2 < RTOL
 
 
+@pytest.mark.parametrize("gemm", ["f16x3", "f32"])
 @pytest.mark.parametrize("tag", ["small", "wide", "c3"])
-def test_blocks_and_input_gradient_match_reference(tag):
+def test_blocks_and_input_gradient_match_reference(tag, gemm):
     """Per-block outputs (encoder blocks, decoder blocks with their mean / trend / season residuals) and the vector-Jacobian
-    product of model_output w.r.t. the input, plus the gradient reaching the encoder output."""
-    m, par = build(tag)
+    product of model_output w.r.t. the input, plus the gradient reaching the encoder output.  gemm: the attention products as split-f16 on
+    the f16 matrix pipe (default; head width 16 only: 'c3' and 'wide' -- 'small' has 8-wide heads and runs the fp32 kernels either way) or fp32."""
+    m, par = build(tag, gemm_mode=gemm)
     z = gold()
     ctx = m.native_context()
     x = T(z["x_%s" % tag]).to(dev())
@@ -104,11 +107,12 @@ def test_blocks_and_input_gradient_match_reference(tag):
     assert e_enc < max(RTOL, 2.0 * noise)
 
 
+@pytest.mark.parametrize("gemm", ["f16x3", "f32"])
 @pytest.mark.parametrize("tag", ["small", "wide", "c3"])
-def test_evaluation_step_matches_reference(tag):
+def test_evaluation_step_matches_reference(tag, gemm):
     """DiffusionTS_model.evaluation_step (DDIM + Langevin infill, sample-major tiling / node-major un-tiling) with every
     normal draw of the reference run injected in its order."""
-    m, par = build(tag)
+    m, par = build(tag, gemm_mode=gemm)
     z = gold()
     batch = T(z["batch_%s" % tag])
     outs, by = m.evaluation_step(batch, noise=T(z["eval_%s_noise" % tag]))

@@ -58,7 +58,7 @@ class SampleOut(C.Structure):
 
 
 class DtsDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("seq_len", "nf", "d_model", "n_heads", "n_enc", "n_dec", "mlp_times", "timesteps", "combine_taps")]
+    _fields_ = [(n, C.c_int32) for n in ("seq_len", "nf", "d_model", "n_heads", "n_enc", "n_dec", "mlp_times", "timesteps", "combine_taps", "gemm")]
 
 
 class DtsSampleShape(C.Structure):
@@ -393,7 +393,8 @@ class Context:
 
     # ---- DiffusionTS -------------------------------------------------------------------
     def load_dts(self, seq_len: int, nf: int, d_model: int, n_heads: int, n_enc: int, n_dec: int, mlp_times: int, timesteps: int,
-                 combine_taps: int, tensors: Sequence[torch.Tensor], ada_tables: torch.Tensor, rfftfreq: torch.Tensor, poly: torch.Tensor):
+                 combine_taps: int, tensors: Sequence[torch.Tensor], ada_tables: torch.Tensor, rfftfreq: torch.Tensor, poly: torch.Tensor,
+                 gemm: str = "f16x3"):
         keep = [_host_f32(t) for t in tensors]
         ada, fr, po = _host_f32(ada_tables), _host_f32(rfftfreq), _host_f32(poly)
         if tuple(ada.shape) != (timesteps, n_enc + 2 * n_dec, 2 * d_model):
@@ -401,7 +402,9 @@ class Context:
         if fr.numel() != seq_len // 2 + 1 or tuple(po.shape) != (3, seq_len):
             raise MpvError("rfftfreq / poly tables do not match seq_len {}".format(seq_len))
         arr = (_F * len(keep))(*[_fptr(t) for t in keep])
-        desc = DtsDesc(seq_len, nf, d_model, n_heads, n_enc, n_dec, mlp_times, timesteps, combine_taps)
+        if gemm not in ("f16x3", "f32"):
+            raise MpvError("DiffusionTS supports gemm_mode 'f16x3' and 'f32'")
+        desc = DtsDesc(seq_len, nf, d_model, n_heads, n_enc, n_dec, mlp_times, timesteps, combine_taps, GEMM_MODES[gemm])
         self._bind_stream()
         self._check(self.lib.mpv_dts_load(self._h, C.byref(desc), arr, len(keep), _fptr(ada), _fptr(fr), _fptr(po)), "mpv_dts_load")
         self.dts = (seq_len, nf, d_model, n_heads, n_enc, n_dec, timesteps)

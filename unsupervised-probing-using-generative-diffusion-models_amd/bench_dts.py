@@ -62,7 +62,7 @@ def record_c3(args, log, rk):
     net = dict(device=device, scaler_type="StandardScaler", task_model="DiffusionTS", dataset_nf=cfg["nf"], windows=cfg["windows"],
                pred_len=cfg["pred_len"], d_model=cfg["d_model"], n_heads=cfg["n_heads"], n_layer_enc=cfg["n_layer_enc"],
                n_layer_dec=cfg["n_layer_dec"], timesteps=cfg["timesteps"], diffusion_steps=cfg["diffusion_steps"],
-               n_z_samples=cfg["n_z"], parallel_sample=cfg["parallel_sample"])
+               n_z_samples=cfg["n_z"], parallel_sample=cfg["parallel_sample"], gemm_mode=os.environ.get("MPV_DTS_GEMM", "f16x3"))
     torch.manual_seed(123)
     model = diffusion_models("DiffusionTS", net).to(device).eval()
     flat = sampled.reshape(-1, cfg["nf"]).float()
@@ -101,7 +101,8 @@ def record_c3(args, log, rk):
     out = {
         "metric": "rolling windows/sec (N=32, T=100), DiffusionTS", "value": rk.world * wps * args.steps / elapsed, "unit": "windows/s", "n_gpus": rk.world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (every contraction on v_mfma_f32_16x16x4_f32)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (every contraction on v_mfma_f32_16x16x4_f32)" if net["gemm_mode"] == "f32" else
+        "f32 (attention products as 3x f16 MFMA with fp32 accumulate, fp32-equivalent; Linear / MLP contractions on v_mfma_f32_16x16x4_f32)", "data": "synthetic",
         "config": {"workload": "DiffusionTS on 100-node BA-graph SIS trajectory (BASELINE configs[2]): windows=100, pred_len=100, d_model=64, "
                                "4 heads, 3 enc + 6 dec blocks, N=32 samples in one chunk (3200 sequences x 200 tokens), T=100 DDIM steps with "
                                "Langevin infill; {} window(s) per step of the {} of the trajectory".format(wps, n_total),

@@ -158,7 +158,29 @@ int attn_launch(mpv_ctx* ctx, int mode, const AttnArgs& a, int B) {
     return MPV_OK;
 }
 
-int attn(mpv_ctx* ctx, int mode, const AttnArgs& a, int B) {
+// the split-f16 kernels of dts_attn_h.h (head width 16): LDS = f16 hi / lo planes of K (+ V transposed / row-major), or of Q and dO
+int attn_launch_h(mpv_ctx* ctx, int mode, const AttnArgs& a, int B) {
+    const int Lkp = (a.Lk + 15) & ~15, Lqp = (a.Lq + 15) & ~15;
+    const dim3 grid(B * a.H), block(256);
+    if (mode == 0) {
+        const size_t lds = sizeof(_Float16) * (2 * (size_t)Lkp * AH_RS + 2 * 16 * (size_t)Lkp);
+        if (int rc = set_lds(ctx, dts_attn_fwd_h_kernel, lds)) return rc;
+        hipLaunchKernelGGL(dts_attn_fwd_h_kernel, grid, block, lds, ctx->stream, a);
+    } else if (mode == 1) {
+        const size_t lds = sizeof(_Float16) * (4 * (size_t)Lkp * AH_RS);
+        if (int rc = set_lds(ctx, dts_attn_dq_h_kernel, lds)) return rc;
+        hipLaunchKernelGGL(dts_attn_dq_h_kernel, grid, block, lds, ctx->stream, a);
+    } else {
+        const size_t lds = sizeof(_Float16) * (4 * (size_t)Lqp * AH_RS) + sizeof(float) * 2 * Lqp;
+        if (int rc = set_lds(ctx, dts_attn_dkv_h_kernel, lds)) return rc;
+        hipLaunchKernelGGL(dts_attn_dkv_h_kernel, grid, block, lds, ctx->stream, a);
+    }
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+int attn(mpv_ctx* ctx, int mode, const AttnArgs& a, int B, bool f16) {
+    if (f16 && a.hd == 16) return attn_launch_h(ctx, mode, a, B);
     switch (a.hd) {
         case 4: return attn_launch<1>(ctx, mode, a, B);
         case 8: return attn_launch<2>(ctx, mode, a, B);
@@ -308,7 +330,7 @@ int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t, bool save)
         const float* sc = ada_t + (size_t)ada_i * 2 * D;
         DTS_TRY(lin(ctx, e.xe[i], D, w.wqkv, w.bqkv, D, 3 * D, T, s.qkv, 3 * D, PRO_ADALN, sc, sc + D));
         AttnArgs a{s.qkv, s.qkv + D, s.qkv + 2 * D, 3 * D, 3 * D, 3 * D, nullptr, nullptr, D, s.att, D, nullptr, 0, s.lse, nullptr, H, L, L, e.hd, scale};
-        DTS_TRY(attn(ctx, 0, a, B));
+        DTS_TRY(attn(ctx, 0, a, B, e.d.gemm != MPV_GEMM_F32));
         DTS_TRY(lin(ctx, s.att, D, w.wp, w.bp, D, D, T, s.x1, D, PRO_NONE, nullptr, nullptr, 0, e.xe[i], D));
         DTS_TRY(mlp_block(ctx, e, s.x1, w.ln2w, w.ln2b, w.w0, w.b0, w.w2, w.b2, s.u, e.xe[i + 1], T, save));
     }
@@ -322,12 +344,12 @@ int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t, bool save)
         const float* sc2 = sc1 + 2 * D;
         DTS_TRY(lin(ctx, e.xd[i], D, w.wqkv1, w.bqkv1, D, 3 * D, T, s.qkv1, 3 * D, PRO_ADALN, sc1, sc1 + D));
         AttnArgs a1{s.qkv1, s.qkv1 + D, s.qkv1 + 2 * D, 3 * D, 3 * D, 3 * D, nullptr, nullptr, D, s.att1, D, nullptr, 0, s.lse1, nullptr, H, L, L, e.hd, scale};
-        DTS_TRY(attn(ctx, 0, a1, B));
+        DTS_TRY(attn(ctx, 0, a1, B, e.d.gemm != MPV_GEMM_F32));
         DTS_TRY(lin(ctx, s.att1, D, w.wp1, w.bp1, D, D, T, s.x1, D, PRO_NONE, nullptr, nullptr, 0, e.xd[i], D));
         DTS_TRY(lin(ctx, s.x1, D, w.wq2, w.bq2, D, D, T, s.q2, D, PRO_ADALN, sc2, sc2 + D));
         DTS_TRY(lin(ctx, encout, D, w.wkv2, w.bkv2, D, 2 * D, T, s.kv2, 2 * D));
         AttnArgs a2{s.q2, s.kv2, s.kv2 + D, D, 2 * D, 2 * D, nullptr, nullptr, D, s.att2, D, nullptr, 0, s.lse2, nullptr, H, L, L, e.hd, scale};
-        DTS_TRY(attn(ctx, 0, a2, B));
+        DTS_TRY(attn(ctx, 0, a2, B, e.d.gemm != MPV_GEMM_F32));
         DTS_TRY(lin(ctx, s.att2, D, w.wp2, w.bp2, D, D, T, s.x2, D, PRO_NONE, nullptr, nullptr, 0, s.x1, D));
         // proj (Conv1d(L -> 2L, k=1) over the token axis) folded into its two consumers: trend block on x2 with composite taps, and
         // the selected spectrum as ONE token mix with (DFT basis x proj[L:])
@@ -358,9 +380,9 @@ int attn_bwd(mpv_ctx* ctx, DtsEngine& e, int B, const float* Q, int ldq, const f
     hipLaunchKernelGGL(dts_attn_delta_kernel, g1d(n), dim3(256), 0, ctx->stream, dO, O, e.D, e.H, e.L, e.hd, n, e.delta);   // n = tokens * heads
     MPV_HIP_TRY(ctx, hipGetLastError());
     AttnArgs a{Q, K, V, ldq, ldkv, ldkv, dO, O, e.D, dq, lddq, nullptr, 0, lse, e.delta, e.H, e.L, e.L, e.hd, scale};
-    DTS_TRY(attn(ctx, 1, a, B));
+    DTS_TRY(attn(ctx, 1, a, B, e.d.gemm != MPV_GEMM_F32));
     a.out = dk; a.ldout = lddkv; a.out2 = dv; a.ldout2 = lddkv;
-    DTS_TRY(attn(ctx, 2, a, B));
+    DTS_TRY(attn(ctx, 2, a, B, e.d.gemm != MPV_GEMM_F32));
     return MPV_OK;
 }
 

@@ -4,6 +4,7 @@
 #pragma once
 #include "chain_common.h"
 #include "dts_kernels.h"
+#include "dts_attn_h.h"
 
 namespace dts {
 

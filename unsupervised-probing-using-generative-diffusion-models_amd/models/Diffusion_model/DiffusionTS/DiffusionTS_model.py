@@ -94,7 +94,7 @@ class DiffusionTS_model(nn.Module):
         poly = torch.stack([lin_space ** float(p + 1) for p in range(3)], dim=0)
         ctx.load_dts(L, self.dataset_nf, tf.n_embd, tf.n_heads, tf.n_layer_enc, tf.n_layer_dec, tf.mlp_hidden_times,
                      self.model.num_timesteps, tf.combine_taps, tf.native_weight_list(), tf.ada_tables(self.model.num_timesteps),
-                     torch.fft.rfftfreq(L), poly)
+                     torch.fft.rfftfreq(L), poly, gemm=self.configs.__dict__.get("gemm_mode", "f16x3"))
 
     def native_context(self):
         return self._native.context()
