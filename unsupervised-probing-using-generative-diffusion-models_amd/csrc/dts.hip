@@ -163,15 +163,15 @@ int attn_launch_h(mpv_ctx* ctx, int mode, const AttnArgs& a, int B) {
     const int Lkp = (a.Lk + 15) & ~15, Lqp = (a.Lq + 15) & ~15;
     const dim3 grid(B * a.H), block(256);
     if (mode == 0) {
-        const size_t lds = sizeof(_Float16) * (2 * (size_t)Lkp * AH_RS + 2 * 16 * (size_t)Lkp);
+        const size_t lds = sizeof(_Float16) * (2 * (size_t)Lkp * AH_RS + 2 * 16 * (size_t)Lkp) + 64;
         if (int rc = set_lds(ctx, dts_attn_fwd_h_kernel, lds)) return rc;
         hipLaunchKernelGGL(dts_attn_fwd_h_kernel, grid, block, lds, ctx->stream, a);
     } else if (mode == 1) {
-        const size_t lds = sizeof(_Float16) * (4 * (size_t)Lkp * AH_RS);
+        const size_t lds = sizeof(_Float16) * (4 * (size_t)Lkp * AH_RS) + 64;
         if (int rc = set_lds(ctx, dts_attn_dq_h_kernel, lds)) return rc;
         hipLaunchKernelGGL(dts_attn_dq_h_kernel, grid, block, lds, ctx->stream, a);
     } else {
-        const size_t lds = sizeof(_Float16) * (4 * (size_t)Lqp * AH_RS) + sizeof(float) * 2 * Lqp;
+        const size_t lds = sizeof(_Float16) * (4 * (size_t)Lqp * AH_RS) + sizeof(float) * 2 * Lqp + 64;
         if (int rc = set_lds(ctx, dts_attn_dkv_h_kernel, lds)) return rc;
         hipLaunchKernelGGL(dts_attn_dkv_h_kernel, grid, block, lds, ctx->stream, a);
     }
@@ -180,7 +180,7 @@ int attn_launch_h(mpv_ctx* ctx, int mode, const AttnArgs& a, int B) {
 }
 
 int attn(mpv_ctx* ctx, int mode, const AttnArgs& a, int B, bool f16) {
-    if (f16 && a.hd == 16) return attn_launch_h(ctx, mode, a, B);
+    if (f16 && a.hd == 16 && a.Lk <= 64 * AH_MAXQ && a.Lq <= 64 * AH_MAXQ) return attn_launch_h(ctx, mode, a, B);   // (a thread holds AH_MAXQ blocks of a staged head tile)
     switch (a.hd) {
         case 4: return attn_launch<1>(ctx, mode, a, B);
         case 8: return attn_launch<2>(ctx, mode, a, B);
@@ -199,16 +199,22 @@ int ln_bwd(mpv_ctx* ctx, int D, const float* g, const float* x, const float* gam
 }
 
 int mlp_fwd(mpv_ctx* ctx, int D, int M, const float* X, const float* W0, const float* b0, const float* W2, const float* b2, const float* lnw,
-            const float* lnb, float* Y, float* U, long long rows) {
+            const float* lnb, float* Y, float* U, long long rows, bool f16) {
     MlpArgs a{X, W0, b0, W2, b2, lnw, lnb, Y, U, rows};
-    const size_t lds = sizeof(float) * ((size_t)M * (D + 4) + (size_t)D * (M + 4));
+    const size_t lds = f16 ? 2 * sizeof(_Float16) * ((size_t)M * (D + 8) + (size_t)D * (M + 8)) + sizeof(float) * 2 * MLP_WAVES
+                           : sizeof(float) * ((size_t)M * (D + 4) + (size_t)D * (M + 4));
     const long long tiles = ((rows + 15) / 16 + MLP_WAVES - 1) / MLP_WAVES;              // 16-token tiles, MLP_WAVES of them per workgroup pass
     const long long per_cu = std::max<long long>(1, std::min<long long>(2, (long long)ctx->max_lds / (long long)lds));
     const int grid = (int)std::min<long long>(tiles, per_cu * ctx->cu_count);
 #define DTS_MLP(DT_, MT_)                                                                              \
     do {                                                                                               \
-        if (int rc = set_lds(ctx, dts_mlp_fwd_kernel<DT_, MT_>, lds)) return rc;                       \
-        hipLaunchKernelGGL((dts_mlp_fwd_kernel<DT_, MT_>), dim3(grid), dim3(64 * MLP_WAVES), lds, ctx->stream, a); \
+        if (f16) {                                                                                     \
+            if (int rc = set_lds(ctx, dts_mlp_fwd_h_kernel<DT_, MT_>, lds)) return rc;                 \
+            hipLaunchKernelGGL((dts_mlp_fwd_h_kernel<DT_, MT_>), dim3(grid), dim3(64 * MLP_WAVES), lds, ctx->stream, a); \
+        } else {                                                                                       \
+            if (int rc = set_lds(ctx, dts_mlp_fwd_kernel<DT_, MT_>, lds)) return rc;                   \
+            hipLaunchKernelGGL((dts_mlp_fwd_kernel<DT_, MT_>), dim3(grid), dim3(64 * MLP_WAVES), lds, ctx->stream, a); \
+        }                                                                                              \
     } while (0)
     if (D == 64 && M == 256) DTS_MLP(4, 16);
     else if (D == 32 && M == 128) DTS_MLP(2, 8);
@@ -220,16 +226,22 @@ int mlp_fwd(mpv_ctx* ctx, int D, int M, const float* X, const float* W0, const f
 }
 
 // d_ln = W0^T (gelu'(u) * (W2^T g)) in one kernel (see dts_mlp_bwd_kernel); -100 when no fused instance exists
-int mlp_bwd(mpv_ctx* ctx, int D, int M, const float* G, const float* U, const float* W2T, const float* W0T, float* Y, long long rows) {
+int mlp_bwd(mpv_ctx* ctx, int D, int M, const float* G, const float* U, const float* W2T, const float* W0T, float* Y, long long rows, bool f16) {
     MlpBwdArgs a{G, U, W2T, W0T, Y, rows};
-    const size_t lds = sizeof(float) * ((size_t)M * (D + 4) + (size_t)D * (M + 4));
+    const size_t lds = f16 ? 2 * sizeof(_Float16) * ((size_t)M * (D + 8) + (size_t)D * (M + 8)) + sizeof(float) * 2 * MLP_WAVES
+                           : sizeof(float) * ((size_t)M * (D + 4) + (size_t)D * (M + 4));
     const long long tiles = ((rows + 15) / 16 + MLP_WAVES - 1) / MLP_WAVES;
     const long long per_cu = std::max<long long>(1, std::min<long long>(2, (long long)ctx->max_lds / (long long)lds));
     const int grid = (int)std::min<long long>(tiles, per_cu * ctx->cu_count);
 #define DTS_MLPB(DT_, MT_)                                                                                           \
     do {                                                                                                            \
-        if (int rc = set_lds(ctx, dts_mlp_bwd_kernel<DT_, MT_>, lds)) return rc;                                    \
-        hipLaunchKernelGGL((dts_mlp_bwd_kernel<DT_, MT_>), dim3(grid), dim3(64 * MLP_WAVES), lds, ctx->stream, a);  \
+        if (f16) {                                                                                                  \
+            if (int rc = set_lds(ctx, dts_mlp_bwd_h_kernel<DT_, MT_>, lds)) return rc;                              \
+            hipLaunchKernelGGL((dts_mlp_bwd_h_kernel<DT_, MT_>), dim3(grid), dim3(64 * MLP_WAVES), lds, ctx->stream, a); \
+        } else {                                                                                                    \
+            if (int rc = set_lds(ctx, dts_mlp_bwd_kernel<DT_, MT_>, lds)) return rc;                                \
+            hipLaunchKernelGGL((dts_mlp_bwd_kernel<DT_, MT_>), dim3(grid), dim3(64 * MLP_WAVES), lds, ctx->stream, a); \
+        }                                                                                                           \
     } while (0)
     if (D == 64 && M == 256) DTS_MLPB(4, 16);
     else if (D == 32 && M == 128) DTS_MLPB(2, 8);
@@ -308,7 +320,7 @@ int carve(mpv_ctx* ctx, DtsEngine& e, int B) {
 
 int mlp_block(mpv_ctx* ctx, DtsEngine& e, const float* x, const float* lnw, const float* lnb, const float* w0, const float* b0, const float* w2,
               const float* b2, float* u, float* out, long long T, bool save) {
-    const int rc = mlp_fwd(ctx, e.D, e.M, x, w0, b0, w2, b2, lnw, lnb, out, save ? u : nullptr, T);
+    const int rc = mlp_fwd(ctx, e.D, e.M, x, w0, b0, w2, b2, lnw, lnb, out, save ? u : nullptr, T, e.d.gemm != MPV_GEMM_F32);
     if (rc != -100) return rc;
     DTS_TRY(lin(ctx, x, e.D, w0, b0, e.D, e.M, T, u, e.M, PRO_LN, lnw, lnb));
     return lin(ctx, u, e.M, w2, b2, e.M, e.D, T, out, e.D, PRO_GELU, nullptr, nullptr, 0, x, e.D);
@@ -410,7 +422,7 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
         MPV_HIP_TRY(ctx, hipGetLastError());
         std::swap(gcur, gnext);                                          // gcur = d_x3
         // x3 = x2 + mlp(ln2(x2))
-        const int fused = mlp_bwd(ctx, D, M, gcur, s.u, w.w2_t, w.w0_t, e.gC, T);       // d_ln = W0^T (gelu'(u) * (W2^T g)), hidden gradient on chip
+        const int fused = mlp_bwd(ctx, D, M, gcur, s.u, w.w2_t, w.w0_t, e.gC, T, e.d.gemm != MPV_GEMM_F32);       // d_ln = W0^T (gelu'(u) * (W2^T g)), hidden gradient on chip
         if (fused == MPV_OK) {
         } else if (fused != -100) {
             return fused;
@@ -449,7 +461,7 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
         const EncW& w = e.enc[i];
         const DtsEngine::EncS& s = e.es[i];
         const float* sc = ada_t + (size_t)i * 2 * D;
-        const int fused = mlp_bwd(ctx, D, M, genc, s.u, w.w2_t, w.w0_t, e.gC, T);
+        const int fused = mlp_bwd(ctx, D, M, genc, s.u, w.w2_t, w.w0_t, e.gC, T, e.d.gemm != MPV_GEMM_F32);
         if (fused == MPV_OK) {
         } else if (fused != -100) {
             return fused;

@@ -23,10 +23,15 @@ typedef _Float16 ah4 __attribute__((ext_vector_type(4)));
     } while (0)
 
 constexpr int AH_RS = 16;            // halves per row of a row-major plane ([tokens][16]; 32-byte rows: the ds_read_b64 of 16 rows is 2-way conflicted)
+constexpr int AH_MAXQ = 4;           // float4 blocks of a head tile a thread holds between the max pass and the split pass: tiles of <= 256 tokens
+constexpr float AH_PSCALE = 8192.0f; // probabilities (<= 1) are split as p * 2^13 ...
+constexpr float AH_PLOG = 13.0f;     // ... formed directly as exp2(s - m + 13)
 
-// x = hi + lo with hi = f16(x) and lo = f16(x - hi), BOTH rounded to nearest: |x - hi - lo| <= 2^-24 |x|, the precision of the fp32 operand itself
-// (the truncating split of nst_gemm.h keeps 22 bits; the sign-descent sampler is sensitive to that difference: with it only 3 of 16 replayed
-// sequences of the full-size 5-step test stayed on the oracle's trajectory, against 13 of 16 for the exact-fp32 kernels).
+// x = hi + lo with hi = f16(x) and lo = f16(x - hi), BOTH rounded to nearest: |x - hi - lo| <= 2^-24 |x| as long as lo is a NORMAL f16, i.e. for
+// |x| >= 2^-2.  f16 has five exponent bits, so every operand is first multiplied by a power of two that puts the largest element of its tile at
+// 2^13..2^14 (pow2_scale): elements down to 2^-15 of the largest keep all 24 bits, smaller ones lose precision only relative to themselves, and
+// gradients carrying a 1 / (batch x length) normaliser (1e-9 at BASELINE configs[2]) are as safe as O(1) activations.  The powers of two are
+// divided out of the fp32 accumulators (exactly).
 __device__ __forceinline__ void attn_split4(const float v0, const float v1, const float v2, const float v3, ah4& hi, ah4& lo) {
     const float v[4] = {v0, v1, v2, v3};
 #pragma unroll
@@ -36,13 +41,51 @@ __device__ __forceinline__ void attn_split4(const float v0, const float v1, cons
     }
 }
 
-// rows [n][16] of one head (token stride ld) -> f16 hi / lo planes: row-major [np][AH_RS] (rows >= n zero) and / or transposed [16][np]
-__device__ __forceinline__ void stage_head_h(const float* src, int ld, int n, int np, _Float16* rh, _Float16* rl, _Float16* th, _Float16* tl) {
-    for (int i = threadIdx.x; i < np * 4; i += 256) {                     // four head columns of a token per thread and pass
-        const int r = i >> 2, d = 4 * (i & 3);
-        const f32x4 v = r < n ? *reinterpret_cast<const f32x4*>(src + (long long)r * ld + d) : f32x4{0, 0, 0, 0};
+__device__ __forceinline__ float pow2_scale(float mx) {
+    if (!(mx > 0.0f) || !(mx < 3.0e38f)) return 1.0f;                   // all-zero tile, or inf / NaN (which then propagate as they would in fp32)
+    int e;
+    (void)frexpf(mx, &e);                                               // mx = m 2^e, m in [0.5, 1)
+    return ldexpf(1.0f, 14 - e);
+}
+
+__device__ __forceinline__ float wave_max(float m) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return m;
+}
+
+// A head tile [n][16] (token stride ld) in registers: thread i holds the float4 blocks i, i + 256, ... (block = token * 4 + column quad).
+struct HeadRegs { f32x4 v[AH_MAXQ]; };
+
+__device__ __forceinline__ float head_load(const float* src, int ld, int n, int np, HeadRegs& h) {
+    float m = 0.0f;
+#pragma unroll
+    for (int u = 0; u < AH_MAXQ; ++u) {
+        const int i = threadIdx.x + 256 * u, r = i >> 2, d = 4 * (i & 3);
+        h.v[u] = (i < np * 4 && r < n) ? *reinterpret_cast<const f32x4*>(src + (long long)r * ld + d) : f32x4{0, 0, 0, 0};
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(h.v[u][0]), fabsf(h.v[u][1])), fmaxf(fabsf(h.v[u][2]), fabsf(h.v[u][3]))));
+    }
+    return m;
+}
+
+// max |x| of a head tile that is NOT staged (the per-wave fragments come out of it later, from L2)
+__device__ __forceinline__ float head_absmax(const float* src, int ld, int n) {
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < n * 4; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long long)(i >> 2) * ld + 4 * (i & 3));
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    return m;
+}
+
+// registers (x scale) -> f16 hi / lo planes: row-major [np][AH_RS] and / or transposed [16][np]
+__device__ __forceinline__ void head_store(const HeadRegs& h, float scale, int np, _Float16* rh, _Float16* rl, _Float16* th, _Float16* tl) {
+#pragma unroll
+    for (int u = 0; u < AH_MAXQ; ++u) {
+        const int i = threadIdx.x + 256 * u, r = i >> 2, d = 4 * (i & 3);
+        if (i >= np * 4) break;
         ah4 hi, lo;
-        attn_split4(v[0], v[1], v[2], v[3], hi, lo);
+        attn_split4(h.v[u][0] * scale, h.v[u][1] * scale, h.v[u][2] * scale, h.v[u][3] * scale, hi, lo);
         if (rh) {
             *reinterpret_cast<ah4*>(rh + r * AH_RS + d) = hi;
             *reinterpret_cast<ah4*>(rl + r * AH_RS + d) = lo;
@@ -57,15 +100,41 @@ __device__ __forceinline__ void stage_head_h(const float* src, int ld, int n, in
     }
 }
 
+// workgroup-wide maxima of NT per-thread values -> power-of-two scales (one barrier pair; red: LDS [4][NT])
+template <int NT>
+__device__ __forceinline__ void wg_scales(float (&m)[NT], float* red, float (&sc)[NT]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        m[k] = wave_max(m[k]);
+        if (lane == 0) red[wave * NT + k] = m[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NT; ++k) sc[k] = pow2_scale(fmaxf(fmaxf(red[k], red[NT + k]), fmaxf(red[2 * NT + k], red[3 * NT + k])));
+}
+
 // four tokens' values of head column `col` out of a row-major plane: p[(row0 + j) * AH_RS + col], j = 0..3
 __device__ __forceinline__ ah4 column4(const _Float16* p, int row0, int col) {
     const _Float16* q = p + row0 * AH_RS + col;
     return ah4{q[0], q[AH_RS], q[2 * AH_RS], q[3 * AH_RS]};
 }
 
-__device__ __forceinline__ void load_split4(const float* p, ah4& hi, ah4& lo) {
+__device__ __forceinline__ void load_split4(const float* p, float scale, ah4& hi, ah4& lo) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-    attn_split4(v[0], v[1], v[2], v[3], hi, lo);
+    attn_split4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale, hi, lo);
+}
+
+// a 16 x 16 tile of gradient-like values in accumulator layout [row 4 g + r][column r16] -> split with a power of two per COLUMN (the four lanes of
+// a column agree on it with two shuffles; returned).  A column of the B operand scales the same column of the product, which is on the same lanes:
+// the caller divides it out of the zero-initialised product that consumes the tile.
+__device__ __forceinline__ float tile_split(const f32x4& t, ah4& hi, ah4& lo) {
+    float m = fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3])));
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    const float sc = pow2_scale(m);
+    attn_split4(t[0] * sc, t[1] * sc, t[2] * sc, t[3] * sc, hi, lo);
+    return sc;
 }
 
 __global__ __launch_bounds__(256) void dts_attn_fwd_h_kernel(const AttnArgs p) {
@@ -77,23 +146,32 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_h_kernel(const AttnArgs p) {
     _Float16* Kl = Kh + Lkp * AH_RS;
     _Float16* VTh = Kl + Lkp * AH_RS;                      // [16][Lkp]
     _Float16* VTl = VTh + 16 * Lkp;
-    stage_head_h(p.K + (long long)b * p.Lk * p.ldk + h * HD, p.ldk, p.Lk, Lkp, Kh, Kl, nullptr, nullptr);
-    stage_head_h(p.V + (long long)b * p.Lk * p.ldv + h * HD, p.ldv, p.Lk, Lkp, nullptr, nullptr, VTh, VTl);
+    float* red = reinterpret_cast<float*>(VTl + 16 * Lkp); // [4][3]
+    const float* Qb = p.Q + (long long)b * p.Lq * p.ldq + h * HD;
+    HeadRegs kr, vr;
+    float mx[3], sc[3];
+    mx[0] = head_load(p.K + (long long)b * p.Lk * p.ldk + h * HD, p.ldk, p.Lk, Lkp, kr);
+    mx[1] = head_load(p.V + (long long)b * p.Lk * p.ldv + h * HD, p.ldv, p.Lk, Lkp, vr);
+    mx[2] = head_absmax(Qb, p.ldq, p.Lq);
+    wg_scales<3>(mx, red, sc);
+    head_store(kr, sc[0], Lkp, Kh, Kl, nullptr, nullptr);
+    head_store(vr, sc[1], Lkp, nullptr, nullptr, VTh, VTl);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
-    const float c = p.scale * LOG2E;
+    const float c = p.scale * LOG2E / (sc[0] * sc[2]);                 // the scores come out of the MFMA times sK sQ
+    const float oinv = 1.0f / sc[1];                                   // O = (2^13 sV O) / (sV 2^13 l)
     for (int jt = wave; jt < ((p.Lq + 15) >> 4); jt += 4) {
         const int j = 16 * jt + r16;
         const bool jl = j < p.Lq;
         ah4 qh, ql;
-        load_split4(p.Q + ((long long)b * p.Lq + (jl ? j : 0)) * p.ldq + h * HD + 4 * g, qh, ql);
+        load_split4(Qb + (long long)(jl ? j : 0) * p.ldq + 4 * g, sc[2], qh, ql);
         float m = -INFINITY, l = 0.0f;
         f32x4 o = {0, 0, 0, 0};
         for (int it = 0; it < (Lkp >> 4); ++it) {
             const ah4 kh = *reinterpret_cast<const ah4*>(Kh + (16 * it + r16) * AH_RS + 4 * g);
             const ah4 kl = *reinterpret_cast<const ah4*>(Kl + (16 * it + r16) * AH_RS + 4 * g);
             f32x4 s = {0, 0, 0, 0};
-            DTS_MMH3(s, kh, kl, qh, ql);                                // S^T[key 4 g + r][query r16]
+            DTS_MMH3(s, kh, kl, qh, ql);                                // sK sQ S^T[key 4 g + r][query r16]
             float tmax = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -104,10 +182,11 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_h_kernel(const AttnArgs p) {
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
             const float mn = fmaxf(m, tmax);                       // finite from the first tile on (Lk >= 1)
             const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            const float mb = mn - AH_PLOG;                         // probabilities come out times 2^13 (the split's scale); l carries the same factor
             float ps = 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[r] = __builtin_amdgcn_exp2f(s[r] - mn);
+                s[r] = __builtin_amdgcn_exp2f(s[r] - mb);
                 ps += s[r];
             }
             l = l * alpha + ps;
@@ -117,15 +196,15 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_h_kernel(const AttnArgs p) {
             attn_split4(s[0], s[1], s[2], s[3], ph, pl);
             const ah4 vh = *reinterpret_cast<const ah4*>(VTh + r16 * Lkp + 16 * it + 4 * g);
             const ah4 vl = *reinterpret_cast<const ah4*>(VTl + r16 * Lkp + 16 * it + 4 * g);
-            DTS_MMH3(o, vh, vl, ph, pl);                                // O^T[d 4 g + r][query r16]
+            DTS_MMH3(o, vh, vl, ph, pl);                                // 2^13 sV O^T[d 4 g + r][query r16]
         }
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
         if (jl) {
-            const float inv = 1.0f / l;
+            const float inv = oinv / l;
             float* dst = p.out + ((long long)b * p.Lq + j) * p.ldout + h * HD + 4 * g;
             *reinterpret_cast<f32x4*>(dst) = o * inv;
-            if (g == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Lq + j] = m + __builtin_amdgcn_logf(l);
+            if (g == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Lq + j] = m + (__builtin_amdgcn_logf(l) - AH_PLOG);
         }
     }
 }
@@ -139,18 +218,29 @@ __global__ __launch_bounds__(256) void dts_attn_dq_h_kernel(const AttnArgs p) {
     _Float16* Kl = Kh + Lkp * AH_RS;
     _Float16* Vh = Kl + Lkp * AH_RS;
     _Float16* Vl = Vh + Lkp * AH_RS;
-    stage_head_h(p.K + (long long)b * p.Lk * p.ldk + h * HD, p.ldk, p.Lk, Lkp, Kh, Kl, nullptr, nullptr);
-    stage_head_h(p.V + (long long)b * p.Lk * p.ldv + h * HD, p.ldv, p.Lk, Lkp, Vh, Vl, nullptr, nullptr);
+    float* red = reinterpret_cast<float*>(Vl + Lkp * AH_RS);      // [4][4]
+    const float* Qb = p.Q + (long long)b * p.Lq * p.ldq + h * HD;
+    const float* Db = p.dO + (long long)b * p.Lq * p.ldo + h * HD;
+    HeadRegs kr, vr;
+    float mx[4], sc[4];
+    mx[0] = head_load(p.K + (long long)b * p.Lk * p.ldk + h * HD, p.ldk, p.Lk, Lkp, kr);
+    mx[1] = head_load(p.V + (long long)b * p.Lk * p.ldv + h * HD, p.ldv, p.Lk, Lkp, vr);
+    mx[2] = head_absmax(Qb, p.ldq, p.Lq);
+    mx[3] = head_absmax(Db, p.ldo, p.Lq);
+    wg_scales<4>(mx, red, sc);
+    head_store(kr, sc[0], Lkp, Kh, Kl, nullptr, nullptr);
+    head_store(vr, sc[1], Lkp, Vh, Vl, nullptr, nullptr);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
-    const float c = p.scale * LOG2E;
+    const float c = p.scale * LOG2E / (sc[0] * sc[2]);
+    const float dpinv = 1.0f / (sc[1] * sc[3]);                        // V . dO comes out times sV sdO
+    const float kinv = 1.0f / sc[0];
     for (int jt = wave; jt < ((p.Lq + 15) >> 4); jt += 4) {
         const int j = 16 * jt + r16;
         const bool jl = j < p.Lq;
-        const long long tok = (long long)b * p.Lq + (jl ? j : 0);
         ah4 qh, ql, dh, dl;
-        load_split4(p.Q + tok * p.ldq + h * HD + 4 * g, qh, ql);
-        load_split4(p.dO + tok * p.ldo + h * HD + 4 * g, dh, dl);
+        load_split4(Qb + (long long)(jl ? j : 0) * p.ldq + 4 * g, sc[2], qh, ql);
+        load_split4(Db + (long long)(jl ? j : 0) * p.ldo + 4 * g, sc[3], dh, dl);
         const float lse = p.lse[((long long)b * p.H + h) * p.Lq + (jl ? j : 0)];
         const float del = p.delta[((long long)b * p.H + h) * p.Lq + (jl ? j : 0)];
         f32x4 dq = {0, 0, 0, 0};
@@ -164,12 +254,14 @@ __global__ __launch_bounds__(256) void dts_attn_dq_h_kernel(const AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pr = (16 * it + 4 * g + r < p.Lk) ? __builtin_amdgcn_exp2f(s[r] * c - lse) : 0.0f;
-                s[r] = pr * (t2[r] - del) * p.scale;
+                s[r] = pr * (t2[r] * dpinv - del) * p.scale;
             }
             ah4 sh, sl;
-            attn_split4(s[0], s[1], s[2], s[3], sh, sl);
-            const ah4 th = column4(Kh, 16 * it + 4 * g, r16), tl = column4(Kl, 16 * it + 4 * g, r16);      // K^T[d = r16][keys 4 g ..]
-            DTS_MMH3(dq, th, tl, sh, sl);
+            const float ssc = tile_split(s, sh, sl);                    // dS^T of this tile times its own power of two
+            const ah4 th = column4(Kh, 16 * it + 4 * g, r16), tl = column4(Kl, 16 * it + 4 * g, r16);      // sK K^T[d = r16][keys 4 g ..]
+            f32x4 part = {0, 0, 0, 0};
+            DTS_MMH3(part, th, tl, sh, sl);
+            dq += part * (kinv / ssc);
         }
         if (jl) *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lq + j) * p.ldout + h * HD + 4 * g) = dq;
     }
@@ -186,49 +278,306 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_h_kernel(const AttnArgs p) {
     _Float16* Dl = Dh + Lqp * AH_RS;
     float* lsel = reinterpret_cast<float*>(Dl + Lqp * AH_RS);    // [Lqp]
     float* dell = lsel + Lqp;                              // [Lqp]
-    stage_head_h(p.Q + (long long)b * p.Lq * p.ldq + h * HD, p.ldq, p.Lq, Lqp, Qh, Ql, nullptr, nullptr);
-    stage_head_h(p.dO + (long long)b * p.Lq * p.ldo + h * HD, p.ldo, p.Lq, Lqp, Dh, Dl, nullptr, nullptr);
+    float* red = dell + Lqp;                               // [4][4]
+    const float* Kb = p.K + (long long)b * p.Lk * p.ldk + h * HD;
+    const float* Vb = p.V + (long long)b * p.Lk * p.ldv + h * HD;
+    HeadRegs qr, dr;
+    float mx[4], sc[4];
+    mx[0] = head_load(p.Q + (long long)b * p.Lq * p.ldq + h * HD, p.ldq, p.Lq, Lqp, qr);
+    mx[1] = head_load(p.dO + (long long)b * p.Lq * p.ldo + h * HD, p.ldo, p.Lq, Lqp, dr);
+    mx[2] = head_absmax(Kb, p.ldk, p.Lk);
+    mx[3] = head_absmax(Vb, p.ldv, p.Lk);
+    wg_scales<4>(mx, red, sc);
+    head_store(qr, sc[0], Lqp, Qh, Ql, nullptr, nullptr);
+    head_store(dr, sc[1], Lqp, Dh, Dl, nullptr, nullptr);
     for (int i = threadIdx.x; i < Lqp; i += 256) {
         lsel[i] = i < p.Lq ? p.lse[((long long)b * p.H + h) * p.Lq + i] : INFINITY;     // padded queries: P = 0
         dell[i] = i < p.Lq ? p.delta[((long long)b * p.H + h) * p.Lq + i] : 0.0f;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
-    const float c = p.scale * LOG2E;
+    const float c = p.scale * LOG2E / (sc[0] * sc[2]);
+    const float dpinv = 1.0f / (sc[1] * sc[3]);
+    const float dvinv = 1.0f / (sc[1] * AH_PSCALE), qinv = 1.0f / sc[0], pscale = p.scale / AH_PSCALE;
     for (int jt = wave; jt < ((p.Lk + 15) >> 4); jt += 4) {
         const int j = 16 * jt + r16;                                  // key
         const bool jl = j < p.Lk;
-        const long long tok = (long long)b * p.Lk + (jl ? j : 0);
         ah4 kh, kl, vh, vl;
-        load_split4(p.K + tok * p.ldk + h * HD + 4 * g, kh, kl);
-        load_split4(p.V + tok * p.ldv + h * HD + 4 * g, vh, vl);
+        load_split4(Kb + (long long)(jl ? j : 0) * p.ldk + 4 * g, sc[2], kh, kl);
+        load_split4(Vb + (long long)(jl ? j : 0) * p.ldv + 4 * g, sc[3], vh, vl);
         f32x4 dk = {0, 0, 0, 0}, dv = {0, 0, 0, 0};
         for (int it = 0; it < (Lqp >> 4); ++it) {
             const int ro = (16 * it + r16) * AH_RS + 4 * g;
             const ah4 qh = *reinterpret_cast<const ah4*>(Qh + ro), ql = *reinterpret_cast<const ah4*>(Ql + ro);
             const ah4 dh = *reinterpret_cast<const ah4*>(Dh + ro), dl = *reinterpret_cast<const ah4*>(Dl + ro);
             f32x4 s = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
-            DTS_MMH3(s, qh, ql, kh, kl);                                // S[query 4 g + r][key r16]
+            DTS_MMH3(s, qh, ql, kh, kl);                                // sQ sK S[query 4 g + r][key r16]
             DTS_MMH3(t2, dh, dl, vh, vl);
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsel + 16 * it + 4 * g);
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(dell + 16 * it + 4 * g);
             f32x4 pr, ds;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pr[r] = __builtin_amdgcn_exp2f(s[r] * c - l4[r]);
-                ds[r] = pr[r] * (t2[r] - d4[r]) * p.scale;
+                pr[r] = __builtin_amdgcn_exp2f(s[r] * c - (l4[r] - AH_PLOG));        // 2^13 P
+                ds[r] = pr[r] * (t2[r] * dpinv - d4[r]) * pscale;
             }
             ah4 ph, pl, sh, sl;
             attn_split4(pr[0], pr[1], pr[2], pr[3], ph, pl);
-            attn_split4(ds[0], ds[1], ds[2], ds[3], sh, sl);
-            const ah4 dth = column4(Dh, 16 * it + 4 * g, r16), dtl = column4(Dl, 16 * it + 4 * g, r16);      // dO^T[d = r16][queries 4 g ..]
+            const float ssc = tile_split(ds, sh, sl);
+            const ah4 dth = column4(Dh, 16 * it + 4 * g, r16), dtl = column4(Dl, 16 * it + 4 * g, r16);      // sdO dO^T[d = r16][queries 4 g ..]
             const ah4 qth = column4(Qh, 16 * it + 4 * g, r16), qtl = column4(Ql, 16 * it + 4 * g, r16);
             DTS_MMH3(dv, dth, dtl, ph, pl);
-            DTS_MMH3(dk, qth, qtl, sh, sl);
+            f32x4 part = {0, 0, 0, 0};
+            DTS_MMH3(part, qth, qtl, sh, sl);
+            dk += part * (qinv / ssc);
         }
         if (jl) {
             *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lk + j) * p.ldout + h * HD + 4 * g) = dk;
-            *reinterpret_cast<f32x4*>(p.out2 + ((long long)b * p.Lk + j) * p.ldout2 + h * HD + 4 * g) = dv;
+            *reinterpret_cast<f32x4*>(p.out2 + ((long long)b * p.Lk + j) * p.ldout2 + h * HD + 4 * g) = dv * dvinv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The fused MLP of a block and its input-gradient mirror (dts_mlp_fwd_kernel / dts_mlp_bwd_kernel of dts_kernels.h) on the f16 matrix pipe,
+// same structure: a wave owns 16-token tiles, the 16 M-wide hidden tile leaves the first product in accumulator layout [hidden unit 4 g + r][token]
+// and IS the B operand of the second product (k = 4 g + j of v_mfma_f32_16x16x16_f16) after GELU (or gelu') and the split.  Weights: f16 hi / lo
+// planes in LDS (split while they are staged, once per workgroup; the same 2 + 2 bytes per weight as fp32).  384 MFMAs of 16.5 cycles per tile
+// against 512 of 32; the fp32 kernels were 65 % matrix-pipe bound.
+// ---------------------------------------------------------------------------------------------------------------------
+// weights [M][D] and [D][M] -> f16 hi / lo planes, each matrix times its own power of two (returned in sa, sb); red: LDS [4][2]
+template <int DT, int MT>
+__device__ __forceinline__ void mlp_stage_weights(const float* Wa /*[M][D]*/, const float* Wb /*[D][M]*/, _Float16* Ah, _Float16* Al, _Float16* Bh, _Float16* Bl,
+                                                  float* red, float& sa, float& sb) {
+    constexpr int D = 16 * DT, M = 16 * MT, KSH = D + 8, MSH = M + 8;
+    float mx[2] = {0.0f, 0.0f}, sc[2];
+    for (int i = threadIdx.x; i < M * (D / 4); i += 64 * MLP_WAVES) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Wa + 4 * (size_t)i), b = *reinterpret_cast<const f32x4*>(Wb + 4 * (size_t)i);
+        mx[0] = fmaxf(mx[0], fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
+        mx[1] = fmaxf(mx[1], fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fmaxf(fabsf(b[2]), fabsf(b[3]))));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        mx[k] = wave_max(mx[k]);
+        if (lane == 0) red[wave * 2 + k] = mx[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float m = 0.0f;
+        for (int w = 0; w < MLP_WAVES; ++w) m = fmaxf(m, red[w * 2 + k]);
+        sc[k] = pow2_scale(m);
+    }
+    sa = sc[0];
+    sb = sc[1];
+    for (int i = threadIdx.x; i < M * (D / 4); i += 64 * MLP_WAVES) {
+        const int n = i / (D / 4), c = i - n * (D / 4);
+        ah4 hi, lo;
+        load_split4(Wa + (size_t)n * D + 4 * c, sa, hi, lo);
+        *reinterpret_cast<ah4*>(Ah + n * KSH + 4 * c) = hi;
+        *reinterpret_cast<ah4*>(Al + n * KSH + 4 * c) = lo;
+    }
+    for (int i = threadIdx.x; i < D * (M / 4); i += 64 * MLP_WAVES) {
+        const int n = i / (M / 4), c = i - n * (M / 4);
+        ah4 hi, lo;
+        load_split4(Wb + (size_t)n * M + 4 * c, sb, hi, lo);
+        *reinterpret_cast<ah4*>(Bh + n * MSH + 4 * c) = hi;
+        *reinterpret_cast<ah4*>(Bl + n * MSH + 4 * c) = lo;
+    }
+}
+
+// power of two for the values a token's four lanes hold (n f32x4 each): the B-operand column of that token
+template <int N>
+__device__ __forceinline__ float token_scale(const f32x4 (&v)[N]) {
+    float m = 0.0f;
+#pragma unroll
+    for (int s = 0; s < N; ++s) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[s][0]), fabsf(v[s][1])), fmaxf(fabsf(v[s][2]), fabsf(v[s][3]))));
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    return pow2_scale(m);
+}
+
+constexpr int MLP_HB = 4;           // hidden tiles formed, activated, split and consumed together (8 in the fp32 kernels; 4 keeps these under 256 VGPRs)
+
+template <int DT, int MT>
+__global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_fwd_h_kernel(const MlpArgs p) {
+    constexpr int D = 16 * DT, M = 16 * MT, KSH = D + 8, MSH = M + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    _Float16* W0h = reinterpret_cast<_Float16*>(ldsb);     // [M][KSH]
+    _Float16* W0l = W0h + M * KSH;
+    _Float16* W2h = W0l + M * KSH;                          // [D][MSH]
+    _Float16* W2l = W2h + D * MSH;
+    float* red = reinterpret_cast<float*>(W2l + D * MSH);  // [MLP_WAVES][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    float s0, s2;
+    mlp_stage_weights<DT, MT>(p.W0, p.W2, W0h, W0l, W2h, W2l, red, s0, s2);
+    __syncthreads();
+    const float i0 = 1.0f / s0, i2 = 1.0f / s2;
+    f32x4 lw[DT], lb[DT];
+#pragma unroll
+    for (int s = 0; s < DT; ++s) {
+        lw[s] = *reinterpret_cast<const f32x4*>(p.lnw + 16 * s + 4 * g);
+        lb[s] = *reinterpret_cast<const f32x4*>(p.lnb + 16 * s + 4 * g);
+    }
+    const long long n_tiles = (p.rows + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * MLP_WAVES) {
+        asm volatile("" ::: "memory");        // the weight fragments are re-read from LDS every tile
+        const long long tok = tile * 16 + r16;
+        const bool live = tok < p.rows;
+        const float* xr = p.X + (live ? tok : 0) * (long long)D + 4 * g;
+        f32x4 xb[DT];
+        float sum = 0.0f;
+#pragma unroll
+        for (int s = 0; s < DT; ++s) {
+            xb[s] = live ? *reinterpret_cast<const f32x4*>(xr + 16 * s) : f32x4{0, 0, 0, 0};
+            sum += (xb[s][0] + xb[s][1]) + (xb[s][2] + xb[s][3]);
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum / (float)D;
+        float q = 0.0f;
+#pragma unroll
+        for (int s = 0; s < DT; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xb[s][e] -= mean;
+                q += xb[s][e] * xb[s][e];
+            }
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
+#pragma unroll
+        for (int s = 0; s < DT; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xb[s][e] = xb[s][e] * rstd * lw[s][e] + lb[s][e];
+        const float sx = token_scale<DT>(xb);
+        const float ix = i0 / sx;
+        ah4 xh[DT], xl[DT];
+#pragma unroll
+        for (int s = 0; s < DT; ++s) attn_split4(xb[s][0] * sx, xb[s][1] * sx, xb[s][2] * sx, xb[s][3] * sx, xh[s], xl[s]);
+        constexpr int HB = MT < MLP_HB ? MT : MLP_HB;
+        f32x4 out[DT];
+#pragma unroll
+        for (int mt = 0; mt < DT; ++mt) out[mt] = f32x4{0, 0, 0, 0};
+#pragma unroll 1
+        for (int hb = 0; hb < MT; hb += HB) {                        // (not unrolled: the compiler otherwise hoists the next blocks' weight fragments, 49 spilled VGPRs)
+            f32x4 u[HB];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                const int nt = hb + j;
+                f32x4 acc = {0, 0, 0, 0};
+                const int wo = (16 * nt + r16) * KSH + 4 * g;
+#pragma unroll
+                for (int s = 0; s < DT; ++s) {
+                    const ah4 ah = *reinterpret_cast<const ah4*>(W0h + wo + 16 * s), al = *reinterpret_cast<const ah4*>(W0l + wo + 16 * s);
+                    DTS_MMH3(acc, ah, al, xh[s], xl[s]);
+                }
+                acc = acc * ix + *reinterpret_cast<const f32x4*>(p.b0 + 16 * nt + 4 * g);
+                if (p.U && live) *reinterpret_cast<f32x4*>(p.U + tok * (long long)M + 16 * nt + 4 * g) = acc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = gelu_f(acc[e]);
+                u[j] = acc;
+            }
+            const float su = token_scale<HB>(u);
+            ah4 uh[HB], ul[HB];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) attn_split4(u[j][0] * su, u[j][1] * su, u[j][2] * su, u[j][3] * su, uh[j], ul[j]);
+            const float iu = i2 / su;
+#pragma unroll
+            for (int mt = 0; mt < DT; ++mt) {
+                f32x4 part = {0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    const int wo = (16 * mt + r16) * MSH + 16 * (hb + j) + 4 * g;
+                    const ah4 ah = *reinterpret_cast<const ah4*>(W2h + wo), al = *reinterpret_cast<const ah4*>(W2l + wo);
+                    DTS_MMH3(part, ah, al, uh[j], ul[j]);
+                }
+                out[mt] += part * iu;
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int mt = 0; mt < DT; ++mt) {
+                const int n0 = 16 * mt + 4 * g;
+                f32x4 v = out[mt] + *reinterpret_cast<const f32x4*>(p.b2 + n0);
+                v += *reinterpret_cast<const f32x4*>(p.X + tok * (long long)D + n0);
+                *reinterpret_cast<f32x4*>(p.Y + tok * (long long)D + n0) = v;
+            }
+        }
+    }
+}
+
+template <int DT, int MT>
+__global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_bwd_h_kernel(const MlpBwdArgs p) {
+    constexpr int D = 16 * DT, M = 16 * MT, KSH = D + 8, MSH = M + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    _Float16* W2h = reinterpret_cast<_Float16*>(ldsb);     // [M][KSH]   W2^T
+    _Float16* W2l = W2h + M * KSH;
+    _Float16* W0h = W2l + M * KSH;                          // [D][MSH]   W0^T
+    _Float16* W0l = W0h + D * MSH;
+    float* red = reinterpret_cast<float*>(W0l + D * MSH);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    float s2, s0;
+    mlp_stage_weights<DT, MT>(p.W2T, p.W0T, W2h, W2l, W0h, W0l, red, s2, s0);
+    __syncthreads();
+    const float i2 = 1.0f / s2, i0 = 1.0f / s0;
+    const long long n_tiles = (p.rows + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * MLP_WAVES) {
+        asm volatile("" ::: "memory");
+        const long long tok = tile * 16 + r16;
+        const bool live = tok < p.rows;
+        const float* gr = p.G + (live ? tok : 0) * (long long)D + 4 * g;
+        f32x4 gb[DT];
+#pragma unroll
+        for (int s = 0; s < DT; ++s) gb[s] = live ? *reinterpret_cast<const f32x4*>(gr + 16 * s) : f32x4{0, 0, 0, 0};
+        const float sg = token_scale<DT>(gb);                         // gradients carry the batch normaliser (1e-9 at full size): the token's own power of two
+        const float ig = i2 / sg;
+        ah4 gh[DT], gl[DT];
+#pragma unroll
+        for (int s = 0; s < DT; ++s) attn_split4(gb[s][0] * sg, gb[s][1] * sg, gb[s][2] * sg, gb[s][3] * sg, gh[s], gl[s]);
+        constexpr int HB = MT < MLP_HB ? MT : MLP_HB;
+        f32x4 out[DT];
+#pragma unroll
+        for (int mt = 0; mt < DT; ++mt) out[mt] = f32x4{0, 0, 0, 0};
+#pragma unroll 1
+        for (int hb = 0; hb < MT; hb += HB) {
+            f32x4 e[HB];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                const int nt = hb + j;
+                f32x4 acc = {0, 0, 0, 0};
+                const int wo = (16 * nt + r16) * KSH + 4 * g;
+#pragma unroll
+                for (int s = 0; s < DT; ++s) {
+                    const ah4 ah = *reinterpret_cast<const ah4*>(W2h + wo + 16 * s), al = *reinterpret_cast<const ah4*>(W2l + wo + 16 * s);
+                    DTS_MMH3(acc, ah, al, gh[s], gl[s]);
+                }
+                const f32x4 u = live ? *reinterpret_cast<const f32x4*>(p.U + tok * (long long)M + 16 * nt + 4 * g) : f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = acc[q] * ig * gelu_grad_f(u[q]);
+                e[j] = acc;
+            }
+            const float se = token_scale<HB>(e);
+            ah4 eh[HB], el[HB];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) attn_split4(e[j][0] * se, e[j][1] * se, e[j][2] * se, e[j][3] * se, eh[j], el[j]);
+            const float ie = i0 / se;
+#pragma unroll
+            for (int mt = 0; mt < DT; ++mt) {
+                f32x4 part = {0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    const int wo = (16 * mt + r16) * MSH + 16 * (hb + j) + 4 * g;
+                    const ah4 ah = *reinterpret_cast<const ah4*>(W0h + wo), al = *reinterpret_cast<const ah4*>(W0l + wo);
+                    DTS_MMH3(part, ah, al, eh[j], el[j]);
+                }
+                out[mt] += part * ie;
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int mt = 0; mt < DT; ++mt) *reinterpret_cast<f32x4*>(p.Y + tok * (long long)D + 16 * mt + 4 * g) = out[mt];
         }
     }
 }
