@@ -48,6 +48,26 @@ def measured_traffic(key, repo_root=None):
     return None
 
 
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E, 8 TB/s peak (about 6.3 TB/s achievable)
+
+
+def multi_kernel_roofline(tr, windows_per_s, achieved_tflops, peak_tflops, peak_name, kernels, extra=None):
+    """Roofline object of a call made of many kernels (c3, c5).  With a committed PMC pass (`tr`, profiles/*/pmc_traffic_<cfg>.json) the
+    bound is stated against HBM: achieved = measured HBM bytes per window x windows/s (every kernel of these schedules streams its operands
+    once, so measured and algorithmic bytes coincide to within the L2 / Infinity-Cache hits the counters still see), `traffic` = those bytes
+    per window; the matrix-pipe view of the same run is kept under `compute`.  Without a PMC pass only the compute view exists."""
+    compute = {"achieved_tflops": achieved_tflops, "peak_tflops": peak_tflops, "peak": peak_name, "frac": achieved_tflops / peak_tflops}
+    if tr and tr.get("bytes_per_window"):
+        gbps = tr["bytes_per_window"] * windows_per_s / 1e9
+        out = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": tr["bytes_per_window"],
+               "kernel": kernels, "dominant_kernel": tr.get("dominant_kernel"), "compute": compute}
+    else:
+        out = {"bound": "mfma", "achieved": achieved_tflops, "peak": peak_tflops, "unit": "TFLOP/s", "frac": achieved_tflops / peak_tflops, "traffic": None,
+               "kernel": kernels, "compute": compute}
+    out.update(extra or {})
+    return out
+
+
 class Ranks:
     @classmethod
     def single(cls, device, backend="nccl"):

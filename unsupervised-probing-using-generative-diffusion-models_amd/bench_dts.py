@@ -45,7 +45,7 @@ def record_c3(args, log, rk):
     from mpv_amd import synthetic
     from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
     from mpv_amd.models.models import diffusion_models
-    from mpv_amd.bench_common import measured_traffic
+    from mpv_amd.bench_common import measured_traffic, multi_kernel_roofline
     device = rk.device
     cfg = dict(C3)
     short = int(os.environ.get("MPV_BENCH_DTS_STEPS", "0"))              # profiling aid (PMC passes): fewer DDIM steps, flagged in the record
@@ -109,12 +109,13 @@ def record_c3(args, log, rk):
                    "windows_per_step_per_gpu": wps, "noise": "on-device Philox4x32-10", "weights": "seeded default init",
                    "truncated_for_profiling": short > 0, "sampling_steps": cfg["diffusion_steps"],
                    "passes_per_window": {"forward": n_fwd, "backward": n_bwd}},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
-                     "traffic": (tr or {}).get("bytes_per_window") if short == 0 else None, "traffic_detail": slim_traffic(tr),
-                     "kernel": "dts_attn_{fwd,dq,dkv} + dts_lin_wave + dts_mlp_{fwd,bwd} + dts_seqmix (whole sampler call)",
-                     "flop_per_window": flop_per_window, "flop_per_sequence_forward": ff, "flop_per_sequence_backward": fb,
-                     "peak_source": "fp32 matrix pipe (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md",
-                     "note": "achieved = algorithmic FLOPs of the dense contractions / wall time of the timed steps (all kernels of the call)"},
+        "roofline": multi_kernel_roofline(
+            tr if short == 0 else None, rk.world * wps * args.steps / elapsed / rk.world, achieved, FP32_MATRIX_PEAK_TFLOPS,
+            "fp32 matrix pipe (algorithmic FLOPs of the whole call; attention and MLP products run as 3x f16 MFMA unless gemm_mode='f32')",
+            "dts_lin_wave + dts_attn_{fwd,dq,dkv}_h + dts_mlp_{fwd,bwd}_h + dts_ln_bwd + dts_seqmix + Fourier / trend kernels (whole sampler call)",
+            {"flop_per_window": flop_per_window, "flop_per_sequence_forward": ff, "flop_per_sequence_backward": fb, "traffic_detail": slim_traffic(tr),
+             "note": "356 transformer passes of about 100 kernels each over [3200 x 200 x 64] activations; achieved compute = algorithmic FLOPs of the "
+                     "dense contractions / wall time of the timed steps"}),
     }
     if not args.no_cpu_baseline and rk.world == 1:
         out["cpu_baseline"] = cpu_baseline(model, series, cfg, log)

@@ -1,8 +1,8 @@
 // DiffusionTS attention on the f16 matrix pipe at fp32-equivalent accuracy (head width 16 = the shipped 64 / 4), forward, dQ and dK-dV.
 // Same structure and arithmetic order as the exact-fp32 kernels of dts_kernels.h (one workgroup per (sequence, head), 16-query / 16-key tiles,
 // online softmax in base 2, the score tile in accumulator layout reused as the next product's B operand) with every 16 x 16 x 16 contraction as
-// ONE v_mfma_f32_16x16x16_f16 per term of the two-term split x = hi + lo (both halves rounded to nearest: 24 significant bits; products
-// hi*hi + hi*lo + lo*hi, fp32 accumulate; the dropped lo*lo is 2^-24 relative) instead of four v_mfma_f32_16x16x4_f32: 3 x 16.5 cycles against 4 x 32
+// ONE v_mfma_f32_16x16x16_f16 per term of the two-term split x = hi + lo of power-of-two scaled operands (22 significant bits; products
+// hi*hi + hi*lo + lo*hi, fp32 accumulate; the dropped lo*lo is 2^-22 relative) instead of four v_mfma_f32_16x16x4_f32: 3 x 16.5 cycles against 4 x 32
 // (tools/ubench/mfma_rates.hip).  The fp32 kernels spent 56 % (forward), 70 % (dQ) and 76 % (dK-dV) of their time on the matrix pipe.
 // K / V (Q / dO in the dK-dV pass) are split ONCE while they are staged into LDS, as f16 hi / lo planes.  Operands indexed by (token, 4 head
 // columns) are one ds_read_b64 per plane out of the row-major planes; operands indexed by (head column, 4 tokens) are read column-wise out of the
@@ -22,23 +22,43 @@ typedef _Float16 ah4 __attribute__((ext_vector_type(4)));
         DTS_MMH(acc, ah, bh);         \
     } while (0)
 
+#ifndef DTS_SPLIT_RNE
+#define DTS_SPLIT_RNE 0              // 1: both halves rounded to nearest (24 bits, 4 + conversions per element); 0: truncating split (22 bits, 3 per element)
+#endif
 constexpr int AH_RS = 16;            // halves per row of a row-major plane ([tokens][16]; 32-byte rows: the ds_read_b64 of 16 rows is 2-way conflicted)
 constexpr int AH_MAXQ = 4;           // float4 blocks of a head tile a thread holds between the max pass and the split pass: tiles of <= 256 tokens
 constexpr float AH_PSCALE = 8192.0f; // probabilities (<= 1) are split as p * 2^13 ...
 constexpr float AH_PLOG = 13.0f;     // ... formed directly as exp2(s - m + 13)
 
-// x = hi + lo with hi = f16(x) and lo = f16(x - hi), BOTH rounded to nearest: |x - hi - lo| <= 2^-24 |x| as long as lo is a NORMAL f16, i.e. for
-// |x| >= 2^-2.  f16 has five exponent bits, so every operand is first multiplied by a power of two that puts the largest element of its tile at
-// 2^13..2^14 (pow2_scale): elements down to 2^-15 of the largest keep all 24 bits, smaller ones lose precision only relative to themselves, and
-// gradients carrying a 1 / (batch x length) normaliser (1e-9 at BASELINE configs[2]) are as safe as O(1) activations.  The powers of two are
-// divided out of the fp32 accumulators (exactly).
+// x = hi + lo: hi = the 11 leading significand bits (exact in f16), lo = f16(x - hi) truncated: 22 significant bits as long as lo is a NORMAL
+// f16, i.e. for |x| >= 2^-2.  f16 has five exponent bits, so every operand is first multiplied by a power of two that puts the largest element of
+// its tile / column at 2^13..2^14 (pow2_scale): elements down to 2^-15 of the largest keep all 22 bits, smaller ones lose precision only relative
+// to themselves, and gradients carrying a 1 / (batch x length) normaliser (1e-9 at BASELINE configs[2]) are as safe as O(1) activations.  The
+// powers of two are divided out of the fp32 accumulators (exactly).  Measured on the full-size replay test (tests/test_full_size_gpu.py, 16
+// sequences of a 3200-sequence batch, 5 steps): WITHOUT the scaling the low halves of small operands flush to zero and 3 of 16 sequences stay
+// on the oracle's trajectory; with it 14 of 16 (the exact-fp32 kernels: 13 of 16); rounding both halves to nearest instead (DTS_SPLIT_RNE, 24
+// bits, one more instruction per element) also gives 14 of 16 and is 4 % slower.
 __device__ __forceinline__ void attn_split4(const float v0, const float v1, const float v2, const float v3, ah4& hi, ah4& lo) {
     const float v[4] = {v0, v1, v2, v3};
+#if DTS_SPLIT_RNE
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         hi[c] = (_Float16)v[c];
         lo[c] = (_Float16)(v[c] - (float)hi[c]);
     }
+#else
+    float h[4], l[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        h[c] = __uint_as_float(__float_as_uint(v[c]) & 0xFFFFE000u);   // 11 leading bits: exact in f16
+        l[c] = v[c] - h[c];
+    }
+    typedef __fp16 pk2 __attribute__((ext_vector_type(2)));
+    const pk2 h01 = __builtin_amdgcn_cvt_pkrtz(h[0], h[1]), h23 = __builtin_amdgcn_cvt_pkrtz(h[2], h[3]);
+    const pk2 l01 = __builtin_amdgcn_cvt_pkrtz(l[0], l[1]), l23 = __builtin_amdgcn_cvt_pkrtz(l[2], l[3]);
+    hi = ah4{(_Float16)h01[0], (_Float16)h01[1], (_Float16)h23[0], (_Float16)h23[1]};
+    lo = ah4{(_Float16)l01[0], (_Float16)l01[1], (_Float16)l23[0], (_Float16)l23[1]};
+#endif
 }
 
 __device__ __forceinline__ float pow2_scale(float mx) {
@@ -64,16 +84,6 @@ __device__ __forceinline__ float head_load(const float* src, int ld, int n, int 
         const int i = threadIdx.x + 256 * u, r = i >> 2, d = 4 * (i & 3);
         h.v[u] = (i < np * 4 && r < n) ? *reinterpret_cast<const f32x4*>(src + (long long)r * ld + d) : f32x4{0, 0, 0, 0};
         m = fmaxf(m, fmaxf(fmaxf(fabsf(h.v[u][0]), fabsf(h.v[u][1])), fmaxf(fabsf(h.v[u][2]), fabsf(h.v[u][3]))));
-    }
-    return m;
-}
-
-// max |x| of a head tile that is NOT staged (the per-wave fragments come out of it later, from L2)
-__device__ __forceinline__ float head_absmax(const float* src, int ld, int n) {
-    float m = 0.0f;
-    for (int i = threadIdx.x; i < n * 4; i += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long long)(i >> 2) * ld + 4 * (i & 3));
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     }
     return m;
 }
@@ -125,6 +135,18 @@ __device__ __forceinline__ void load_split4(const float* p, float scale, ah4& hi
     attn_split4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale, hi, lo);
 }
 
+// the 16 head columns of ONE token as a B-operand column (lane (r16, g) holds columns 4 g .. 4 g + 3 of token r16): split with the token's own
+// power of two (its four lanes agree on it with two shuffles; returned) -- no pass over the head tile is needed for operands that enter as columns
+__device__ __forceinline__ float load_split_col(const float* p, ah4& hi, ah4& lo) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    const float sc = pow2_scale(m);
+    attn_split4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc, hi, lo);
+    return sc;
+}
+
 // a 16 x 16 tile of gradient-like values in accumulator layout [row 4 g + r][column r16] -> split with a power of two per COLUMN (the four lanes of
 // a column agree on it with two shuffles; returned).  A column of the B operand scales the same column of the product, which is on the same lanes:
 // the caller divides it out of the zero-initialised product that consumes the tile.
@@ -146,25 +168,24 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_h_kernel(const AttnArgs p) {
     _Float16* Kl = Kh + Lkp * AH_RS;
     _Float16* VTh = Kl + Lkp * AH_RS;                      // [16][Lkp]
     _Float16* VTl = VTh + 16 * Lkp;
-    float* red = reinterpret_cast<float*>(VTl + 16 * Lkp); // [4][3]
+    float* red = reinterpret_cast<float*>(VTl + 16 * Lkp); // [4][2]
     const float* Qb = p.Q + (long long)b * p.Lq * p.ldq + h * HD;
     HeadRegs kr, vr;
-    float mx[3], sc[3];
+    float mx[2], sc[2];
     mx[0] = head_load(p.K + (long long)b * p.Lk * p.ldk + h * HD, p.ldk, p.Lk, Lkp, kr);
     mx[1] = head_load(p.V + (long long)b * p.Lk * p.ldv + h * HD, p.ldv, p.Lk, Lkp, vr);
-    mx[2] = head_absmax(Qb, p.ldq, p.Lq);
-    wg_scales<3>(mx, red, sc);
+    wg_scales<2>(mx, red, sc);
     head_store(kr, sc[0], Lkp, Kh, Kl, nullptr, nullptr);
     head_store(vr, sc[1], Lkp, nullptr, nullptr, VTh, VTl);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
-    const float c = p.scale * LOG2E / (sc[0] * sc[2]);                 // the scores come out of the MFMA times sK sQ
+    const float c0 = p.scale * LOG2E / sc[0];
     const float oinv = 1.0f / sc[1];                                   // O = (2^13 sV O) / (sV 2^13 l)
     for (int jt = wave; jt < ((p.Lq + 15) >> 4); jt += 4) {
         const int j = 16 * jt + r16;
         const bool jl = j < p.Lq;
         ah4 qh, ql;
-        load_split4(Qb + (long long)(jl ? j : 0) * p.ldq + 4 * g, sc[2], qh, ql);
+        const float c = c0 / load_split_col(Qb + (long long)(jl ? j : 0) * p.ldq + 4 * g, qh, ql);      // the scores come out of the MFMA times sK sQ(query)
         float m = -INFINITY, l = 0.0f;
         f32x4 o = {0, 0, 0, 0};
         for (int it = 0; it < (Lkp >> 4); ++it) {
@@ -218,29 +239,26 @@ __global__ __launch_bounds__(256) void dts_attn_dq_h_kernel(const AttnArgs p) {
     _Float16* Kl = Kh + Lkp * AH_RS;
     _Float16* Vh = Kl + Lkp * AH_RS;
     _Float16* Vl = Vh + Lkp * AH_RS;
-    float* red = reinterpret_cast<float*>(Vl + Lkp * AH_RS);      // [4][4]
+    float* red = reinterpret_cast<float*>(Vl + Lkp * AH_RS);      // [4][2]
     const float* Qb = p.Q + (long long)b * p.Lq * p.ldq + h * HD;
     const float* Db = p.dO + (long long)b * p.Lq * p.ldo + h * HD;
     HeadRegs kr, vr;
-    float mx[4], sc[4];
+    float mx[2], sc[2];
     mx[0] = head_load(p.K + (long long)b * p.Lk * p.ldk + h * HD, p.ldk, p.Lk, Lkp, kr);
     mx[1] = head_load(p.V + (long long)b * p.Lk * p.ldv + h * HD, p.ldv, p.Lk, Lkp, vr);
-    mx[2] = head_absmax(Qb, p.ldq, p.Lq);
-    mx[3] = head_absmax(Db, p.ldo, p.Lq);
-    wg_scales<4>(mx, red, sc);
+    wg_scales<2>(mx, red, sc);
     head_store(kr, sc[0], Lkp, Kh, Kl, nullptr, nullptr);
     head_store(vr, sc[1], Lkp, Vh, Vl, nullptr, nullptr);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
-    const float c = p.scale * LOG2E / (sc[0] * sc[2]);
-    const float dpinv = 1.0f / (sc[1] * sc[3]);                        // V . dO comes out times sV sdO
+    const float c0 = p.scale * LOG2E / sc[0];
     const float kinv = 1.0f / sc[0];
     for (int jt = wave; jt < ((p.Lq + 15) >> 4); jt += 4) {
         const int j = 16 * jt + r16;
         const bool jl = j < p.Lq;
         ah4 qh, ql, dh, dl;
-        load_split4(Qb + (long long)(jl ? j : 0) * p.ldq + 4 * g, sc[2], qh, ql);
-        load_split4(Db + (long long)(jl ? j : 0) * p.ldo + 4 * g, sc[3], dh, dl);
+        const float c = c0 / load_split_col(Qb + (long long)(jl ? j : 0) * p.ldq + 4 * g, qh, ql);
+        const float dpinv = 1.0f / (sc[1] * load_split_col(Db + (long long)(jl ? j : 0) * p.ldo + 4 * g, dh, dl));      // V . dO comes out times sV sdO(query)
         const float lse = p.lse[((long long)b * p.H + h) * p.Lq + (jl ? j : 0)];
         const float del = p.delta[((long long)b * p.H + h) * p.Lq + (jl ? j : 0)];
         f32x4 dq = {0, 0, 0, 0};
@@ -278,16 +296,14 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_h_kernel(const AttnArgs p) {
     _Float16* Dl = Dh + Lqp * AH_RS;
     float* lsel = reinterpret_cast<float*>(Dl + Lqp * AH_RS);    // [Lqp]
     float* dell = lsel + Lqp;                              // [Lqp]
-    float* red = dell + Lqp;                               // [4][4]
+    float* red = dell + Lqp;                               // [4][2]
     const float* Kb = p.K + (long long)b * p.Lk * p.ldk + h * HD;
     const float* Vb = p.V + (long long)b * p.Lk * p.ldv + h * HD;
     HeadRegs qr, dr;
-    float mx[4], sc[4];
+    float mx[2], sc[2];
     mx[0] = head_load(p.Q + (long long)b * p.Lq * p.ldq + h * HD, p.ldq, p.Lq, Lqp, qr);
     mx[1] = head_load(p.dO + (long long)b * p.Lq * p.ldo + h * HD, p.ldo, p.Lq, Lqp, dr);
-    mx[2] = head_absmax(Kb, p.ldk, p.Lk);
-    mx[3] = head_absmax(Vb, p.ldv, p.Lk);
-    wg_scales<4>(mx, red, sc);
+    wg_scales<2>(mx, red, sc);
     head_store(qr, sc[0], Lqp, Qh, Ql, nullptr, nullptr);
     head_store(dr, sc[1], Lqp, Dh, Dl, nullptr, nullptr);
     for (int i = threadIdx.x; i < Lqp; i += 256) {
@@ -296,15 +312,14 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_h_kernel(const AttnArgs p) {
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
-    const float c = p.scale * LOG2E / (sc[0] * sc[2]);
-    const float dpinv = 1.0f / (sc[1] * sc[3]);
+    const float c0 = p.scale * LOG2E / sc[0];
     const float dvinv = 1.0f / (sc[1] * AH_PSCALE), qinv = 1.0f / sc[0], pscale = p.scale / AH_PSCALE;
     for (int jt = wave; jt < ((p.Lk + 15) >> 4); jt += 4) {
         const int j = 16 * jt + r16;                                  // key
         const bool jl = j < p.Lk;
         ah4 kh, kl, vh, vl;
-        load_split4(Kb + (long long)(jl ? j : 0) * p.ldk + 4 * g, sc[2], kh, kl);
-        load_split4(Vb + (long long)(jl ? j : 0) * p.ldv + 4 * g, sc[3], vh, vl);
+        const float c = c0 / load_split_col(Kb + (long long)(jl ? j : 0) * p.ldk + 4 * g, kh, kl);
+        const float dpinv = 1.0f / (sc[1] * load_split_col(Vb + (long long)(jl ? j : 0) * p.ldv + 4 * g, vh, vl));
         f32x4 dk = {0, 0, 0, 0}, dv = {0, 0, 0, 0};
         for (int it = 0; it < (Lqp >> 4); ++it) {
             const int ro = (16 * it + r16) * AH_RS + 4 * g;
