@@ -53,6 +53,10 @@ struct DtsEngine {
     // sampler state [B][L][F]
     float *img = nullptr, *target = nullptr, *xstart = nullptr, *pmean = nullptr, *noise = nullptr;
     bool snapshots = false;                          // mpv_dts_vjp: keep the gradient at the encoder output for mpv_dts_debug_tensor
+    // Attention operands (Q | K | V, attention output, and their gradients) in 16-column BLOCKED layout [block][tokens][16] when a head is 16
+    // wide: a (sequence, head) tile is then 12.8 KB of contiguous memory instead of 64-byte pieces of 768-byte rows (half of every 128-byte
+    // line unused: measured 1.16 GB per forward attention launch against 0.66 GB algorithmic).  MPV_DTS_ROWMAJOR=1 keeps the round-2 layout.
+    bool blocked = false;
 };
 
 namespace {
@@ -66,8 +70,9 @@ int set_lds(mpv_ctx* ctx, K kernel, size_t bytes) {
 }
 
 int lin(mpv_ctx* ctx, const float* X, int ldx, const float* W, const float* bias, int K, int N, long long rows, float* Y, int ldy, int pro = PRO_NONE,
-        const float* P1 = nullptr, const float* P2 = nullptr, int ldp = 0, const float* R = nullptr, int ldr = 0, int accumulate = 0) {
-    LinArgs a{X, ldx, W, bias, R, ldr, Y, ldy, P1, P2, ldp, rows, K, N, pro, accumulate};
+        const float* P1 = nullptr, const float* P2 = nullptr, int ldp = 0, const float* R = nullptr, int ldr = 0, int accumulate = 0, long long xblk = 0,
+        long long yblk = 0) {
+    LinArgs a{X, ldx, W, bias, R, ldr, Y, ldy, P1, P2, ldp, rows, K, N, pro, accumulate, xblk, yblk};
     static const bool tile_kernel = getenv("MPV_DTS_LIN_TILE") != nullptr;              // validation aid: the workgroup-tile kernel for every call
     if (!tile_kernel && K % 16 == 0 && N % 16 == 0) {
         const size_t wl = sizeof(float) * (size_t)N * (K + 4);
@@ -94,6 +99,7 @@ int lin(mpv_ctx* ctx, const float* X, int ldx, const float* W, const float* bias
         }
 #undef DTS_LINW
     }
+    if (xblk || yblk) return mpv_fail(ctx, MPV_ESTATE, "DiffusionTS: blocked operands need a dts_lin_wave_kernel instance");
     const size_t lds = sizeof(float) * (size_t)(N + LIN_TM) * (K + 4);
     if (int rc = set_lds(ctx, dts_lin_kernel, lds)) return rc;
     const long long tiles = (rows + LIN_TM - 1) / LIN_TM;
@@ -333,6 +339,10 @@ int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t, bool save)
     const float scale = 1.0f / std::sqrt((float)e.hd);
     const float* ada_t = e.ada + (size_t)t * e.n_ada * 2 * D;
     hipStream_t st = ctx->stream;
+    // blocked attention operands: block stride blk = T * 16 floats, every leading dimension 16, head h = block h (K: block H + h, V: 2 H + h)
+    const long long blk = e.blocked ? T * 16 : 0, hs = e.blocked ? T * 16 : e.hd;
+    const long long qo = e.blocked ? (long long)H * T * 16 : D;         // offset of the K part behind the Q part (V: twice that)
+    const int l3 = e.blocked ? 16 : 3 * D, l2 = e.blocked ? 16 : 2 * D, l1 = e.blocked ? 16 : D;
     hipLaunchKernelGGL(dts_embed_fwd_kernel, g1d(T * D), dim3(256), 0, st, x, e.wemb, e.bemb, e.pe_enc, e.pe_dec, L, F, D, T * D, e.xe[0], e.xd[0]);
     MPV_HIP_TRY(ctx, hipGetLastError());
     int ada_i = 0;
@@ -340,10 +350,10 @@ int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t, bool save)
         const EncW& w = e.enc[i];
         const DtsEngine::EncS& s = e.es[i];
         const float* sc = ada_t + (size_t)ada_i * 2 * D;
-        DTS_TRY(lin(ctx, e.xe[i], D, w.wqkv, w.bqkv, D, 3 * D, T, s.qkv, 3 * D, PRO_ADALN, sc, sc + D));
-        AttnArgs a{s.qkv, s.qkv + D, s.qkv + 2 * D, 3 * D, 3 * D, 3 * D, nullptr, nullptr, D, s.att, D, nullptr, 0, s.lse, nullptr, H, L, L, e.hd, scale};
+        DTS_TRY(lin(ctx, e.xe[i], D, w.wqkv, w.bqkv, D, 3 * D, T, s.qkv, l3, PRO_ADALN, sc, sc + D, 0, nullptr, 0, 0, 0, blk));
+        AttnArgs a{s.qkv, s.qkv + qo, s.qkv + 2 * qo, l3, l3, l3, nullptr, nullptr, l1, s.att, l1, nullptr, 0, s.lse, nullptr, H, L, L, e.hd, scale, hs};
         DTS_TRY(attn(ctx, 0, a, B, e.d.gemm != MPV_GEMM_F32));
-        DTS_TRY(lin(ctx, s.att, D, w.wp, w.bp, D, D, T, s.x1, D, PRO_NONE, nullptr, nullptr, 0, e.xe[i], D));
+        DTS_TRY(lin(ctx, s.att, l1, w.wp, w.bp, D, D, T, s.x1, D, PRO_NONE, nullptr, nullptr, 0, e.xe[i], D, 0, blk));
         DTS_TRY(mlp_block(ctx, e, s.x1, w.ln2w, w.ln2b, w.w0, w.b0, w.w2, w.b2, s.u, e.xe[i + 1], T, save));
     }
     const float* encout = e.xe[e.d.n_enc];
@@ -354,15 +364,15 @@ int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t, bool save)
         const DtsEngine::DecS& s = e.dsv[i];
         const float* sc1 = ada_t + (size_t)ada_i * 2 * D;
         const float* sc2 = sc1 + 2 * D;
-        DTS_TRY(lin(ctx, e.xd[i], D, w.wqkv1, w.bqkv1, D, 3 * D, T, s.qkv1, 3 * D, PRO_ADALN, sc1, sc1 + D));
-        AttnArgs a1{s.qkv1, s.qkv1 + D, s.qkv1 + 2 * D, 3 * D, 3 * D, 3 * D, nullptr, nullptr, D, s.att1, D, nullptr, 0, s.lse1, nullptr, H, L, L, e.hd, scale};
+        DTS_TRY(lin(ctx, e.xd[i], D, w.wqkv1, w.bqkv1, D, 3 * D, T, s.qkv1, l3, PRO_ADALN, sc1, sc1 + D, 0, nullptr, 0, 0, 0, blk));
+        AttnArgs a1{s.qkv1, s.qkv1 + qo, s.qkv1 + 2 * qo, l3, l3, l3, nullptr, nullptr, l1, s.att1, l1, nullptr, 0, s.lse1, nullptr, H, L, L, e.hd, scale, hs};
         DTS_TRY(attn(ctx, 0, a1, B, e.d.gemm != MPV_GEMM_F32));
-        DTS_TRY(lin(ctx, s.att1, D, w.wp1, w.bp1, D, D, T, s.x1, D, PRO_NONE, nullptr, nullptr, 0, e.xd[i], D));
-        DTS_TRY(lin(ctx, s.x1, D, w.wq2, w.bq2, D, D, T, s.q2, D, PRO_ADALN, sc2, sc2 + D));
-        DTS_TRY(lin(ctx, encout, D, w.wkv2, w.bkv2, D, 2 * D, T, s.kv2, 2 * D));
-        AttnArgs a2{s.q2, s.kv2, s.kv2 + D, D, 2 * D, 2 * D, nullptr, nullptr, D, s.att2, D, nullptr, 0, s.lse2, nullptr, H, L, L, e.hd, scale};
+        DTS_TRY(lin(ctx, s.att1, l1, w.wp1, w.bp1, D, D, T, s.x1, D, PRO_NONE, nullptr, nullptr, 0, e.xd[i], D, 0, blk));
+        DTS_TRY(lin(ctx, s.x1, D, w.wq2, w.bq2, D, D, T, s.q2, l1, PRO_ADALN, sc2, sc2 + D, 0, nullptr, 0, 0, 0, blk));
+        DTS_TRY(lin(ctx, encout, D, w.wkv2, w.bkv2, D, 2 * D, T, s.kv2, l2, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0, blk));
+        AttnArgs a2{s.q2, s.kv2, s.kv2 + qo, l1, l2, l2, nullptr, nullptr, l1, s.att2, l1, nullptr, 0, s.lse2, nullptr, H, L, L, e.hd, scale, hs};
         DTS_TRY(attn(ctx, 0, a2, B, e.d.gemm != MPV_GEMM_F32));
-        DTS_TRY(lin(ctx, s.att2, D, w.wp2, w.bp2, D, D, T, s.x2, D, PRO_NONE, nullptr, nullptr, 0, s.x1, D));
+        DTS_TRY(lin(ctx, s.att2, l1, w.wp2, w.bp2, D, D, T, s.x2, D, PRO_NONE, nullptr, nullptr, 0, s.x1, D, 0, blk));
         // proj (Conv1d(L -> 2L, k=1) over the token axis) folded into its two consumers: trend block on x2 with composite taps, and
         // the selected spectrum as ONE token mix with (DFT basis x proj[L:])
         hipLaunchKernelGGL(dts_trend_fwd_kernel, dim3(B), dim3(256), sizeof(float) * (15 * D + 3 * F), st, s.x2, (long long)L * D, w.tw0, w.tb0, w.tw3, w.tb3,
@@ -389,9 +399,11 @@ int attn_bwd(mpv_ctx* ctx, DtsEngine& e, int B, const float* Q, int ldq, const f
              float* lse, float* dq, int lddq, float* dk, float* dv, int lddkv) {
     const long long n = (long long)B * e.H * e.L;
     const float scale = 1.0f / std::sqrt((float)e.hd);
-    hipLaunchKernelGGL(dts_attn_delta_kernel, g1d(n), dim3(256), 0, ctx->stream, dO, O, e.D, e.H, e.L, e.hd, n, e.delta);   // n = tokens * heads
+    const long long hs = e.blocked ? (long long)B * e.L * 16 : e.hd;
+    const int ldo = e.blocked ? 16 : e.D;
+    hipLaunchKernelGGL(dts_attn_delta_kernel, g1d(n), dim3(256), 0, ctx->stream, dO, O, ldo, hs, e.H, e.L, e.hd, n, e.delta);   // n = tokens * heads
     MPV_HIP_TRY(ctx, hipGetLastError());
-    AttnArgs a{Q, K, V, ldq, ldkv, ldkv, dO, O, e.D, dq, lddq, nullptr, 0, lse, e.delta, e.H, e.L, e.L, e.hd, scale};
+    AttnArgs a{Q, K, V, ldq, ldkv, ldkv, dO, O, ldo, dq, lddq, nullptr, 0, lse, e.delta, e.H, e.L, e.L, e.hd, scale, hs};
     DTS_TRY(attn(ctx, 1, a, B, e.d.gemm != MPV_GEMM_F32));
     a.out = dk; a.ldout = lddkv; a.out2 = dv; a.ldout2 = lddkv;
     DTS_TRY(attn(ctx, 2, a, B, e.d.gemm != MPV_GEMM_F32));
@@ -404,6 +416,9 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
     const long long T = (long long)B * L;
     const float* ada_t = e.ada + (size_t)t * e.n_ada * 2 * D;
     hipStream_t st = ctx->stream;
+    const long long blk = e.blocked ? T * 16 : 0;                       // blocked attention operands, as in forward()
+    const long long qo = e.blocked ? (long long)e.H * T * 16 : D;
+    const int l3 = e.blocked ? 16 : 3 * D, l2 = e.blocked ? 16 : 2 * D, l1 = e.blocked ? 16 : D;
     // tail: d_h (decoder output) -> gA, d_season, d_means
     hipLaunchKernelGGL(dts_tail_bwd_kernel, dim3(B), dim3(256), 0, st, gout, e.winv, e.wcs, e.wcm, L, F, D, e.d.combine_taps, e.d.n_dec, e.gA, e.gseason,
                        e.gmeans);
@@ -441,15 +456,15 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
                            e.topk, e.NFp, gcur, (long long)L * D);
         MPV_HIP_TRY(ctx, hipGetLastError());
         // x2 = x1 + proj2(attn2(q2(ln1_1(x1)), kv2(enc)))
-        DTS_TRY(lin(ctx, gcur, D, w.wp2_t, nullptr, D, D, T, e.gC, D));                      // d_att2
-        DTS_TRY(attn_bwd(ctx, e, B, s.q2, D, s.kv2, s.kv2 + D, 2 * D, s.att2, e.gC, s.lse2, e.gqkv, D, e.gkv, e.gkv + D, 2 * D));
-        DTS_TRY(lin(ctx, e.gkv, 2 * D, w.wkv2_t, nullptr, 2 * D, D, T, e.genc, D, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 1));
-        DTS_TRY(lin(ctx, e.gqkv, D, w.wq2_t, nullptr, D, D, T, e.gC, D));
+        DTS_TRY(lin(ctx, gcur, D, w.wp2_t, nullptr, D, D, T, e.gC, l1, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0, blk));      // d_att2
+        DTS_TRY(attn_bwd(ctx, e, B, s.q2, l1, s.kv2, s.kv2 + qo, l2, s.att2, e.gC, s.lse2, e.gqkv, l1, e.gkv, e.gkv + qo, l2));
+        DTS_TRY(lin(ctx, e.gkv, l2, w.wkv2_t, nullptr, 2 * D, D, T, e.genc, D, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 1, blk));
+        DTS_TRY(lin(ctx, e.gqkv, l1, w.wq2_t, nullptr, D, D, T, e.gC, D, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 0, blk));
         DTS_TRY(ln_bwd(ctx, D, e.gC, s.x1, sc2, 1, gcur, 1, T));       // gcur = d_x1
         // x1 = x0 + proj1(attn1(qkv1(ln1(x0))))
-        DTS_TRY(lin(ctx, gcur, D, w.wp1_t, nullptr, D, D, T, e.gC, D));
-        DTS_TRY(attn_bwd(ctx, e, B, s.qkv1, 3 * D, s.qkv1 + D, s.qkv1 + 2 * D, 3 * D, s.att1, e.gC, s.lse1, e.gqkv, 3 * D, e.gqkv + D, e.gqkv + 2 * D, 3 * D));
-        DTS_TRY(lin(ctx, e.gqkv, 3 * D, w.wqkv1_t, nullptr, 3 * D, D, T, e.gC, D));
+        DTS_TRY(lin(ctx, gcur, D, w.wp1_t, nullptr, D, D, T, e.gC, l1, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0, blk));
+        DTS_TRY(attn_bwd(ctx, e, B, s.qkv1, l3, s.qkv1 + qo, s.qkv1 + 2 * qo, l3, s.att1, e.gC, s.lse1, e.gqkv, l3, e.gqkv + qo, e.gqkv + 2 * qo, l3));
+        DTS_TRY(lin(ctx, e.gqkv, l3, w.wqkv1_t, nullptr, 3 * D, D, T, e.gC, D, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 0, blk));
         DTS_TRY(ln_bwd(ctx, D, e.gC, e.xd[i], sc1, 1, gcur, 1, T));    // gcur = d_x0 = gradient w.r.t. the previous block's output
     }
     if (e.snapshots)                                                     // "g_enc" of mpv_dts_debug_tensor (gseason is free from here on)
@@ -473,9 +488,9 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
             DTS_TRY(lin(ctx, e.gwide, M, w.w0_t, nullptr, M, D, T, e.gC, D, PRO_GELUGRAD, s.u, nullptr, M));
         }
         DTS_TRY(ln_bwd(ctx, D, e.gC, s.x1, w.ln2w, 0, genc, 1, T));    // genc = d_x1
-        DTS_TRY(lin(ctx, genc, D, w.wp_t, nullptr, D, D, T, e.gC, D));
-        DTS_TRY(attn_bwd(ctx, e, B, s.qkv, 3 * D, s.qkv + D, s.qkv + 2 * D, 3 * D, s.att, e.gC, s.lse, e.gqkv, 3 * D, e.gqkv + D, e.gqkv + 2 * D, 3 * D));
-        DTS_TRY(lin(ctx, e.gqkv, 3 * D, w.wqkv_t, nullptr, 3 * D, D, T, e.gC, D));
+        DTS_TRY(lin(ctx, genc, D, w.wp_t, nullptr, D, D, T, e.gC, l1, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0, blk));
+        DTS_TRY(attn_bwd(ctx, e, B, s.qkv, l3, s.qkv + qo, s.qkv + 2 * qo, l3, s.att, e.gC, s.lse, e.gqkv, l3, e.gqkv + qo, e.gqkv + 2 * qo, l3));
+        DTS_TRY(lin(ctx, e.gqkv, l3, w.wqkv_t, nullptr, 3 * D, D, T, e.gC, D, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 0, blk));
         DTS_TRY(ln_bwd(ctx, D, e.gC, e.xe[i], sc, 1, genc, 1, T));     // genc = d_x0
     }
     (void)tmp;
@@ -529,6 +544,7 @@ int mpv_dts_load(mpv_ctx* ctx, const mpv_dts_desc* d, const float* const* tensor
     if (!e) return mpv_fail(ctx, MPV_ENOMEM, "mpv_dts_load: out of host memory");
     e->d = *d;
     e->L = L; e->F = F; e->D = D; e->H = H; e->hd = hd; e->M = d->mlp_times * D;
+    e->blocked = hd == 16 && !getenv("MPV_DTS_ROWMAJOR") && !getenv("MPV_DTS_LIN_TILE");
     e->NF = (L % 2 == 0) ? L / 2 - 1 : (L - 1) / 2;                      // rfft bins 1 .. (L/2 - 1 | (L-1)/2), transformer.py:66-73
     e->NFp = (e->NF + 15) & ~15;
     e->topk = (int)std::log((double)e->NF);                              // int(factor * log(length)), :93

@@ -169,11 +169,11 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_h_kernel(const AttnArgs p) {
     _Float16* VTh = Kl + Lkp * AH_RS;                      // [16][Lkp]
     _Float16* VTl = VTh + 16 * Lkp;
     float* red = reinterpret_cast<float*>(VTl + 16 * Lkp); // [4][2]
-    const float* Qb = p.Q + (long long)b * p.Lq * p.ldq + h * HD;
+    const float* Qb = p.Q + (long long)b * p.Lq * p.ldq + h * p.hs;
     HeadRegs kr, vr;
     float mx[2], sc[2];
-    mx[0] = head_load(p.K + (long long)b * p.Lk * p.ldk + h * HD, p.ldk, p.Lk, Lkp, kr);
-    mx[1] = head_load(p.V + (long long)b * p.Lk * p.ldv + h * HD, p.ldv, p.Lk, Lkp, vr);
+    mx[0] = head_load(p.K + (long long)b * p.Lk * p.ldk + h * p.hs, p.ldk, p.Lk, Lkp, kr);
+    mx[1] = head_load(p.V + (long long)b * p.Lk * p.ldv + h * p.hs, p.ldv, p.Lk, Lkp, vr);
     wg_scales<2>(mx, red, sc);
     head_store(kr, sc[0], Lkp, Kh, Kl, nullptr, nullptr);
     head_store(vr, sc[1], Lkp, nullptr, nullptr, VTh, VTl);
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_h_kernel(const AttnArgs p) {
         l += __shfl_xor(l, 32);
         if (jl) {
             const float inv = oinv / l;
-            float* dst = p.out + ((long long)b * p.Lq + j) * p.ldout + h * HD + 4 * g;
+            float* dst = p.out + ((long long)b * p.Lq + j) * p.ldout + h * p.hs + 4 * g;
             *reinterpret_cast<f32x4*>(dst) = o * inv;
             if (g == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Lq + j] = m + (__builtin_amdgcn_logf(l) - AH_PLOG);
         }
@@ -240,12 +240,12 @@ __global__ __launch_bounds__(256) void dts_attn_dq_h_kernel(const AttnArgs p) {
     _Float16* Vh = Kl + Lkp * AH_RS;
     _Float16* Vl = Vh + Lkp * AH_RS;
     float* red = reinterpret_cast<float*>(Vl + Lkp * AH_RS);      // [4][2]
-    const float* Qb = p.Q + (long long)b * p.Lq * p.ldq + h * HD;
-    const float* Db = p.dO + (long long)b * p.Lq * p.ldo + h * HD;
+    const float* Qb = p.Q + (long long)b * p.Lq * p.ldq + h * p.hs;
+    const float* Db = p.dO + (long long)b * p.Lq * p.ldo + h * p.hs;
     HeadRegs kr, vr;
     float mx[2], sc[2];
-    mx[0] = head_load(p.K + (long long)b * p.Lk * p.ldk + h * HD, p.ldk, p.Lk, Lkp, kr);
-    mx[1] = head_load(p.V + (long long)b * p.Lk * p.ldv + h * HD, p.ldv, p.Lk, Lkp, vr);
+    mx[0] = head_load(p.K + (long long)b * p.Lk * p.ldk + h * p.hs, p.ldk, p.Lk, Lkp, kr);
+    mx[1] = head_load(p.V + (long long)b * p.Lk * p.ldv + h * p.hs, p.ldv, p.Lk, Lkp, vr);
     wg_scales<2>(mx, red, sc);
     head_store(kr, sc[0], Lkp, Kh, Kl, nullptr, nullptr);
     head_store(vr, sc[1], Lkp, Vh, Vl, nullptr, nullptr);
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void dts_attn_dq_h_kernel(const AttnArgs p) {
             DTS_MMH3(part, th, tl, sh, sl);
             dq += part * (kinv / ssc);
         }
-        if (jl) *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lq + j) * p.ldout + h * HD + 4 * g) = dq;
+        if (jl) *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lq + j) * p.ldout + h * p.hs + 4 * g) = dq;
     }
 }
 
@@ -297,12 +297,12 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_h_kernel(const AttnArgs p) {
     float* lsel = reinterpret_cast<float*>(Dl + Lqp * AH_RS);    // [Lqp]
     float* dell = lsel + Lqp;                              // [Lqp]
     float* red = dell + Lqp;                               // [4][2]
-    const float* Kb = p.K + (long long)b * p.Lk * p.ldk + h * HD;
-    const float* Vb = p.V + (long long)b * p.Lk * p.ldv + h * HD;
+    const float* Kb = p.K + (long long)b * p.Lk * p.ldk + h * p.hs;
+    const float* Vb = p.V + (long long)b * p.Lk * p.ldv + h * p.hs;
     HeadRegs qr, dr;
     float mx[2], sc[2];
-    mx[0] = head_load(p.Q + (long long)b * p.Lq * p.ldq + h * HD, p.ldq, p.Lq, Lqp, qr);
-    mx[1] = head_load(p.dO + (long long)b * p.Lq * p.ldo + h * HD, p.ldo, p.Lq, Lqp, dr);
+    mx[0] = head_load(p.Q + (long long)b * p.Lq * p.ldq + h * p.hs, p.ldq, p.Lq, Lqp, qr);
+    mx[1] = head_load(p.dO + (long long)b * p.Lq * p.ldo + h * p.hs, p.ldo, p.Lq, Lqp, dr);
     wg_scales<2>(mx, red, sc);
     head_store(qr, sc[0], Lqp, Qh, Ql, nullptr, nullptr);
     head_store(dr, sc[1], Lqp, Dh, Dl, nullptr, nullptr);
@@ -347,8 +347,8 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_h_kernel(const AttnArgs p) {
             dk += part * (qinv / ssc);
         }
         if (jl) {
-            *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lk + j) * p.ldout + h * HD + 4 * g) = dk;
-            *reinterpret_cast<f32x4*>(p.out2 + ((long long)b * p.Lk + j) * p.ldout2 + h * HD + 4 * g) = dv * dvinv;
+            *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lk + j) * p.ldout + h * p.hs + 4 * g) = dk;
+            *reinterpret_cast<f32x4*>(p.out2 + ((long long)b * p.Lk + j) * p.ldout2 + h * p.hs + 4 * g) = dv * dvinv;
         }
     }
 }

@@ -45,6 +45,10 @@ struct LinArgs {
     int K, N;
     int pro;
     int accumulate;                 // Y += result
+    // 16-column BLOCKED operands (dts_lin_wave_kernel only): element (row, c) of X at X + (c / 16) xblk + row * ldx + c % 16 (ldx = 16), likewise Y with
+    // yblk; 0 = plain row-major.  The attention operands (Q | K | V, the attention output and their gradients) live in this layout, so that one
+    // (sequence, head) tile is contiguous: [block = which * H + head][rows][16].
+    long long xblk, yblk;
 };
 
 constexpr int LIN_TM = 64;          // tokens per workgroup pass
@@ -175,9 +179,10 @@ __global__ __launch_bounds__(64 * LINW_WAVES) void dts_lin_wave_kernel(const Lin
         const long long tok = tile * 16 + r16;
         const bool live = tok < p.rows;
         const float* xr = p.X + (live ? tok : 0) * (long long)p.ldx + 4 * g;
+        const long long xs = p.xblk ? p.xblk : 16, ys = p.yblk ? p.yblk : 16;
         f32x4 xb[KT];
 #pragma unroll
-        for (int s = 0; s < KT; ++s) xb[s] = live ? *reinterpret_cast<const f32x4*>(xr + 16 * s) : f32x4{0, 0, 0, 0};
+        for (int s = 0; s < KT; ++s) xb[s] = live ? *reinterpret_cast<const f32x4*>(xr + xs * s) : f32x4{0, 0, 0, 0};
         if (p.pro == PRO_LN || p.pro == PRO_ADALN) {
             float sum = 0.0f;
 #pragma unroll
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(64 * LINW_WAVES) void dts_lin_wave_kernel(const Lin
             f32x4 addend = {0, 0, 0, 0};            // what the epilogue adds is requested before the MFMAs of this block
             if (live) {
                 if (p.R) addend = *reinterpret_cast<const f32x4*>(p.R + tok * (long long)p.ldr + n0);
-                if (p.accumulate) addend += *reinterpret_cast<const f32x4*>(p.Y + tok * (long long)p.ldy + n0);
+                if (p.accumulate) addend += *reinterpret_cast<const f32x4*>(p.Y + tok * (long long)p.ldy + ys * nt + 4 * g);
             }
             f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
             const float* wa = Wl + (16 * nt + r16) * KS + 4 * g;
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(64 * LINW_WAVES) void dts_lin_wave_kernel(const Lin
                 f32x4 v = acc0 + acc1;
                 if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n0);
                 v += addend;
-                *reinterpret_cast<f32x4*>(p.Y + tok * (long long)p.ldy + n0) = v;
+                *reinterpret_cast<f32x4*>(p.Y + tok * (long long)p.ldy + ys * nt + 4 * g) = v;
             }
         }
     }
@@ -370,7 +375,8 @@ struct AttnArgs {
     const float* delta;                             // [B][H][Lq]
     int H, Lq, Lk, hd;
     float scale;
-};
+    long long hs;                                   // offset of head h's columns: h * hs floats.  Row-major token rows [rows][H hd]: hs = hd, ld = the row
+};                                                  // width; 16-column BLOCKED buffers [block][rows][16] (dts.hip): hs = rows * 16, every ld = 16
 
 template <int E>
 __device__ __forceinline__ void load_frag(const float* p, float (&f)[E]) {
@@ -408,8 +414,8 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_kernel(const AttnArgs p) {
     const int Lkp = (p.Lk + 15) & ~15, TS = Lkp + 4;
     float* Kl = lds;                       // [Lkp][RS]
     float* VT = Kl + Lkp * RS;             // [16][TS]
-    stage_head<E>(p.K + (long long)b * p.Lk * p.ldk + h * HD, p.ldk, p.Lk, Lkp, Kl, nullptr);
-    stage_head<E>(p.V + (long long)b * p.Lk * p.ldv + h * HD, p.ldv, p.Lk, Lkp, nullptr, VT);
+    stage_head<E>(p.K + (long long)b * p.Lk * p.ldk + h * p.hs, p.ldk, p.Lk, Lkp, Kl, nullptr);
+    stage_head<E>(p.V + (long long)b * p.Lk * p.ldv + h * p.hs, p.ldv, p.Lk, Lkp, nullptr, VT);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
     const float c = p.scale * LOG2E;
@@ -417,7 +423,7 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_kernel(const AttnArgs p) {
         const int j = 16 * jt + r16;
         const bool jl = j < p.Lq;
         float qf[E];
-        load_frag<E>(p.Q + ((long long)b * p.Lq + (jl ? j : 0)) * p.ldq + h * HD + E * g, qf);
+        load_frag<E>(p.Q + ((long long)b * p.Lq + (jl ? j : 0)) * p.ldq + h * p.hs + E * g, qf);
         float m = -INFINITY, l = 0.0f;
         f32x4 o = {0, 0, 0, 0};
         for (int it = 0; it < (Lkp >> 4); ++it) {
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_kernel(const AttnArgs p) {
         if (jl) {
             if (4 * g < HD) {
                 const float inv = 1.0f / l;
-                float* dst = p.out + ((long long)b * p.Lq + j) * p.ldout + h * HD + 4 * g;
+                float* dst = p.out + ((long long)b * p.Lq + j) * p.ldout + h * p.hs + 4 * g;
                 *reinterpret_cast<f32x4*>(dst) = o * inv;
             }
             if (g == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Lq + j] = m + __builtin_amdgcn_logf(l);
@@ -463,15 +469,15 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_kernel(const AttnArgs p) {
 }
 
 // delta[b][h][q] = sum_d dO[q][d] O[q][d]; thread per (token, head), heads fastest: a wave reads 64 consecutive head slices
-__global__ void dts_attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O, int ld, int H, int L, int hd, long long n, float* delta) {
+__global__ void dts_attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O, int ld, long long hs, int H, int L, int hd, long long n, float* delta) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // tok*H + h
     if (i >= n) return;
     const int h = (int)(i % H);
     const long long tok = i / H;
     const long long b = tok / L;
     const int q = (int)(tok - b * L);
-    const float* a = dO + tok * ld + h * hd;
-    const float* o = O + tok * ld + h * hd;
+    const float* a = dO + tok * ld + h * hs;
+    const float* o = O + tok * ld + h * hs;
     float s = 0.0f;
     for (int d = 0; d < hd; d += 4) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(a + d), y = *reinterpret_cast<const f32x4*>(o + d);
@@ -489,8 +495,8 @@ __global__ __launch_bounds__(256) void dts_attn_dq_kernel(const AttnArgs p) {
     float* Kl = lds;                       // [Lkp][RS]
     float* Vl = Kl + Lkp * RS;             // [Lkp][RS]
     // (no transposed copy of K: the dS.K operand is read column-wise out of Kl with four ds_read_b32 -- 27 % less LDS, one more workgroup per CU)
-    stage_head<E>(p.K + (long long)b * p.Lk * p.ldk + h * HD, p.ldk, p.Lk, Lkp, Kl, nullptr);
-    stage_head<E>(p.V + (long long)b * p.Lk * p.ldv + h * HD, p.ldv, p.Lk, Lkp, Vl, nullptr);
+    stage_head<E>(p.K + (long long)b * p.Lk * p.ldk + h * p.hs, p.ldk, p.Lk, Lkp, Kl, nullptr);
+    stage_head<E>(p.V + (long long)b * p.Lk * p.ldv + h * p.hs, p.ldv, p.Lk, Lkp, Vl, nullptr);
     if (HD < 16) {                         // columns HD..15 of the padded rows are read by lanes r16 >= HD: keep them finite
         for (int i = threadIdx.x; i < Lkp * 4; i += 256) Kl[(i >> 2) * RS + HD + (i & 3)] = 0.0f;
     }
@@ -502,8 +508,8 @@ __global__ __launch_bounds__(256) void dts_attn_dq_kernel(const AttnArgs p) {
         const bool jl = j < p.Lq;
         const long long tok = (long long)b * p.Lq + (jl ? j : 0);
         float qf[E], df[E];
-        load_frag<E>(p.Q + tok * p.ldq + h * HD + E * g, qf);
-        load_frag<E>(p.dO + tok * p.ldo + h * HD + E * g, df);
+        load_frag<E>(p.Q + tok * p.ldq + h * p.hs + E * g, qf);
+        load_frag<E>(p.dO + tok * p.ldo + h * p.hs + E * g, df);
         const float lse = p.lse[((long long)b * p.H + h) * p.Lq + (jl ? j : 0)];
         const float del = p.delta[((long long)b * p.H + h) * p.Lq + (jl ? j : 0)];
         f32x4 dq = {0, 0, 0, 0};
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(256) void dts_attn_dq_kernel(const AttnArgs p) {
             for (int r = 0; r < 4; ++r) DTS_MMA(dq, (r16 < HD ? kc[r * RS] : 0.0f), s[r]);
         }
         if (jl && 4 * g < HD)
-            *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lq + j) * p.ldout + h * HD + 4 * g) = dq;
+            *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lq + j) * p.ldout + h * p.hs + 4 * g) = dq;
     }
 }
 
@@ -542,8 +548,8 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_kernel(const AttnArgs p) {
     float* lsel = Dl + Lqp * RS;           // [Lqp]
     float* dell = lsel + Lqp;              // [Lqp]
     // (no transposed copies: the P^T.dO and dS^T.Q operands are read column-wise out of Dl / Ql -- 44 % less LDS, twice the workgroups per CU)
-    stage_head<E>(p.Q + (long long)b * p.Lq * p.ldq + h * HD, p.ldq, p.Lq, Lqp, Ql, nullptr);
-    stage_head<E>(p.dO + (long long)b * p.Lq * p.ldo + h * HD, p.ldo, p.Lq, Lqp, Dl, nullptr);
+    stage_head<E>(p.Q + (long long)b * p.Lq * p.ldq + h * p.hs, p.ldq, p.Lq, Lqp, Ql, nullptr);
+    stage_head<E>(p.dO + (long long)b * p.Lq * p.ldo + h * p.hs, p.ldo, p.Lq, Lqp, Dl, nullptr);
     for (int i = threadIdx.x; i < Lqp; i += 256) {
         lsel[i] = i < p.Lq ? p.lse[((long long)b * p.H + h) * p.Lq + i] : INFINITY;     // padded queries: P = 0
         dell[i] = i < p.Lq ? p.delta[((long long)b * p.H + h) * p.Lq + i] : 0.0f;
@@ -556,8 +562,8 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_kernel(const AttnArgs p) {
         const bool jl = j < p.Lk;
         const long long tok = (long long)b * p.Lk + (jl ? j : 0);
         float kf[E], vf[E];
-        load_frag<E>(p.K + tok * p.ldk + h * HD + E * g, kf);
-        load_frag<E>(p.V + tok * p.ldv + h * HD + E * g, vf);
+        load_frag<E>(p.K + tok * p.ldk + h * p.hs + E * g, kf);
+        load_frag<E>(p.V + tok * p.ldv + h * p.hs + E * g, vf);
         f32x4 dk = {0, 0, 0, 0}, dv = {0, 0, 0, 0};
         for (int it = 0; it < (Lqp >> 4); ++it) {
             float qa[E], da[E];
@@ -586,8 +592,8 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_kernel(const AttnArgs p) {
             }
         }
         if (jl && 4 * g < HD) {
-            *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lk + j) * p.ldout + h * HD + 4 * g) = dk;
-            *reinterpret_cast<f32x4*>(p.out2 + ((long long)b * p.Lk + j) * p.ldout2 + h * HD + 4 * g) = dv;
+            *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lk + j) * p.ldout + h * p.hs + 4 * g) = dk;
+            *reinterpret_cast<f32x4*>(p.out2 + ((long long)b * p.Lk + j) * p.ldout2 + h * p.hs + 4 * g) = dv;
         }
     }
 }
