@@ -241,7 +241,7 @@ int mpv_dts_vjp(mpv_ctx* ctx, const float* x, int32_t B, int32_t t, const float*
  * "season_sum", "means"; after mpv_dts_vjp also "g_enc", the gradient at the encoder output) into out (dev). */
 int mpv_dts_debug_tensor(mpv_ctx* ctx, const char* name, int32_t index, float* out, int64_t n_floats);
 
-#define MPV_DTS_PLAN_COLS 10
+#define MPV_DTS_PLAN_COLS 11
 typedef struct {
     int32_t n_windows;     /* W evaluation_step calls batched in this call                                   */
     int32_t nodes;         /* V = batch rows of one evaluation_step                                           */
@@ -257,9 +257,11 @@ typedef struct {
 /* history: dev [W][V][windows][F] scaled windows.  plan: HOST [n_pairs][MPV_DTS_PLAN_COLS], one row per DDIM pair
  * (time, time_next) of fast_sample_infill, built by the host with the reference's fp32 ops: 0 time, 1 time_next,
  * 2 sqrt_recip_alphas_cumprod[time], 3 sqrt_recipm1_alphas_cumprod[time], 4 sqrt(alpha_next), 5 sqrt(1 - alpha_next) (eta = 0),
- * 6 K Langevin iterations, 7 their learning rate, 8 sqrt_alphas_cumprod[time], 9 sqrt_one_minus_alphas_cumprod[time].
+ * 6 K Langevin iterations, 7 their learning rate, 8 sqrt_alphas_cumprod[time], 9 sqrt_one_minus_alphas_cumprod[time], 10 sigma of the pair
+ * (eta sqrt((1 - a/a_next)(1 - a_next)/(1 - a)); 0 for eta = 0, then column 5 is sqrt(1 - alpha_next); otherwise column 5 = sqrt(1 - alpha_next -
+ * sigma^2), the step adds sigma * noise and both Langevin loss terms are divided by sigma, DiffusionTS.py:294-300, 392-395).
  * noise: dev or NULL.  When given: for chunk c < S/par, every normal draw of the reference in its order -- img,
- * then per pair with time_next >= 0: the sigma = 0 `noise`, K Langevin epsilons (both drawn but unused), q_sample's noise --
+ * then per pair with time_next >= 0: the step's `noise` (used when sigma != 0), K Langevin epsilons (drawn but unused: coef_ = 0), q_sample's noise --
  * each draw a tensor [W][par*V][L][F] (the W windows' streams side by side).  NULL: Philox4x32-10 for the draws that are used.
  * samples: dev [W][V][pred_len][F][S]; window w's slice is the reference's `outs`. */
 int mpv_dts_sample(mpv_ctx* ctx, const mpv_dts_sample_shape* shape, const float* history, const float* plan, const float* noise,

@@ -69,3 +69,36 @@ def test_evaluation_step_with_the_reference_noise_stream(gold, tag):
     with pytest.raises(ValueError):
         D.evaluation_step(sd, D.DTSConfig(cfg.windows, cfg.pred_len, cfg.nf, n_z_samples=5, parallel_sample=2), T(gold["batch_%s" % tag]),
                           lambda s: torch.zeros(s))
+
+
+def test_eta_sampler_matches_reference_and_host_plan_carries_sigma():
+    """eta != 0 (reference DiffusionTS.py:294-300, 392-395: stochastic DDIM step, sigma-weighted Langevin terms): the oracle against
+    evaluation_step recorded from the reference (tests/golden/make_golden_diffusionts_eta.py, the `small` model), and the host plan's sigma
+    column against the reference's formula."""
+    from conftest import GOLDEN
+    from mpv_amd.models.models import diffusion_models
+    z, ze = np.load(GOLDEN / "diffusionts_cases.npz"), np.load(GOLDEN / "diffusionts_eta_cases.npz")
+    keys = ("windows", "pred_len", "dataset_nf", "d_model", "n_layer_enc", "n_layer_dec", "n_heads", "timesteps", "diffusion_steps", "n_z_samples", "parallel_sample")
+    par = dict(zip(keys, [int(v) for v in z["cfg_small"]]))
+    sd = {k[len("sd_small_"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_small_")}
+    L = par["windows"] + par["pred_len"]
+    for tag, eta in (("eta05", 0.5), ("eta1", 1.0)):
+        cfg = D.DTSConfig(par["windows"], par["pred_len"], par["dataset_nf"], par["d_model"], par["n_layer_enc"], par["n_layer_dec"], par["n_heads"],
+                          par["timesteps"], par["diffusion_steps"], n_z_samples=4, parallel_sample=2, eta=eta)
+        it = iter(torch.from_numpy(ze["eval_%s_noise" % tag]).reshape(-1, 4, L, par["dataset_nf"]).unbind(0))
+        out = D.evaluation_step(sd, cfg, torch.from_numpy(ze["batch"]), lambda shape: next(it))
+        assert torch.equal(out, torch.from_numpy(ze["eval_%s_out" % tag]))
+        m = diffusion_models("DiffusionTS", dict(par, eta=eta, device="cpu", scaler_type="StandardScaler"))
+        plan = m._plan()
+        assert tuple(plan.shape) == (par["diffusion_steps"], 11)
+        tb = D.schedule_tables(par["timesteps"])
+        for row in plan.tolist():
+            t, tn = int(row[0]), int(row[1])
+            if tn < 0:
+                assert row[10] == 0.0
+                continue
+            a, an = tb["alphas_cumprod"][t], tb["alphas_cumprod"][tn]
+            sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+            assert row[10] == float(sigma) and row[5] == float((1 - an - sigma ** 2).sqrt())
+    m0 = diffusion_models("DiffusionTS", dict(par, device="cpu", scaler_type="StandardScaler"))
+    assert float(m0._plan()[:, 10].abs().max()) == 0.0

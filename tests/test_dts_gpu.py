@@ -180,3 +180,23 @@ def test_dts_c_abi_error_paths():
     assert lib.mpv_dts_forward(c._h, C.c_void_p(x.data_ptr()), 1, 999, C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr())) < 0
     d = _native.DtsDesc(20, 2, 48, 2, 1, 1, 4, 10, 1)
     assert lib.mpv_dts_load(c._h, C.byref(d), None, 0, None, None, None) < 0
+
+
+@pytest.mark.parametrize("gemm", ["f16x3", "f32"])
+@pytest.mark.parametrize("tag,eta", [("eta05", 0.5), ("eta1", 1.0)])
+def test_evaluation_step_with_eta_matches_reference(tag, eta, gemm):
+    """eta != 0: the DDIM step adds sigma * noise and both Langevin loss terms are divided by sigma (reference DiffusionTS.py:294-300,
+    392-395); the reference's evaluation_step on the `small` model with every normal draw injected in its order."""
+    from conftest import GOLDEN
+    ze = np.load(GOLDEN / "diffusionts_eta_cases.npz")
+    m, par = build("small", eta=eta, gemm_mode=gemm)
+    outs, _ = m.evaluation_step(T(ze["batch"]), noise=T(ze["eval_%s_noise" % tag]))
+    want = ze["eval_%s_out" % tag]
+    err = rel_err(outs, want)
+    mpv_g, mpv_w = outs.var(dim=-1, unbiased=False).mean().item(), T(want).var(dim=-1, unbiased=False).mean().item()
+    print("DiffusionTS evaluation_step eta=%.1f (%s): samples rel err %.3e, MPV %.6g vs %.6g" % (eta, gemm, err, mpv_g, mpv_w))
+    assert err < 1e-2 and abs(mpv_g - mpv_w) <= RTOL * abs(mpv_w)
+    m0, _ = build("small", eta=eta, noise_source="torch_cpu")
+    torch.manual_seed(77)
+    o2, _ = m0.evaluation_step(T(ze["batch"]))
+    assert rel_err(o2, want) < 1e-2                                   # the reference's own seed replays its run (the step's noise is now consumed)

@@ -66,7 +66,7 @@ class DtsSampleShape(C.Structure):
                 ("n_pairs", C.c_int32), ("infill_coef", C.c_float), ("rows_per_pass", C.c_int32), ("seed", C.c_uint64)]
 
 
-DTS_PLAN_COLS = 10
+DTS_PLAN_COLS = 11
 
 
 class StgDesc(C.Structure):

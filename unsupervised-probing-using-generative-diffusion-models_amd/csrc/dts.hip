@@ -791,16 +791,24 @@ int mpv_dts_sample(mpv_ctx* ctx, const mpv_dts_sample_shape* s, const float* his
                 hipLaunchKernelGGL(dts_predict_kernel, g1d(n), dim3(256), 0, st, e.img, e.trend, e.season, kc, last ? 1 : 0, n, e.xstart, e.pmean);
                 MPV_HIP_TRY(ctx, hipGetLastError());
                 if (last) break;
-                DTS_TRY(next_noise(false, nullptr));                     // `noise` of :300, multiplied by sigma = 0
-                // img = pred_mean; Langevin refinement of the whole tensor (:359-407)
-                MPV_HIP_TRY(ctx, hipMemcpyAsync(e.img, e.pmean, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+                const float sigma = pr[10];                              // eta sqrt(...) of the pair; 0 for the DDIM sampler every shipped config uses
+                DTS_TRY(next_noise(sigma != 0.0f, e.noise));             // `noise` of :300
+                // img = pred_mean + sigma noise; Langevin refinement of the whole tensor (:359-407)
+                if (sigma != 0.0f) {
+                    hipLaunchKernelGGL(dts_add_noise_kernel, g1d(n), dim3(256), 0, st, e.pmean, e.noise, sigma, n, e.img);
+                    MPV_HIP_TRY(ctx, hipGetLastError());
+                } else {
+                    MPV_HIP_TRY(ctx, hipMemcpyAsync(e.img, e.pmean, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+                }
+                // sigma != 0: both loss terms of langevin_fn are divided by sigma (:392-395), i.e. their gradients are
+                const float inv_nmask_s = sigma != 0.0f ? inv_nmask / sigma : inv_nmask, coef_s = sigma != 0.0f ? coef_over_b / sigma : coef_over_b;
                 const int K = (int)pr[6];
                 for (int it = 0; it < K; ++it) {
                     DTS_TRY(forward(ctx, e, e.img, B, time, true));
-                    hipLaunchKernelGGL(dts_infill_grad_kernel, g1d(n), dim3(256), 0, st, e.trend, e.season, e.target, L, F, s->windows, inv_nmask, n, e.gout);
+                    hipLaunchKernelGGL(dts_infill_grad_kernel, g1d(n), dim3(256), 0, st, e.trend, e.season, e.target, L, F, s->windows, inv_nmask_s, n, e.gout);
                     MPV_HIP_TRY(ctx, hipGetLastError());
                     DTS_TRY(backward(ctx, e, e.gout, e.gx, B, time));
-                    hipLaunchKernelGGL(dts_langevin_step_kernel, g1d(n), dim3(256), 0, st, e.gx, e.pmean, coef_over_b, pr[7], n, e.img);
+                    hipLaunchKernelGGL(dts_langevin_step_kernel, g1d(n), dim3(256), 0, st, e.gx, e.pmean, coef_s, pr[7], n, e.img);
                     MPV_HIP_TRY(ctx, hipGetLastError());
                     DTS_TRY(next_noise(false, nullptr));                 // epsilon of :403, multiplied by coef_ = 0
                 }

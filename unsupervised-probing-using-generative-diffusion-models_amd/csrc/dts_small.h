@@ -424,6 +424,14 @@ __global__ void dts_predict_kernel(const float* __restrict__ img, const float* _
     pred_mean[i] = xs * k.sa + k.c * pn;
 }
 
+// img = pred_mean + sigma * noise   (the stochastic DDIM step, eta != 0: DiffusionTS.py:300)
+__global__ void dts_add_noise_kernel(const float* __restrict__ pmean, const float* __restrict__ noise, float sigma, long long n, float* img) {
+#pragma clang fp contract(off)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    img[i] = pmean[i] + sigma * noise[i];
+}
+
 // g_out = d(infill)/d(x_start): 2 (x_start - target) / N_masked on the observed part (x_start NOT clamped here, :389)
 __global__ void dts_infill_grad_kernel(const float* __restrict__ trend, const float* __restrict__ season, const float* __restrict__ target, int L, int F,
                                        int windows, float inv_nmask, long long n, float* gout) {

@@ -63,21 +63,20 @@ class Diffusion_TS(nn.Module):
 
     # ---- scalar plan of fast_sample_infill (reference :277-310, 359-381) ------------------------------------------
     def infill_plan(self, sampling_timesteps: int, learning_rate: float) -> torch.Tensor:
-        """One row per DDIM pair (time, time_next), float32 [n_pairs][8]:
+        """One row per DDIM pair (time, time_next), float32 [n_pairs][9]:
         0 time, 1 time_next, 2 sqrt_recip_alphas_cumprod[time], 3 sqrt_recipm1_alphas_cumprod[time],
-        4 sqrt(alpha_next), 5 c = sqrt(1 - alpha_next)  (eta = 0), 6 K Langevin iterations, 7 their learning rate;
-        rows with time_next < 0 carry zeros in 4..7.  Evaluated with the reference's fp32 tensor ops."""
-        if float(self.eta) != 0.0:
-            raise NotImplementedError("the native DiffusionTS sampler implements the eta = 0 (DDIM) branch of "
-                                      "fast_sample_infill; every shipped config uses it")
+        4 sqrt(alpha_next), 5 c = sqrt(1 - alpha_next - sigma^2), 6 K Langevin iterations, 7 their learning rate,
+        8 sigma = eta sqrt((1 - alpha / alpha_next)(1 - alpha_next) / (1 - alpha))  (0 for eta = 0, the shipped configs);
+        rows with time_next < 0 carry zeros in 4..8.  Evaluated with the reference's fp32 tensor ops (:294-297)."""
         T = self.num_timesteps
         times = list(reversed(torch.linspace(-1, T - 1, steps=sampling_timesteps + 1).int().tolist()))
         rows = []
         for time, time_next in zip(times[:-1], times[1:]):
-            r = [float(time), float(time_next), float(self.sqrt_recip_alphas_cumprod[time]), float(self.sqrt_recipm1_alphas_cumprod[time]), 0.0, 0.0, 0.0, 0.0]
+            r = [float(time), float(time_next), float(self.sqrt_recip_alphas_cumprod[time]), float(self.sqrt_recipm1_alphas_cumprod[time]), 0.0, 0.0, 0.0, 0.0, 0.0]
             if time_next >= 0:
                 alpha_next = self.alphas_cumprod[time_next].float().cpu()
-                sigma = 0.0 * ((1 - self.alphas_cumprod[time].cpu() / alpha_next) * (1 - alpha_next) / (1 - self.alphas_cumprod[time].cpu())).sqrt()
+                sigma = self.eta * ((1 - self.alphas_cumprod[time].cpu() / alpha_next) * (1 - alpha_next) / (1 - self.alphas_cumprod[time].cpu())).sqrt()
+                r[8] = float(sigma)
                 r[4] = float(alpha_next.sqrt())
                 r[5] = float((1 - alpha_next - sigma ** 2).sqrt())
                 lr = learning_rate

@@ -111,7 +111,7 @@ class DiffusionTS_model(nn.Module):
         plan = self.model.infill_plan(self.sampling_timesteps, lr)
         t = plan[:, 0].long()
         extra = torch.stack([self.model.sqrt_alphas_cumprod.cpu()[t], self.model.sqrt_one_minus_alphas_cumprod.cpu()[t]], dim=1)
-        return torch.cat([plan, extra], dim=1).contiguous()
+        return torch.cat([plan[:, :8], extra, plan[:, 8:9]], dim=1).contiguous()        # MPV_DTS_PLAN_COLS = 11: sigma last
 
     def host_noise(self, n_windows: int, nodes: int) -> torch.Tensor:
         """Every normal draw of `n_windows` evaluation_step calls with torch.randn on the CPU in the reference's order (window,
