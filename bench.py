@@ -539,7 +539,9 @@ def cpu_baseline_and_parity(model, sampled, n_cpu_windows, modes):
             _, _, mpv, _ = model.sample_windows(x, 1, 0, 1, noise=z6, summary=True, want_samples=False)
             gpu_mpv.append(float(mpv[0]))
         gpu_mpv = np.array(gpu_mpv)
+        ulp = np.spacing(np.abs(cpu_mpv).astype(np.float32)).astype(np.float64)           # the curve is float32: its spacing at each window's MPV
         per_mode[gemm] = {"mpv_max_abs_err": float(np.abs(gpu_mpv - cpu_mpv).max()),
+                          "mpv_max_abs_err_ulps": float((np.abs(gpu_mpv - cpu_mpv) / ulp).max()),
                           "mpv_max_rel_err": float((np.abs(gpu_mpv - cpu_mpv) / np.abs(cpu_mpv)).max()),
                           "samples_max_rel_err": samp_err}
     model.gemm_mode = modes[0]
