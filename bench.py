@@ -319,6 +319,7 @@ def main():
 
     if extras and not args.no_other_configs and args.max_windows is None:
         out["other_configs"] = other_config_records(args, device)
+        out["other_families"] = other_family_records(args, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         parity = cpu_baseline_and_parity(model, sampled, args.cpu_windows, [args.gemm] + others)
         for g, err in parity.pop("per_mode").items():
@@ -354,6 +355,20 @@ def other_config_records(args, device):
         except Exception as exc:                   # noqa: BLE001
             recs[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             log("other config %s failed: %s" % (key, recs[key]["error"]))
+        torch.cuda.empty_cache()
+    return recs
+
+
+def other_family_records(args, device):
+    """Secondary records of the model families BASELINE.json's configs do not name (NsDiff_spatial, TMDM): mpv_amd/bench_families.py."""
+    recs = {}
+    for key, fn in (("nsdiff_spatial", "record_nsdiff_spatial"), ("tmdm", "record_tmdm")):
+        try:
+            import importlib
+            recs[key] = getattr(importlib.import_module("mpv_amd.bench_families"), fn)(device, log, cpu=not args.no_cpu_baseline)
+        except Exception as exc:                   # noqa: BLE001
+            recs[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            log("other family %s failed: %s" % (key, recs[key]["error"]))
         torch.cuda.empty_cache()
     return recs
 
