@@ -18,7 +18,7 @@ PKG = ROOT / "unsupervised-probing-using-generative-diffusion-models_amd"
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-I", str(ROOT / "include"),
-               "-I", str(PKG / "csrc"), "-c", str(PKG / "csrc" / "nsdiff_chain_f16.hip"), "-o", tmp + "/f16.o", "-save-temps"]
+               "-I", str(PKG / "csrc"), "-c", str(PKG / "csrc" / "nsdiff_chain_f16.hip"), "-o", tmp + "/f16.o", "-save-temps"] + [a for a in sys.argv[1:] if a.startswith("-D")]
         subprocess.run(cmd, cwd=tmp, check=True, capture_output=True)
         asm = next(Path(tmp).glob("*gfx950.s")).read_text()
     bad = 0

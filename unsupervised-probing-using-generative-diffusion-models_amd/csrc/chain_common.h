@@ -36,6 +36,7 @@ struct ChainArgs {
     const unsigned short* w1img;   // layer 1 as MFMA k-slots: [128][16*NK] f16 (nsdiff_chain_f16.hip::L1)
     const unsigned *b2p, *b3p;     // layer 2/3 biases, (hi | lo << 16) f16 pairs of b * 2^sB
     const float *g1, *g2, *g3, *wsl;
+    const unsigned *gs2, *gs3;     // g2, g3 as bf16 outer-product A operands: [T*128 + 128 zero entries][4 words]
     const float* w4h;              // eps head as the split-f16 kernel stages it (x ln2 for TMDM, whose activations are not normalised)
     float bone2, bone3;            // bias k-slot constant of layers 2, 3: 2^(sW - sB)  (x the B-operand scale)
     float l1_scale;                // 2^(s1 + 4): scale of the layer-1 accumulators
@@ -143,22 +144,40 @@ struct StepCoef {
 
 // One element of p_sample / p_sample_t_1to0 (nsdiff_utils.py:131-157, 209-239).  Contraction is
 // off so each product and sum rounds once, as the reference's eager fp32 tensor ops do.
+// FAST (split-f16 sampler only, whose network output already differs from fp32 in the seventh digit): v_sqrt_f32 for the
+// three square roots and one Newton-refined v_rcp_f32 per denominator instead of the IEEE division / square-root sequences
+// (each <= 1-2 ulp; a negative discriminant still gives NaN, as in the reference).
+template <bool FAST = false>
 __device__ __forceinline__ float posterior(const StepCoef& c, float y, float mu, float g, float eps, float sig, float z,
                                            bool last) {
 #pragma clang fp contract(off)
+    auto root = [](float x) { return FAST ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); };
+    auto recip = [](float d) {
+        const float r = __builtin_amdgcn_rcpf(d);
+        return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    };
     const float lam1 = c.c1 * g - sig * c.c2;
     const float lam2 = g * g * c.q1 * c.q2 - sig * g * c.c4;
-    const float sy0 = (-lam1 + sqrtf(lam1 * lam1 - c.l4 * lam2)) / c.l2;   // NaN if disc < 0, as reference
+    const float num = -lam1 + root(lam1 * lam1 - c.l4 * lam2);              // NaN if disc < 0, as reference
+    const float sy0 = FAST ? num * recip(c.l2) : num / c.l2;
     const float nz = c.n1 * g + c.bt * sy0;
-    const float y0r = c.invr * (y - c.omr * mu - eps * sqrtf(nz));
+    const float y0r = c.invr * (y - c.omr * mu - eps * root(nz));
     if (last) return y0r;
     const float s1 = c.q1 * g + c.aoma * sy0;
     const float s2 = c.q2 * g + c.bt1 * sy0;
     const float den = c.a * s2 + s1;
-    const float g0 = c.sp * s1 / den;
-    const float g1 = c.sa * s2 / den;
-    const float g2 = (c.k1 * s2 + c.k2 * s1) / den;
-    return g0 * y0r + g1 * y + g2 * mu + sqrtf(sig) * z;
+    float g0, g1, g2;
+    if (FAST) {
+        const float r = recip(den);
+        g0 = c.sp * s1 * r;
+        g1 = c.sa * s2 * r;
+        g2 = (c.k1 * s2 + c.k2 * s1) * r;
+    } else {
+        g0 = c.sp * s1 / den;
+        g1 = c.sa * s2 / den;
+        g2 = (c.k1 * s2 + c.k2 * s1) / den;
+    }
+    return g0 * y0r + g1 * y + g2 * mu + root(sig) * z;
 }
 
 

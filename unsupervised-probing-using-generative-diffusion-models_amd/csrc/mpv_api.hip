@@ -168,6 +168,31 @@ static int load_chain_model(mpv_ctx* ctx, NsdiffModel& m, int T, int F, const mp
         g3[i] = std::ldexp(w->embed[2][i] * LOG2E, -sW[2]);
     }
     for (size_t i = 0; i < (size_t)F * H; ++i) wsl[i] = w->sig_w[i] * LN2;
+    // scale rows of layers 2, 3 as A operands of the bf16 outer product  S[row][chain] = g''[row] / ||l||[chain]  (one
+    // v_mfma_f32_32x32x16_bf16 per activation tile): three-term bf16 split g = g0 + g1 + g2 (24 bits, fp32 range), k-slots
+    // (g0, g1, g2, g0, g1, g0, 0, 0) against (m0, m0, m0, m1, m1, m2, 0, 0).  [T][128] entries of four words, then 128 zero
+    // entries: the upper half-wave (k-slots 8..15) reads those.
+    auto bf16_terms = [](float x, unsigned (&t)[3]) {
+        for (int i = 0; i < 3; ++i) {
+            unsigned u; std::memcpy(&u, &x, 4);
+            u &= 0xFFFF0000u;
+            float h; std::memcpy(&h, &u, 4);
+            t[i] = u >> 16;
+            x -= h;
+        }
+    };
+    std::vector<unsigned> gs[2];
+    for (int L = 0; L < 2; ++L) {
+        const std::vector<float>& g = L ? g3 : g2;
+        gs[L].assign(((size_t)T * H + H) * 4, 0u);
+        for (size_t i = 0; i < (size_t)T * H; ++i) {
+            unsigned t[3];
+            bf16_terms(g[i], t);
+            gs[L][4 * i] = t[0] | (t[1] << 16);
+            gs[L][4 * i + 1] = t[2] | (t[0] << 16);
+            gs[L][4 * i + 2] = t[1] | (t[0] << 16);
+        }
+    }
     std::vector<float> coef2(coef, coef + (size_t)T * MPV_COEF_COLS);
     for (int t = 0; t < T; ++t) coef2[(size_t)t * MPV_COEF_COLS + 18] = coef2[(size_t)t * MPV_COEF_COLS + 19] = 0.0f;
     auto as_f32 = [](const void* v) { return reinterpret_cast<const float*>(v); };
@@ -177,7 +202,8 @@ static int load_chain_model(mpv_ctx* ctx, NsdiffModel& m, int T, int F, const mp
                       {as_f32(w3h.data()), (size_t)H * H / 2}, {as_f32(w3l.data()), (size_t)H * H / 2},
                       {as_f32(w1img.data()), w1img.size() / 2}, {as_f32(bp[1].data()), (size_t)H}, {as_f32(bp[2].data()), (size_t)H},
                       {g1.data(), (size_t)T * H}, {g2.data(), (size_t)T * H}, {g3.data(), (size_t)T * H},
-                      {wsl.data(), (size_t)F * H}, {coef2.data(), coef2.size()}, {w4s.data(), (size_t)F * H}},
+                      {wsl.data(), (size_t)F * H}, {coef2.data(), coef2.size()}, {w4s.data(), (size_t)F * H},
+                      {as_f32(gs[0].data()), gs[0].size()}, {as_f32(gs[1].data()), gs[1].size()}},
                      &m.blob16, &d16);
     if (rc != MPV_OK) return rc;
     m.w2h = reinterpret_cast<const unsigned short*>(d16[0]); m.w2l = reinterpret_cast<const unsigned short*>(d16[1]);
@@ -186,6 +212,7 @@ static int load_chain_model(mpv_ctx* ctx, NsdiffModel& m, int T, int F, const mp
     m.b2p = reinterpret_cast<const unsigned*>(d16[5]); m.b3p = reinterpret_cast<const unsigned*>(d16[6]);
     m.g1 = d16[7]; m.g2 = d16[8]; m.g3 = d16[9]; m.wsl = d16[10];
     m.coef = d16[11];
+    m.gs2 = reinterpret_cast<const unsigned*>(d16[13]); m.gs3 = reinterpret_cast<const unsigned*>(d16[14]);
     m.w4h = d16[12];                                      // eps head as the split-f16 kernel reads it (x act_scale)
     m.steps = T; m.nf = F; m.loaded = true;
     return MPV_OK;

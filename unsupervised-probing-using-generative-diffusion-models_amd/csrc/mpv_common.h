@@ -15,7 +15,7 @@ struct NsdiffModel {
     // split-f16 matrix-core variant (see nsdiff_chain_f16.hip)
     float* blob16 = nullptr;
     const unsigned short *w2h, *w2l, *w3h, *w3l, *w1img;
-    const unsigned *b2p, *b3p;
+    const unsigned *b2p, *b3p, *gs2, *gs3;
     const float *g1, *g2, *g3, *wsl, *w4h;
     float bone2 = 1.0f, bone3 = 1.0f, l1_scale = 1.0f;
 };

@@ -254,7 +254,7 @@ static void fill_model_args(ChainArgs& a, const NsdiffModel& m) {
     a.w1t = m.w1t; a.w2 = m.w2; a.w3 = m.w3; a.b1 = m.b1; a.b2 = m.b2; a.b3 = m.b3;
     a.e1 = m.e1; a.e2 = m.e2; a.e3 = m.e3; a.w4 = m.w4; a.ws = m.ws; a.b4 = m.b4; a.bs = m.bs; a.coef = m.coef;
     a.w2h = m.w2h; a.w2l = m.w2l; a.w3h = m.w3h; a.w3l = m.w3l;
-    a.w1img = m.w1img; a.b2p = m.b2p; a.b3p = m.b3p; a.g1 = m.g1; a.g2 = m.g2; a.g3 = m.g3; a.wsl = m.wsl; a.w4h = m.w4h;
+    a.w1img = m.w1img; a.b2p = m.b2p; a.b3p = m.b3p; a.g1 = m.g1; a.g2 = m.g2; a.g3 = m.g3; a.wsl = m.wsl; a.w4h = m.w4h; a.gs2 = m.gs2; a.gs3 = m.gs3;
     a.bone2 = m.bone2; a.bone3 = m.bone3; a.l1_scale = m.l1_scale; a.hi_mask = 0xFFFFE000u;
 }
 

@@ -109,6 +109,31 @@ __device__ __forceinline__ f32x16 mfma16(const f16x8& a, const f16x8& b, const f
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// ---- x' = acc * g''[row] / ||l||[chain] with ONE multiply per element (-DMPV_OUTER=0: two multiplies, scale rows of layers 2, 3 in
+// LDS).  The scale tile S = g'' (x) 1/||l|| comes from the matrix pipe (one v_mfma_f32_32x32x16_bf16 per activation tile; three-term
+// bf16 splits, six k-slots: >= 22 bits, fp32 exponent range, so no operand scaling).  A operands: host table ChainArgs::gs2 / gs3;
+// B operand: outer_b(1/||l||).  It removes 128 v_mul and 32 ds_read_b128 per step and leaves the results unchanged.  Worth 0.7 % only
+// (profiles/r03/chain_variants.txt: 576.0 -> 572.6 ms per 181-window launch): the woven segments it lightens are close to the matrix
+// pipe's own pace already, and the operand set-up lands in un-woven phases.
+#ifndef MPV_OUTER
+#define MPV_OUTER 1
+#endif
+template <int F> struct OuterOn { static constexpr bool value = (MPV_OUTER > 0) && F <= 2; };   // F = 3: its operands would spill inside the step
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 outer_tile(const u32x4& a, const u32x4& b) {
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), zero, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4 outer_b(float m) {         // k-slots (m0, m0, m0, m1, m1, m2, 0, 0)
+    const unsigned u0 = __float_as_uint(m) & 0xFFFF0000u;
+    const float r1 = m - __uint_as_float(u0);
+    const unsigned u1 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(u1);
+    const unsigned u2 = __float_as_uint(r2);
+    const u32x4 b = {u0 | (u0 >> 16), (u0 >> 16) | u1, (u1 >> 16) | (u2 & 0xFFFF0000u), 0u};
+    return b;
+}
+
 // one k-step of output tile j: acc += W_lo h_hi + W_hi h_lo + W_hi h_hi   (FIRST: acc starts from zero).
 // NP = products kept: 3 = all (fp32-equivalent, >= 21 bits), 2 = W_lo h_hi + W_hi h_hi (activations rounded to f16),
 // 1 = W_hi h_hi (plain f16 operands); accumulation is fp32 in every mode.
@@ -128,10 +153,12 @@ __device__ __forceinline__ void mfma_ks(f32x16& acc, const unsigned char* smem, 
     }
 }
 
-// bias k-slots: A = (b_hi, b_lo, b_hi, 0...) of the lane's row (upper half-wave zero), B = (c_hi, c_hi, c_lo, 0...)
-__device__ __forceinline__ void mfma_bias(f32x16& acc, unsigned ab, const f16x8& bone) {
-    const u32x4 a = {ab, ab & 0xFFFFu, 0u, 0u};
-    acc = mfma16(__builtin_bit_cast(f16x8, a), bone, acc);
+// bias k-slots.  A = (b_hi, b_lo, b_hi, 0...) of the lane's row lives in the 16 pad bytes behind row `row` of the W_hi image (written once
+// per workgroup), so the bias is simply k-step 8 of the tile: one ds_read_b128, no operand registers held across the step.  The upper
+// half-wave reads the first 16 bytes of the next row there (finite weights); its B operand is zero (StepCtx::kb2 / kb3 are 0 for it).
+// B = (c_hi, c_hi, c_lo, 0...).
+__device__ __forceinline__ void mfma_bias(f32x16& acc, const unsigned char* smem, unsigned wbase, int img_hi, int j, const f16x8& bone) {
+    acc = mfma16(LDS_H8(smem, wbase + img_hi + j * 32 * (HROW * 2) + 8 * 32), bone, acc);
 }
 
 __device__ __forceinline__ f16x8 bias_operand(float c) {            // c = c_hi + c_lo in f16
@@ -185,6 +212,20 @@ __device__ __forceinline__ void softplus16(f32x16& a, const unsigned char* smem,
 #pragma unroll
         for (int i = 0; i < 16; ++i) a[i] = __builtin_amdgcn_fmed3f(c[i], a[i], 3.0e38f);        // max(., x')
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ss[i & 3] = __builtin_fmaf(a[i], a[i], ss[i & 3]);
+}
+
+// the same with the scale tile S = g'' (x) 1/||l|| (fast path only)
+__device__ __forceinline__ void softplus16_outer(f32x16& a, const f32x16& S, float (&ss)[4]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] *= S[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = __builtin_amdgcn_exp2f(a[i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] += 1.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = __builtin_amdgcn_logf(a[i]);
 #pragma unroll
     for (int i = 0; i < 16; ++i) ss[i & 3] = __builtin_fmaf(a[i], a[i], ss[i & 3]);
 }
@@ -282,6 +323,7 @@ struct ActState {
     f32x16& a;                // accumulators in, l (or l - hi when SPLIT) out
     f32x16 hi;
     f32x4 gm[4];
+    const f32x16& S;          // OUTER: the scale tile of this activation (then gm and m2 are unused)
     f32x4 w4[F > 0 ? F : 1][4];
     float (&ss)[4];
     float (*ea)[4];
@@ -290,9 +332,10 @@ struct ActState {
     u32x4 ph[2], pl[2];
 };
 
-template <int ST, int E, int F>
+template <int ST, int E, int F, bool OUTER>
 __device__ __forceinline__ void act_op(ActState<F>& s) {
-    if constexpr (ST == 0) s.a[E] *= s.gm[E >> 2][E & 3];
+    if constexpr (ST == 0 && OUTER) s.a[E] *= s.S[E];
+    else if constexpr (ST == 0) s.a[E] *= s.gm[E >> 2][E & 3];
     else if constexpr (ST == 1) s.a[E] *= s.m2;
 #ifdef MPV_ABL_NO_TRANS            // ablation: plain multiplies instead of exp2/log2 (results are wrong)
     else if constexpr (ST == 2) s.a[E] *= 1.0001f;
@@ -327,18 +370,34 @@ __device__ __forceinline__ void split_op(ActState<F>& s) {
 
 // One woven segment: MFMAs m = 0..NM-1 of output tile `jt` (k-steps KS0.., three per k-step, then the bias k-slots
 // when BIAS) with chunk m of the activation of another tile behind each.  A operands are read two k-steps ahead.
-template <int F, int NP, int KS0, int NKS, bool BIAS, bool SCALE, bool SPLIT, bool EPS>
+template <int F, int NP, int KS0, int NKS, bool BIAS, bool SCALE, bool SPLIT, bool EPS, bool NEXT_S = false>
 __device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, unsigned wbase, int img_hi, int img_lo, int jt,
-                                      const f16x8 (&bh)[8], const f16x8 (&bl)[8], unsigned ab, const f16x8& bone,
+                                      const f16x8 (&bh)[8], const f16x8 (&bl)[8], const f16x8& bone,
                                       f32x16& a, unsigned grow, int ja, float m2, unsigned mask, float (&ss)[4],
                                       unsigned f_base, float (*ea)[4],
-                                      f16x8* oh0, f16x8* oh1, f16x8* ol0, f16x8* ol1) {
+                                      f16x8* oh0, f16x8* oh1, f16x8* ol0, f16x8* ol1,
+                                      f32x16& S, const u32x4* sa_next, const u32x4& mb) {
     using LD = Lds<F>;
     constexpr int NM = NP * NKS + (BIAS ? 1 : 0);
     constexpr int NEPS = EPS ? F : 0;
     constexpr int SPL = SPLIT ? (NP == 3 ? 1 : 2) : 0;
-    using PL = ActPlanOf<SCALE, SPL, NEPS, NM>;
-    ActState<F> s{a, {}, {}, {}, ss, ea, m2, mask, {}, {}};
+    constexpr bool OUTER = SCALE && OuterOn<F>::value;       // S = g'' (x) 1/||l|| replaces the g'' rows and the m2 multiply
+#ifdef MPV_ABL_NO_M2               // ablation: no 1/||l|| multiply at all (results are wrong)
+    using PL = ActPlanOf<false, SPL, NEPS, NM>;
+#else
+    using PL = ActPlanOf<SCALE && !OUTER, SPL, NEPS, NM>;
+#endif
+    // the scale tile of the NEXT activation is issued behind MFMA S_AT: every stage-0 multiply of this one is in an earlier chunk
+#ifndef MPV_OUTER_AT
+#define MPV_OUTER_AT 18
+#endif
+    constexpr int S_AT = MPV_OUTER_AT < NM - 1 ? MPV_OUTER_AT : NM - 1;
+    u32x4 sa = {0u, 0u, 0u, 0u};
+#ifndef MPV_ABL_S_CONST            // ablation: the scale tile is never recomputed (results are wrong)
+    if constexpr (OUTER && NEXT_S) sa = *sa_next;
+#endif
+    f32x16 s_next = S;
+    ActState<F> s{a, {}, {}, S, {}, ss, ea, m2, mask, {}, {}};
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #ifndef MPV_RING
 #define MPV_RING 3
@@ -349,12 +408,15 @@ __device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, un
         constexpr int ks = decltype(ic)::value;
         const int off = jt * 32 * (HROW * 2) + ks * 32;
         ah[ks % RING] = LDS_H8(smem, wbase + img_hi + off);
-        if constexpr (NP >= 2) al[ks % RING] = LDS_H8(smem, wbase + img_lo + off);
+        if constexpr (NP >= 2 && ks < KS0 + NKS) al[ks % RING] = LDS_H8(smem, wbase + img_lo + off);   // k-step 8 = the bias slots (hi image only)
     };
+    constexpr int NKA = NKS + (BIAS ? 1 : 0);                 // A-operand reads of the segment
     // prologue: scale rows (and eps-head rows) of the activated tile, A operands of the first two k-steps
+    if constexpr (!OUTER) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s.gm[q] = LDS_F4(smem, grow + (32 * ja + 8 * q) * 4);
-    static_for<0, (AHEAD < NKS ? AHEAD : NKS)>([&](auto ic) { load_a(IC<KS0 + decltype(ic)::value>{}); });
+        for (int q = 0; q < 4; ++q) s.gm[q] = LDS_F4(smem, grow + (32 * ja + 8 * q) * 4);
+    }
+    static_for<0, (AHEAD < NKA ? AHEAD : NKA)>([&](auto ic) { load_a(IC<KS0 + decltype(ic)::value>{}); });
     SEG_FENCE();
     static_for<0, NM>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
@@ -363,7 +425,7 @@ __device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, un
             constexpr int ty = (NP == 3) ? g % 3 : (NP == 2 ? 2 * (g % 2) : 2);      // 0: W_lo h_hi, 1: W_hi h_lo, 2: W_hi h_hi
             constexpr bool first = (ks == 0) && (g % NP == 0);
 #ifndef MPV_ABL_NO_LDSA
-            if constexpr (g % NP == 0 && g / NP + AHEAD < NKS) load_a(IC<ks + AHEAD>{});
+            if constexpr (g % NP == 0 && g / NP + AHEAD < NKA) load_a(IC<ks + AHEAD>{});
 #endif
 #if defined(MPV_ABL_NO_LDSA)      // ablation: every k-step multiplies the A operands of the first one (results are wrong)
             if constexpr (ty == 0) acc = mfma16(al[KS0 % RING], bh[ks], first ? zero : acc);
@@ -379,7 +441,8 @@ __device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, un
             else acc = mfma16(ah[ks % RING], bh[ks], first ? zero : acc);
 #endif
         } else {
-            mfma_bias(acc, ab, bone);
+            static_assert(KS0 + NKS == 8, "the bias slots are k-step 8");
+            acc = mfma16(ah[8 % RING], bone, acc);
         }
         static_for<PL::P.start[g], PL::P.start[g + 1]>([&](auto kc) {
             constexpr int kk = decltype(kc)::value;
@@ -389,7 +452,7 @@ __device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, un
                 for (int f = 0; f < F; ++f)
                     s.w4[f][E >> 2] = LDS_F4(smem, f_base + (LD::W4 - LD::F32) + (f * HID + 32 * ja + 8 * (E >> 2)) * 4);
             }
-            if constexpr (ST < 6) act_op<ST, E, F>(s);
+            if constexpr (ST < 6) act_op<ST, E, F, OUTER>(s);
             else if constexpr (SPL == 1) split_op<ST, E, F>(s);
             else if constexpr (SPL == 2) cvt_op<E, F>(s);
             else {
@@ -397,8 +460,12 @@ __device__ __forceinline__ void woven(f32x16& acc, const unsigned char* smem, un
                 s.ea[f][E & 3] = __builtin_fmaf(s.w4[f][E >> 2][E & 3], s.a[E], s.ea[f][E & 3]);
             }
         });
+#ifndef MPV_ABL_S_CONST
+        if constexpr (OUTER && NEXT_S && g == S_AT) s_next = outer_tile(sa, mb);
+#endif
         SEG_FENCE();
     });
+    if constexpr (OUTER && NEXT_S) S = s_next;
     if constexpr (SPLIT) {
         *oh0 = __builtin_bit_cast(f16x8, s.ph[0]); *oh1 = __builtin_bit_cast(f16x8, s.ph[1]);
         if constexpr (NP == 3) {
@@ -514,10 +581,11 @@ struct StepCtx {                 // everything a step needs besides the chain st
     const float *coef, *w1t, *b1;   // global: per-step coefficient rows; fp32 layer-1 weights for the exact path
     float l1_scale;
     unsigned a_base, a_base3, w1_base, f_base, g_base;   // a_base3 = a_base + W3H: keeps every immediate < 64 KB
-    unsigned ab2[4], ab3[4];
-    float kb2, kb3;              // 2^(sW - sB) of layers 2, 3: bias B operand = (B-operand scale) * kb
+    float kb2, kb3;              // 2^(sW - sB) of layers 2, 3: bias B operand = (B-operand scale) * kb; 0 in the upper half-wave
     unsigned hi_mask;
     int h;
+    const float *g2t, *g3t;      // global scale rows of layers 2, 3 at step t (the cold path stages them itself when the hot one does not)
+    const u32x4 *gs2, *gs3;      // this lane's outer-product A operands of the step (tile j at [32 j]; zeros for the upper half-wave)
 };
 
 // one feature of one chain: finish the two head dot products across the half-waves, sigma's softplus, posterior.
@@ -531,7 +599,10 @@ __device__ __forceinline__ float feature_update(const float* cr, float ep, float
     const StepCoef c = {cr[0], cr[1], cr[2],  cr[3],  cr[4],  cr[5],  cr[6],  cr[7],  cr[8],
                         cr[9], cr[10], cr[11], cr[12], cr[13], cr[14], cr[15], cr[16], cr[17]};
     const float sig = softplus_dev(sp + __shfl_xor(sp, 32) + bs);
-    return posterior(c, y, mu, g, eps, sig, z, last);
+#ifndef MPV_FAST_POST
+#define MPV_FAST_POST 1
+#endif
+    return posterior<(MPV_FAST_POST != 0)>(c, y, mu, g, eps, sig, z, last);
 }
 template <bool NORM>
 __device__ __noinline__ float feature_update_ool(const float* cr, float ep, float sp, float b4, float bs, float y, float mu,
@@ -621,6 +692,8 @@ __device__ __forceinline__ Vec<F> chain_step_fast(const StepCtx& k, int t, const
 #pragma unroll
     for (int c = 0; c < 3 * F; ++c) insum += fabsf(in[c]);
     ok = insum < IN_LIMIT;                                   // false for NaN/inf as well
+    u32x4 sa2 = {0u, 0u, 0u, 0u};
+    if constexpr (NORM && OuterOn<F>::value) sa2 = k.gs2[0];  // first scale-tile operand of layer 2: in flight during layer 1
     f32x16 a1[4];
     layer1_mfma<F>(k.smem, k.w1_base, in, k.h, a1);
     f16x8 Ah[8], Al[8], Bh[8], Bl[8];
@@ -637,8 +710,9 @@ __device__ __forceinline__ Vec<F> chain_step_fast(const StepCtx& k, int t, const
     f32x16 c2[2], l3[4];
     f16x8 bone = {0, 0, 0, 0, 0, 0, 0, 0};
     // ---- layer 2 tile 0, k-steps 0..5  ||  layer-1 activation tile 3
-    woven<F, NP, 0, 6, false, false, true, false>(c2[0], k.smem, k.a_base, LD::W2H, LD::W2L, 0, Ah, Al, 0u, bone, a1[3], k.g_base, 3,
-                                              1.0f, k.hi_mask, ss, k.f_base, nullptr, &Ah[6], &Ah[7], &Al[6], &Al[7]);
+    woven<F, NP, 0, 6, false, false, true, false>(c2[0], k.smem, k.a_base, LD::W2H, LD::W2L, 0, Ah, Al, bone, a1[3], k.g_base, 3,
+                                              1.0f, k.hi_mask, ss, k.f_base, nullptr, &Ah[6], &Ah[7], &Al[6], &Al[7], a1[3], nullptr,
+                                              u32x4{0u, 0u, 0u, 0u});
     TR(1);
     // every layer: lo < ||l|| < 2^13, written as comparisons that a NaN fails (min/max would skip it)
     constexpr float NRM_LO = NORM ? 1.0f : -1.0f;
@@ -646,26 +720,40 @@ __device__ __forceinline__ Vec<F> chain_step_fast(const StepCtx& k, int t, const
     norm_fast(chain_sum(ss), nrm, inv);
     ok = ok && (nrm > NRM_LO) && (nrm < 8192.0f);
     bone = bias_operand((NORM ? nrm : 1.0f) * k.kb2);
+    constexpr bool OUTER = NORM && OuterOn<F>::value;
+    f32x16 S = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    u32x4 mb = {0u, 0u, 0u, 0u};
+    u32x4 sa3 = {0u, 0u, 0u, 0u};
+    if constexpr (OUTER) {
+        mb = outer_b(inv);
+        S = outer_tile(sa2, mb);
+        sa3 = k.gs3[0];                                      // layer 3's first scale tile is due a whole layer from here
+    }
     mfma_tile<6, 8, NP>(c2[0], k.smem, k.a_base, LD::W2H, LD::W2L, 0, Ah, Al);
-    mfma_bias(c2[0], k.ab2[0], bone);
+    mfma_bias(c2[0], k.smem, k.a_base, LD::W2H, 0, bone);
     TR(2);
     ss[0] = ss[1] = ss[2] = ss[3] = 0.0f;
     // ---- layer 2 tile j  ||  layer-2 activation of tile j-1
 #pragma unroll
     for (int j = 1; j < 4; ++j)
-        woven<F, NP, 0, 8, true, NORM, true, false>(c2[j & 1], k.smem, k.a_base, LD::W2H, LD::W2L, j, Ah, Al, k.ab2[j], bone,
-                                                c2[(j - 1) & 1], g2, j - 1, inv, k.hi_mask, ss, k.f_base, nullptr,
-                                                &Bh[2 * j - 2], &Bh[2 * j - 1], &Bl[2 * j - 2], &Bl[2 * j - 1]);
+        woven<F, NP, 0, 8, true, NORM, true, false, true>(c2[j & 1], k.smem, k.a_base, LD::W2H, LD::W2L, j, Ah, Al, bone,
+                                                      c2[(j - 1) & 1], g2, j - 1, inv, k.hi_mask, ss, k.f_base, nullptr,
+                                                      &Bh[2 * j - 2], &Bh[2 * j - 1], &Bl[2 * j - 2], &Bl[2 * j - 1],
+                                                      S, k.gs2 + 32 * j, mb);
     TR(3);
     // ---- layer 3 tile 0, k-steps 0..5  ||  layer-2 activation tile 3
-    woven<F, NP, 0, 6, false, NORM, true, false>(l3[0], k.smem, k.a_base3, 0, W3REL, 0, Bh, Bl, 0u, bone, c2[1], g2, 3, inv,
-                                             k.hi_mask, ss, k.f_base, nullptr, &Bh[6], &Bh[7], &Bl[6], &Bl[7]);
+    woven<F, NP, 0, 6, false, NORM, true, false>(l3[0], k.smem, k.a_base3, 0, W3REL, 0, Bh, Bl, bone, c2[1], g2, 3, inv,
+                                             k.hi_mask, ss, k.f_base, nullptr, &Bh[6], &Bh[7], &Bl[6], &Bl[7], S, nullptr, mb);
     TR(4);
     norm_fast(chain_sum(ss), nrm, inv);
     ok = ok && (nrm > NRM_LO) && (nrm < 8192.0f);
     bone = bias_operand((NORM ? nrm : 1.0f) * k.kb3);
+    if constexpr (OUTER) {
+        mb = outer_b(inv);
+        S = outer_tile(sa3, mb);
+    }
     mfma_tile<6, 8, NP>(l3[0], k.smem, k.a_base3, 0, W3REL, 0, Bh, Bl);
-    mfma_bias(l3[0], k.ab3[0], bone);
+    mfma_bias(l3[0], k.smem, k.a_base3, 0, 0, bone);
     TR(5);
     ss[0] = ss[1] = ss[2] = ss[3] = 0.0f;
     float ea[F][4];
@@ -676,10 +764,12 @@ __device__ __forceinline__ Vec<F> chain_step_fast(const StepCtx& k, int t, const
     // ---- layer 3 tile j  ||  layer-3 activation (and eps-head partial sums) of tile j-1
 #pragma unroll
     for (int j = 1; j < 4; ++j)
-        woven<F, NP, 0, 8, true, NORM, false, true>(l3[j], k.smem, k.a_base3, 0, W3REL, j, Bh, Bl, k.ab3[j], bone, l3[j - 1], g3,
-                                                j - 1, inv, k.hi_mask, ss, k.f_base, ea, nullptr, nullptr, nullptr, nullptr);
+        woven<F, NP, 0, 8, true, NORM, false, true, true>(l3[j], k.smem, k.a_base3, 0, W3REL, j, Bh, Bl, bone, l3[j - 1], g3,
+                                                      j - 1, inv, k.hi_mask, ss, k.f_base, ea, nullptr, nullptr, nullptr, nullptr,
+                                                      S, k.gs3 + 32 * j, mb);
     TR(6);
-    softplus16<false, NORM>(l3[3], k.smem, g3, 3, inv, ss);
+    if constexpr (OUTER) softplus16_outer(l3[3], S, ss);
+    else softplus16<false, NORM>(l3[3], k.smem, g3, 3, inv, ss);
     eps_partial<F>(k, l3[3], 3, ea);
     norm_fast(chain_sum(ss), nrm, inv);
     ok = ok && (nrm > NRM_LO) && (nrm < 8192.0f);
@@ -702,6 +792,14 @@ __device__ __noinline__ Vec<F> chain_step_safe(StepCtx k, int t, Vec<F> y, Vec<F
     for (int f = 0; f < F; ++f) {
         in[f] = y.v[f]; in[F + f] = mu.v[f]; in[2 * F + f] = g.v[f];
     }
+    if constexpr (NORM && OuterOn<F>::value) {               // the hot path keeps only layer 1's scale row in LDS
+        const int lane = threadIdx.x & 63;
+        if (lane < 32) {
+            unsigned char* const rows = const_cast<unsigned char*>(k.smem) + (k.g_base - k.h * 16) + lane * 16;
+            *reinterpret_cast<f32x4*>(rows + HID * 4) = *reinterpret_cast<const f32x4*>(k.g2t + lane * 4);
+            *reinterpret_cast<f32x4*>(rows + 2 * HID * 4) = *reinterpret_cast<const f32x4*>(k.g3t + lane * 4);
+        }
+    }
     f32x16 a[4], c[4];
     f16x8 bh[8], bl[8];
     layer1_valu<F>(k.w1t, k.b1, in, k.h, k.l1_scale, a);
@@ -716,7 +814,7 @@ __device__ __noinline__ Vec<F> chain_step_safe(StepCtx k, int t, Vec<F> y, Vec<F
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         mfma_tile<0, 8>(c[j], k.smem, k.a_base, LD::W2H, LD::W2L, j, bh, bl);
-        mfma_bias(c[j], k.ab2[j], bone);
+        mfma_bias(c[j], k.smem, k.a_base, LD::W2H, j, bone);
     }
     ss[0] = ss[1] = ss[2] = ss[3] = 0.0f;
 #pragma unroll
@@ -729,7 +827,7 @@ __device__ __noinline__ Vec<F> chain_step_safe(StepCtx k, int t, Vec<F> y, Vec<F
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         mfma_tile<0, 8>(a[j], k.smem, k.a_base3, 0, W3REL, j, bh, bl);
-        mfma_bias(a[j], k.ab3[j], bone);
+        mfma_bias(a[j], k.smem, k.a_base3, 0, j, bone);
     }
     ss[0] = ss[1] = ss[2] = ss[3] = 0.0f;
     float ea[F][4];
@@ -814,6 +912,12 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
         *reinterpret_cast<uint4*>(smem + LD::W3H + dst) = *reinterpret_cast<const uint4*>(p.w3h + src);
         *reinterpret_cast<uint4*>(smem + LD::W3L + dst) = *reinterpret_cast<const uint4*>(p.w3l + src);
     }
+    for (int i = threadIdx.x; i < 2 * HID; i += THREADS) {           // bias k-slots (b_hi, b_lo, b_hi, 0...) in the pad of the W_hi rows
+        const int row = i & (HID - 1);
+        const unsigned b = (i < HID ? p.b2p : p.b3p)[row];
+        const uint4 v = {b, b & 0xFFFFu, 0u, 0u};
+        *reinterpret_cast<uint4*>(smem + (i < HID ? LD::W2H : LD::W3H) + row * (HROW * 2) + HID * 2) = v;
+    }
     for (int i = threadIdx.x; i < HID * 2 * L1<F>::NK; i += THREADS)     // W1 image, 16-byte pieces
         *reinterpret_cast<uint4*>(smem + LD::W1 + i * 16) = *reinterpret_cast<const uint4*>(p.w1img + i * 8);
     {
@@ -848,14 +952,8 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
     k0.w1_base = LD::W1 + r_lane * (32 * L1<F>::NK) + h_lane * 16;
     k0.f_base = LD::F32 + h_lane * 16;                                           // float tables at hidden 4h
     k0.g_base = LD::GAM + wave * (3 * HID * 4) + h_lane * 16;                    // this wave's scale rows
-    // biases of layers 2/3 as MFMA A operands (row = tile row of this lane; only k-slots 0,1 of half-wave 0)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        k0.ab2[j] = h_lane ? 0u : p.b2p[32 * j + r_lane];
-        k0.ab3[j] = h_lane ? 0u : p.b3p[32 * j + r_lane];
-    }
-    k0.kb2 = p.bone2;
-    k0.kb3 = p.bone3;
+    k0.kb2 = h_lane ? 0.0f : p.bone2;
+    k0.kb3 = h_lane ? 0.0f : p.bone3;
     k0.hi_mask = p.hi_mask;                                                       // 0xFFFFE000, stays in an SGPR
     k0.h = h_lane;
     unsigned char* const gam_w = smem + LD::GAM + wave * (3 * HID * 4);
@@ -906,17 +1004,24 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
 #pragma clang fp contract(off)
             y.v[f] = sqrtf(g.v[f]) * z[f] + mu.v[f];
         }
+        constexpr bool ROWS23 = !(NORM && OuterOn<F>::value);  // layers 2, 3 take their scales from the outer product otherwise
         if (lane < 32) {                                   // scale rows of the first step t = T-1
             const long long g0 = (long long)(p.T - 1) * HID + (gl >> 2);
             *reinterpret_cast<f32x4*>(gam_w + gl) = *reinterpret_cast<const f32x4*>(p.g1 + g0);
-            *reinterpret_cast<f32x4*>(gam_w + HID * 4 + gl) = *reinterpret_cast<const f32x4*>(p.g2 + g0);
-            *reinterpret_cast<f32x4*>(gam_w + 2 * HID * 4 + gl) = *reinterpret_cast<const f32x4*>(p.g3 + g0);
+            if constexpr (ROWS23) {
+                *reinterpret_cast<f32x4*>(gam_w + HID * 4 + gl) = *reinterpret_cast<const f32x4*>(p.g2 + g0);
+                *reinterpret_cast<f32x4*>(gam_w + 2 * HID * 4 + gl) = *reinterpret_cast<const f32x4*>(p.g3 + g0);
+            }
         }
 #ifdef MPV_TRACE
         unsigned long long tr[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long tr_last = __builtin_amdgcn_s_memtime();
         const unsigned long long tr_t0 = tr_last, tr_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+        // outer-product A operands of step t: entry t*128 + row (upper half-wave: the zero entries behind the table)
+        const int gs_stride = h_lane ? 0 : HID;
+        const u32x4* gsp2 = reinterpret_cast<const u32x4*>(p.gs2) + (h_lane ? p.T * HID : (p.T - 1) * HID + r_lane);
+        const u32x4* gsp3 = reinterpret_cast<const u32x4*>(p.gs3) + (h_lane ? p.T * HID : (p.T - 1) * HID + r_lane);
 #pragma nounroll
         for (int t = p.T - 1; t >= 0; --t) {
             // The LDS operands are loop invariant in t; left alone, LICM hoists hundreds of them out of the step
@@ -924,13 +1029,25 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
             // loop while the address arithmetic itself stays hoisted.
             StepCtx k = k0;
             asm volatile("" : "+v"(k.a_base), "+v"(k.a_base3), "+v"(k.w1_base), "+v"(k.f_base), "+v"(k.g_base));
+            k.gs2 = k.gs3 = nullptr;
+            k.g2t = k.g3t = nullptr;
+            if constexpr (!ROWS23) {
+                k.gs2 = gsp2;
+                k.gs3 = gsp3;
+                k.g2t = p.g2 + t * HID;
+                k.g3t = p.g3 + t * HID;
+                gsp2 -= gs_stride;
+                gsp3 -= gs_stride;
+            }
             // prefetch the next step's scale rows into registers now, park them in LDS at the end of the step
             f32x4 nx1 = {0, 0, 0, 0}, nx2 = nx1, nx3 = nx1;
             if (t > 0 && lane < 32) {
                 const long long g0 = (long long)(t - 1) * HID + (gl >> 2);
                 nx1 = *reinterpret_cast<const f32x4*>(p.g1 + g0);
-                nx2 = *reinterpret_cast<const f32x4*>(p.g2 + g0);
-                nx3 = *reinterpret_cast<const f32x4*>(p.g3 + g0);
+                if constexpr (ROWS23) {
+                    nx2 = *reinterpret_cast<const f32x4*>(p.g2 + g0);
+                    nx3 = *reinterpret_cast<const f32x4*>(p.g3 + g0);
+                }
             }
             if (t > 0) {
                 if (PHILOX) {
@@ -952,12 +1069,18 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void nsdiff_chain_f16_kernel(co
             y = yn;
             if (t > 0 && lane < 32) {                       // all reads of this step's rows are done (same wave, in order)
                 *reinterpret_cast<f32x4*>(gam_w + gl) = nx1;
-                *reinterpret_cast<f32x4*>(gam_w + HID * 4 + gl) = nx2;
-                *reinterpret_cast<f32x4*>(gam_w + 2 * HID * 4 + gl) = nx3;
+                if constexpr (ROWS23) {
+                    *reinterpret_cast<f32x4*>(gam_w + HID * 4 + gl) = nx2;
+                    *reinterpret_cast<f32x4*>(gam_w + 2 * HID * 4 + gl) = nx3;
+                }
             }
         }
 #ifdef MPV_TRACE
+#ifdef MPV_TRACE_ALL                               // every wave adds its phases: unbiased averages (wave 0 of a block wins arbitration)
+        if (lane == 0) {
+#else
         if (blockIdx.x == 0 && threadIdx.x == 0) {
+#endif
             tr[12] = __builtin_amdgcn_s_memtime() - tr_t0;                 // shader-clock ticks of this tile
             tr[13] = __builtin_amdgcn_s_memrealtime() - tr_r0;             // 100 MHz reference ticks of this tile
             for (int i = 0; i < 14; ++i) atomicAdd(&mpv_trace[i], tr[i]);
