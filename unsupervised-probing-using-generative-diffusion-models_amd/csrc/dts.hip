@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 #include "dts_small.h"
 #include "nst_gemm.h"
@@ -77,14 +78,22 @@ int lin(mpv_ctx* ctx, const float* X, int ldx, const float* W, const float* bias
     if (!tile_kernel && K % 16 == 0 && N % 16 == 0) {
         const size_t wl = sizeof(float) * (size_t)N * (K + 4);
         const long long wtiles = ((rows + 15) / 16 + LINW_WAVES - 1) / LINW_WAVES;
-        const long long wper = std::max<long long>(1, std::min<long long>(3, (long long)ctx->max_lds / (long long)std::max<size_t>(wl, 1)));
-        const dim3 wgrid((unsigned)std::min<long long>(wtiles, wper * ctx->cu_count)), wblock(64 * LINW_WAVES);
-#define DTS_LINW(KT_)                                                                         \
-    do {                                                                                      \
-        if (int rc = set_lds(ctx, dts_lin_wave_kernel<KT_>, wl)) return rc;                   \
-        hipLaunchKernelGGL(dts_lin_wave_kernel<KT_>, wgrid, wblock, wl, ctx->stream, a);      \
-        MPV_HIP_TRY(ctx, hipGetLastError());                                                  \
-        return MPV_OK;                                                                        \
+        // persistent grid = exactly the workgroups that are resident at once (registers and LDS decide: 2 per CU at K = 64, 1 at K >= 128); a
+        // larger grid leaves a partial second round (K = 64: 150 -> 130 us per launch at 3200 x 200 tokens)
+        static const int wcap = getenv("MPV_DTS_LINW_WGS") ? std::max(1, atoi(getenv("MPV_DTS_LINW_WGS"))) : 0;        // tuning aid: force it
+        const dim3 wblock(64 * LINW_WAVES);
+#define DTS_LINW(KT_)                                                                                                              \
+    do {                                                                                                                           \
+        if (int rc = set_lds(ctx, dts_lin_wave_kernel<KT_>, wl)) return rc;                                                        \
+        static thread_local std::map<size_t, int> known;                      /* LDS bytes -> resident workgroups per CU */       \
+        int& resident = known[wl];                                                                                                 \
+        if (!resident)                                                                                                             \
+            MPV_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, dts_lin_wave_kernel<KT_>, 64 * LINW_WAVES, wl));  \
+        const long long wper = wcap ? wcap : std::max(1, resident);                                                                \
+        const dim3 wgrid((unsigned)std::min<long long>(wtiles, wper * ctx->cu_count));                                             \
+        hipLaunchKernelGGL(dts_lin_wave_kernel<KT_>, wgrid, wblock, wl, ctx->stream, a);                                           \
+        MPV_HIP_TRY(ctx, hipGetLastError());                                                                                       \
+        return MPV_OK;                                                                                                             \
     } while (0)
         switch (K / 16) {
             case 1: DTS_LINW(1);

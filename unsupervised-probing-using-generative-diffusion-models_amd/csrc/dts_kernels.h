@@ -174,15 +174,33 @@ __global__ __launch_bounds__(64 * LINW_WAVES) void dts_lin_wave_kernel(const Lin
     }
     __syncthreads();
     const long long n_tiles = (p.rows + 15) / 16;
-    for (long long tile = (long long)blockIdx.x * LINW_WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * LINW_WAVES) {
+    const long long xs = p.xblk ? p.xblk : 16, ys = p.yblk ? p.yblk : 16;
+    // the X tile of the wave's NEXT iteration is requested before this one's products (narrow K only: it costs KT more float4 registers)
+#ifndef DTS_LINW_PREFETCH
+#define DTS_LINW_PREFETCH 1
+#endif
+    constexpr bool AHEAD = (DTS_LINW_PREFETCH != 0) && KT <= 4;
+    const long long tile0 = (long long)blockIdx.x * LINW_WAVES + wave, tstep = (long long)gridDim.x * LINW_WAVES;
+    auto load_tile = [&](long long tile, f32x4 (&dst)[KT]) {
+        const long long tok = tile * 16 + r16;
+        const bool live = tile < n_tiles && tok < p.rows;
+        const float* xr = p.X + (live ? tok : 0) * (long long)p.ldx + 4 * g;
+#pragma unroll
+        for (int s = 0; s < KT; ++s) dst[s] = live ? *reinterpret_cast<const f32x4*>(xr + xs * s) : f32x4{0, 0, 0, 0};
+    };
+    f32x4 xn[AHEAD ? KT : 1];
+    if constexpr (AHEAD) load_tile(tile0, xn);
+    for (long long tile = tile0; tile < n_tiles; tile += tstep) {
         asm volatile("" ::: "memory");              // weight fragments stay in LDS (hoisted out of the loop they would spill)
         const long long tok = tile * 16 + r16;
         const bool live = tok < p.rows;
-        const float* xr = p.X + (live ? tok : 0) * (long long)p.ldx + 4 * g;
-        const long long xs = p.xblk ? p.xblk : 16, ys = p.yblk ? p.yblk : 16;
         f32x4 xb[KT];
+        if constexpr (AHEAD) {
 #pragma unroll
-        for (int s = 0; s < KT; ++s) xb[s] = live ? *reinterpret_cast<const f32x4*>(xr + xs * s) : f32x4{0, 0, 0, 0};
+            for (int s = 0; s < KT; ++s) xb[s] = xn[s];
+        } else {
+            load_tile(tile, xb);
+        }
         if (p.pro == PRO_LN || p.pro == PRO_ADALN) {
             float sum = 0.0f;
 #pragma unroll
@@ -224,29 +242,45 @@ __global__ __launch_bounds__(64 * LINW_WAVES) void dts_lin_wave_kernel(const Lin
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xb[s][e] = gelu_f(xb[s][e]);
         }
-        for (int nt = 0; nt < (p.N >> 4); ++nt) {
-            const int n0 = 16 * nt + 4 * g;
-            f32x4 addend = {0, 0, 0, 0};            // what the epilogue adds is requested before the MFMAs of this block
-            if (live) {
-                if (p.R) addend = *reinterpret_cast<const f32x4*>(p.R + tok * (long long)p.ldr + n0);
-                if (p.accumulate) addend += *reinterpret_cast<const f32x4*>(p.Y + tok * (long long)p.ldy + ys * nt + 4 * g);
-            }
-            f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-            const float* wa = Wl + (16 * nt + r16) * KS + 4 * g;
+        // output blocks four at a time: everything the four epilogues add (residual, accumulation target) is requested up front, ahead of the
+        // next tile's X, so that the first wait of the products covers these older loads only and the X tile stays in flight
+        const int NT = p.N >> 4;
+        for (int nt0 = 0; nt0 < NT; nt0 += 4) {
+            f32x4 addend[4];
 #pragma unroll
-            for (int s = 0; s < KT; ++s) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(wa + 16 * s);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (s & 1) DTS_MMA(acc1, a[e], xb[s][e]);
-                    else DTS_MMA(acc0, a[e], xb[s][e]);
+            for (int i = 0; i < 4; ++i) {
+                const int nt = nt0 + i;
+                addend[i] = f32x4{0, 0, 0, 0};
+                if (live && nt < NT) {
+                    if (p.R) addend[i] = *reinterpret_cast<const f32x4*>(p.R + tok * (long long)p.ldr + 16 * nt + 4 * g);
+                    if (p.accumulate) addend[i] += *reinterpret_cast<const f32x4*>(p.Y + tok * (long long)p.ldy + ys * nt + 4 * g);
                 }
             }
-            if (live) {
-                f32x4 v = acc0 + acc1;
-                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n0);
-                v += addend;
-                *reinterpret_cast<f32x4*>(p.Y + tok * (long long)p.ldy + ys * nt + 4 * g) = v;
+            if constexpr (AHEAD) {
+                if (nt0 == 0) load_tile(tile + tstep, xn);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int nt = nt0 + i;
+                if (nt >= NT) break;
+                const int n0 = 16 * nt + 4 * g;
+                f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+                const float* wa = Wl + (16 * nt + r16) * KS + 4 * g;
+#pragma unroll
+                for (int s = 0; s < KT; ++s) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(wa + 16 * s);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (s & 1) DTS_MMA(acc1, a[e], xb[s][e]);
+                        else DTS_MMA(acc0, a[e], xb[s][e]);
+                    }
+                }
+                if (live) {
+                    f32x4 v = acc0 + acc1;
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n0);
+                    v += addend[i];
+                    *reinterpret_cast<f32x4*>(p.Y + tok * (long long)p.ldy + ys * nt + 4 * g) = v;
+                }
             }
         }
     }
@@ -263,13 +297,17 @@ __global__ __launch_bounds__(256) void dts_ln_bwd_kernel(const float* __restrict
     const long long tok = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int li = threadIdx.x & 15;
     const bool live = tok < rows;
-    float xv[NPL], gv[NPL];
-    float s = 0.0f;
+    // all three streams (x, g and, when accumulating, the old dx) are requested before the first reduction
+    float xv[NPL], gv[NPL], ov[NPL];
 #pragma unroll
     for (int e = 0; e < NPL; ++e) {
         xv[e] = live ? x[tok * D + NPL * li + e] : 0.0f;
-        s += xv[e];
+        gv[e] = live ? g[tok * D + NPL * li + e] : 0.0f;
+        ov[e] = (live && accumulate) ? dx[tok * D + NPL * li + e] : 0.0f;
     }
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < NPL; ++e) s += xv[e];
 #pragma unroll
     for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m);
     const float mean = s / (float)D;
@@ -287,7 +325,7 @@ __global__ __launch_bounds__(256) void dts_ln_bwd_kernel(const float* __restrict
     for (int e = 0; e < NPL; ++e) {
         const float gm = ada ? 1.0f + gam[NPL * li + e] : gam[NPL * li + e];
         xv[e] *= rstd;                                             // xhat
-        gv[e] = live ? g[tok * D + NPL * li + e] * gm : 0.0f;
+        gv[e] = gv[e] * gm;
         m1 += gv[e];
         m2 += gv[e] * xv[e];
     }
@@ -302,8 +340,7 @@ __global__ __launch_bounds__(256) void dts_ln_bwd_kernel(const float* __restrict
 #pragma unroll
         for (int e = 0; e < NPL; ++e) {
             const float v = rstd * (gv[e] - m1 - xv[e] * m2);
-            float* o = dx + tok * D + NPL * li + e;
-            *o = accumulate ? *o + v : v;
+            dx[tok * D + NPL * li + e] = accumulate ? ov[e] + v : v;
         }
     }
 }
