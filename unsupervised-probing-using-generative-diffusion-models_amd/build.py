@@ -21,6 +21,10 @@ LIB = PKG / "libmpv_hip.so"
 # -fno-slp-vectorize: packed-f32 VALU (v_pk_fma_f32 ...) issues at half rate beside MFMAs on gfx950
 # (tools/ubench/pipe_overlap4: 4 v_pk_fma per MFMA gap = 68 cycles vs 8 v_fma = 48)
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fPIC"]
+# per-file additions.  dts.hip: MFMA results stay in VGPRs -- the short 16x16 products of the attention / MLP kernels are consumed by the
+# VALU at once, and with accumulation registers as destination every tile paid 8-16 v_accvgpr_read/write (attention forward: 89 -> 77
+# instructions per key tile)
+EXTRA = {"dts.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def sources():
@@ -47,7 +51,7 @@ def stale() -> bool:
 
 
 def _compile(src: Path, obj: Path, verbose: bool):
-    cmd = [hipcc_path(), *FLAGS, "-I", str(ROOT / "include"), "-I", str(CSRC), "-c", str(src), "-o", str(obj)]
+    cmd = [hipcc_path(), *FLAGS, *EXTRA.get(src.name, []), "-I", str(ROOT / "include"), "-I", str(CSRC), "-c", str(src), "-o", str(obj)]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)

@@ -390,7 +390,7 @@ int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t, bool save)
         DTS_TRY(seqmix(ctx, D, w.wdft, 2 * e.NFp, e.Lp, w.bdft, s.x2, (long long)L * D, D, L, e.spec, 2LL * e.NFp * D, D, 2 * e.NFp, B));
         hipLaunchKernelGGL(dts_fourier_select_kernel, g1d((long long)B * D), dim3(256), 0, st, e.spec, e.NF, e.NFp, D, e.topk, (long long)B * D, s.fidx,
                            e.famp, e.fph);
-        hipLaunchKernelGGL(dts_fourier_synth_kernel, g1d(T * D), dim3(256), 0, st, s.fidx, e.famp, e.fph, e.freq + 1, L, D, e.topk, T * D, e.season_sum);
+        hipLaunchKernelGGL(dts_fourier_synth_kernel, dim3(B), dim3(256), 0, st, s.fidx, e.famp, e.fph, e.freq + 1, L, D, e.topk, e.season_sum);
         MPV_HIP_TRY(ctx, hipGetLastError());
         DTS_TRY(mlp_block(ctx, e, s.x2, w.ln2w, w.ln2b, w.w0, w.b0, w.w2, w.b2, s.u, e.x3, T, save));
         hipLaunchKernelGGL(dts_meansub_fwd_kernel, dim3(B), dim3(256), sizeof(float) * (256 + D), st, e.x3, w.wlin, w.blin, L, F, D, e.xd[i + 1],
@@ -461,7 +461,7 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
         // trend / season branches through proj
         hipLaunchKernelGGL(dts_trend_bwd_kernel, dim3(B), dim3(256), sizeof(float) * (3 * F + 3 * D), st, gout, s.t3, w.tw0, w.tw3, e.poly, L, F, D, gcur,
                            (long long)L * D);
-        hipLaunchKernelGGL(dts_fourier_bwd_kernel, dim3(B), dim3(256), sizeof(float) * 2 * e.topk * D, st, e.gseason, s.fidx, e.cosT, e.sinT, w.wdft_t, L, D,
+        hipLaunchKernelGGL(dts_fourier_bwd_kernel, dim3(B), dim3(256), sizeof(float) * (10 * e.topk * D + 2 * L), st, e.gseason, s.fidx, e.cosT, e.sinT, w.wdft_t, L, D,
                            e.topk, e.NFp, gcur, (long long)L * D);
         MPV_HIP_TRY(ctx, hipGetLastError());
         // x2 = x1 + proj2(attn2(q2(ln1_1(x1)), kv2(enc)))

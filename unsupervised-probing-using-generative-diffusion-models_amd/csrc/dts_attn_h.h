@@ -9,6 +9,7 @@
 // SAME planes in the backward kernels (four 2-byte reads per plane; a transposed copy would cost a workgroup per CU, and these kernels live on
 // occupancy), and from a transposed plane in the forward kernel, where V is used in no other way.
 #pragma once
+#include <type_traits>
 
 namespace dts {
 
@@ -65,6 +66,16 @@ __device__ __forceinline__ float pow2_scale(float mx) {
     if (!(mx > 0.0f) || !(mx < 3.0e38f)) return 1.0f;                   // all-zero tile, or inf / NaN (which then propagate as they would in fp32)
     int e;
     (void)frexpf(mx, &e);                                               // mx = m 2^e, m in [0.5, 1)
+    return ldexpf(1.0f, 14 - e);
+}
+
+// the same with the reciprocal (exact), for products whose scale is divided out again per tile
+__device__ __forceinline__ float pow2_scale(float mx, float& inv) {
+    inv = 1.0f;
+    if (!(mx > 0.0f) || !(mx < 3.0e38f)) return 1.0f;
+    int e;
+    (void)frexpf(mx, &e);
+    inv = ldexpf(1.0f, e - 14);
     return ldexpf(1.0f, 14 - e);
 }
 
@@ -150,11 +161,11 @@ __device__ __forceinline__ float load_split_col(const float* p, ah4& hi, ah4& lo
 // a 16 x 16 tile of gradient-like values in accumulator layout [row 4 g + r][column r16] -> split with a power of two per COLUMN (the four lanes of
 // a column agree on it with two shuffles; returned).  A column of the B operand scales the same column of the product, which is on the same lanes:
 // the caller divides it out of the zero-initialised product that consumes the tile.
-__device__ __forceinline__ float tile_split(const f32x4& t, ah4& hi, ah4& lo) {
+__device__ __forceinline__ float tile_split(const f32x4& t, ah4& hi, ah4& lo, float& inv) {
     float m = fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3])));
     m = fmaxf(m, __shfl_xor(m, 16));
     m = fmaxf(m, __shfl_xor(m, 32));
-    const float sc = pow2_scale(m);
+    const float sc = pow2_scale(m, inv);
     attn_split4(t[0] * sc, t[1] * sc, t[2] * sc, t[3] * sc, hi, lo);
     return sc;
 }
@@ -181,51 +192,55 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_h_kernel(const AttnArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
     const float c0 = p.scale * LOG2E / sc[0];
     const float oinv = 1.0f / sc[1];                                   // O = (2^13 sV O) / (sV 2^13 l)
+    const int nkt = Lkp >> 4, tail = (p.Lk & 15) ? nkt - 1 : nkt;      // key tile with padded keys (only that one is masked)
     for (int jt = wave; jt < ((p.Lq + 15) >> 4); jt += 4) {
         const int j = 16 * jt + r16;
         const bool jl = j < p.Lq;
         ah4 qh, ql;
         const float c = c0 / load_split_col(Qb + (long long)(jl ? j : 0) * p.ldq + 4 * g, qh, ql);      // the scores come out of the MFMA times sK sQ(query)
-        float m = -INFINITY, l = 0.0f;
+        // online softmax on the RAW scores (c > 0): running maximum mr of s, probabilities 2^13 exp2(c (s - mr)) as one fused multiply-add per score
+        float mr = -INFINITY, l = 0.0f;
         f32x4 o = {0, 0, 0, 0};
-        for (int it = 0; it < (Lkp >> 4); ++it) {
-            const ah4 kh = *reinterpret_cast<const ah4*>(Kh + (16 * it + r16) * AH_RS + 4 * g);
-            const ah4 kl = *reinterpret_cast<const ah4*>(Kl + (16 * it + r16) * AH_RS + 4 * g);
+        const _Float16* kp = Kh + r16 * AH_RS + 4 * g;
+        const _Float16* vp = VTh + r16 * Lkp + 4 * g;
+        const int klo = Lkp * AH_RS, vlo = 16 * Lkp;
+        auto key_tile = [&](int it, auto masked) {
+            const ah4 kh = *reinterpret_cast<const ah4*>(kp + 16 * AH_RS * it);
+            const ah4 kl = *reinterpret_cast<const ah4*>(kp + klo + 16 * AH_RS * it);
             f32x4 s = {0, 0, 0, 0};
             DTS_MMH3(s, kh, kl, qh, ql);                                // sK sQ S^T[key 4 g + r][query r16]
-            float tmax = -INFINITY;
+            if constexpr (decltype(masked)::value) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[r] = (16 * it + 4 * g + r < p.Lk) ? s[r] * c : -INFINITY;
-                tmax = fmaxf(tmax, s[r]);
+                for (int r = 0; r < 4; ++r)
+                    if (16 * it + 4 * g + r >= p.Lk) s[r] = -INFINITY;
             }
+            float tmax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float mn = fmaxf(m, tmax);                       // finite from the first tile on (Lk >= 1)
-            const float alpha = __builtin_amdgcn_exp2f(m - mn);
-            const float mb = mn - AH_PLOG;                         // probabilities come out times 2^13 (the split's scale); l carries the same factor
-            float ps = 0.0f;
+            const float mn = fmaxf(mr, tmax);                      // finite from the first tile on (Lk >= 1)
+            const float alpha = __builtin_amdgcn_exp2f((mr - mn) * c);
+            const float nb = __builtin_fmaf(-mn, c, AH_PLOG);      // probabilities come out times 2^13 (the split's scale); l carries the same factor
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[r] = __builtin_amdgcn_exp2f(s[r] - mb);
-                ps += s[r];
-            }
+            for (int r = 0; r < 4; ++r) s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, nb));
+            const float ps = (s[0] + s[1]) + (s[2] + s[3]);
             l = l * alpha + ps;
             o *= alpha;
-            m = mn;
+            mr = mn;
             ah4 ph, pl;
             attn_split4(s[0], s[1], s[2], s[3], ph, pl);
-            const ah4 vh = *reinterpret_cast<const ah4*>(VTh + r16 * Lkp + 16 * it + 4 * g);
-            const ah4 vl = *reinterpret_cast<const ah4*>(VTl + r16 * Lkp + 16 * it + 4 * g);
+            const ah4 vh = *reinterpret_cast<const ah4*>(vp + 16 * it);
+            const ah4 vl = *reinterpret_cast<const ah4*>(vp + vlo + 16 * it);
             DTS_MMH3(o, vh, vl, ph, pl);                                // 2^13 sV O^T[d 4 g + r][query r16]
-        }
+        };
+        for (int it = 0; it < tail; ++it) key_tile(it, std::false_type{});
+        if (tail < nkt) key_tile(tail, std::true_type{});
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
         if (jl) {
             const float inv = oinv / l;
             float* dst = p.out + ((long long)b * p.Lq + j) * p.ldout + h * p.hs + 4 * g;
             *reinterpret_cast<f32x4*>(dst) = o * inv;
-            if (g == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Lq + j] = m + (__builtin_amdgcn_logf(l) - AH_PLOG);
+            if (g == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Lq + j] = __builtin_fmaf(mr, c, __builtin_amdgcn_logf(l) - AH_PLOG);
         }
     }
 }
@@ -262,25 +277,39 @@ __global__ __launch_bounds__(256) void dts_attn_dq_h_kernel(const AttnArgs p) {
         const float lse = p.lse[((long long)b * p.H + h) * p.Lq + (jl ? j : 0)];
         const float del = p.delta[((long long)b * p.H + h) * p.Lq + (jl ? j : 0)];
         f32x4 dq = {0, 0, 0, 0};
-        for (int it = 0; it < (Lkp >> 4); ++it) {
-            const int ro = (16 * it + r16) * AH_RS + 4 * g;
-            const ah4 kh = *reinterpret_cast<const ah4*>(Kh + ro), kl = *reinterpret_cast<const ah4*>(Kl + ro);
-            const ah4 vh = *reinterpret_cast<const ah4*>(Vh + ro), vl = *reinterpret_cast<const ah4*>(Vl + ro);
+        const int nkt = Lkp >> 4, tail = (p.Lk & 15) ? nkt - 1 : nkt;  // key tile with padded keys (only that one is masked)
+        const int plane = Lkp * AH_RS;                                 // Kh -> Kl -> Vh -> Vl are consecutive planes
+        const _Float16* kp = Kh + r16 * AH_RS + 4 * g;
+        const _Float16* kc = Kh + (4 * g) * AH_RS + r16;               // column reads: keys 4 g .. 4 g + 3, head column r16
+        auto key_tile = [&](int it, auto masked) {
+            const _Float16* kr = kp + 16 * AH_RS * it;
+            const ah4 kh = *reinterpret_cast<const ah4*>(kr), kl = *reinterpret_cast<const ah4*>(kr + plane);
+            const ah4 vh = *reinterpret_cast<const ah4*>(kr + 2 * plane), vl = *reinterpret_cast<const ah4*>(kr + 3 * plane);
             f32x4 s = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
             DTS_MMH3(s, kh, kl, qh, ql);
             DTS_MMH3(t2, vh, vl, dh, dl);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pr = (16 * it + 4 * g + r < p.Lk) ? __builtin_amdgcn_exp2f(s[r] * c - lse) : 0.0f;
+                const float pr = __builtin_amdgcn_exp2f(s[r] * c - lse);
                 s[r] = pr * (t2[r] * dpinv - del) * p.scale;
             }
+            if constexpr (decltype(masked)::value) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * it + 4 * g + r >= p.Lk) s[r] = 0.0f;
+            }
             ah4 sh, sl;
-            const float ssc = tile_split(s, sh, sl);                    // dS^T of this tile times its own power of two
-            const ah4 th = column4(Kh, 16 * it + 4 * g, r16), tl = column4(Kl, 16 * it + 4 * g, r16);      // sK K^T[d = r16][keys 4 g ..]
+            float issc;
+            (void)tile_split(s, sh, sl, issc);                          // dS^T of this tile times its own power of two
+            const _Float16* kq = kc + 16 * AH_RS * it;
+            const ah4 th = ah4{kq[0], kq[AH_RS], kq[2 * AH_RS], kq[3 * AH_RS]};                          // sK K^T[d = r16][keys 4 g ..]
+            const ah4 tl = ah4{kq[plane], kq[plane + AH_RS], kq[plane + 2 * AH_RS], kq[plane + 3 * AH_RS]};
             f32x4 part = {0, 0, 0, 0};
             DTS_MMH3(part, th, tl, sh, sl);
-            dq += part * (kinv / ssc);
-        }
+            dq += part * (kinv * issc);
+        };
+        for (int it = 0; it < tail; ++it) key_tile(it, std::false_type{});
+        if (tail < nkt) key_tile(tail, std::true_type{});
         if (jl) *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lq + j) * p.ldout + h * p.hs + 4 * g) = dq;
     }
 }
@@ -321,10 +350,13 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_h_kernel(const AttnArgs p) {
         const float c = c0 / load_split_col(Kb + (long long)(jl ? j : 0) * p.ldk + 4 * g, kh, kl);
         const float dpinv = 1.0f / (sc[1] * load_split_col(Vb + (long long)(jl ? j : 0) * p.ldv + 4 * g, vh, vl));
         f32x4 dk = {0, 0, 0, 0}, dv = {0, 0, 0, 0};
+        const int plane = Lqp * AH_RS;                                 // Qh -> Ql -> Dh -> Dl are consecutive planes
+        const _Float16* qp = Qh + r16 * AH_RS + 4 * g;                 // row reads: query 16 it + r16, head columns 4 g ..
+        const _Float16* qc = Qh + (4 * g) * AH_RS + r16;               // column reads: queries 16 it + 4 g .., head column r16
         for (int it = 0; it < (Lqp >> 4); ++it) {
-            const int ro = (16 * it + r16) * AH_RS + 4 * g;
-            const ah4 qh = *reinterpret_cast<const ah4*>(Qh + ro), ql = *reinterpret_cast<const ah4*>(Ql + ro);
-            const ah4 dh = *reinterpret_cast<const ah4*>(Dh + ro), dl = *reinterpret_cast<const ah4*>(Dl + ro);
+            const _Float16* qr = qp + 16 * AH_RS * it;
+            const ah4 qh = *reinterpret_cast<const ah4*>(qr), ql = *reinterpret_cast<const ah4*>(qr + plane);
+            const ah4 dh = *reinterpret_cast<const ah4*>(qr + 2 * plane), dl = *reinterpret_cast<const ah4*>(qr + 3 * plane);
             f32x4 s = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
             DTS_MMH3(s, qh, ql, kh, kl);                                // sQ sK S[query 4 g + r][key r16]
             DTS_MMH3(t2, dh, dl, vh, vl);
@@ -338,13 +370,17 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_h_kernel(const AttnArgs p) {
             }
             ah4 ph, pl, sh, sl;
             attn_split4(pr[0], pr[1], pr[2], pr[3], ph, pl);
-            const float ssc = tile_split(ds, sh, sl);
-            const ah4 dth = column4(Dh, 16 * it + 4 * g, r16), dtl = column4(Dl, 16 * it + 4 * g, r16);      // sdO dO^T[d = r16][queries 4 g ..]
-            const ah4 qth = column4(Qh, 16 * it + 4 * g, r16), qtl = column4(Ql, 16 * it + 4 * g, r16);
+            float issc;
+            (void)tile_split(ds, sh, sl, issc);
+            const _Float16* qq = qc + 16 * AH_RS * it;
+            const ah4 qth = ah4{qq[0], qq[AH_RS], qq[2 * AH_RS], qq[3 * AH_RS]};
+            const ah4 qtl = ah4{qq[plane], qq[plane + AH_RS], qq[plane + 2 * AH_RS], qq[plane + 3 * AH_RS]};
+            const ah4 dth = ah4{qq[2 * plane], qq[2 * plane + AH_RS], qq[2 * plane + 2 * AH_RS], qq[2 * plane + 3 * AH_RS]};      // sdO dO^T[d = r16][queries 4 g ..]
+            const ah4 dtl = ah4{qq[3 * plane], qq[3 * plane + AH_RS], qq[3 * plane + 2 * AH_RS], qq[3 * plane + 3 * AH_RS]};
             DTS_MMH3(dv, dth, dtl, ph, pl);
             f32x4 part = {0, 0, 0, 0};
             DTS_MMH3(part, qth, qtl, sh, sl);
-            dk += part * (qinv / ssc);
+            dk += part * (qinv * issc);
         }
         if (jl) {
             *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lk + j) * p.ldout + h * p.hs + 4 * g) = dk;

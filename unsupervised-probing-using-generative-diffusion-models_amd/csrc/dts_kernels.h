@@ -23,9 +23,27 @@ namespace dts {
 
 constexpr float LOG2E = 1.44269504088896341f;
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf on one path: erf(|x|) = 1 - 2^p(|x|), p = log2 erfc as a degree-9 polynomial without constant term on [0, 4] (weighted minimax fit; erf = 1 in
+// fp32 beyond 3.92).  Absolute error <= 1e-7 (2e-9 for the polynomial, the rest is the rounding of 1 - 2^p), the same as the library's near |x| ~ 1;
+// unlike the library's it is not RELATIVELY accurate for |x| << 1, which GELU does not need: erf enters as 1 + erf.  13 instructions against the ~28
+// of the two-branch library routine, which the fused MLP kernels (256 hidden units per token) spent a third of their time in.
+__device__ __forceinline__ float erf_abs7(float x) {
+    float t = fabsf(x);
+    t = t > 4.0f ? 4.0f : t;                                           // (a NaN stays a NaN)
+    float p = 1.162548672e-05f;
+    p = __builtin_fmaf(p, t, -1.531847762e-04f);
+    p = __builtin_fmaf(p, t, 8.491812494e-04f);
+    p = __builtin_fmaf(p, t, -2.276909126e-03f);
+    p = __builtin_fmaf(p, t, 8.749411102e-05f);
+    p = __builtin_fmaf(p, t, 2.772253888e-02f);
+    p = __builtin_fmaf(p, t, -1.483071528e-01f);
+    p = __builtin_fmaf(p, t, -9.184430430e-01f);
+    p = __builtin_fmaf(p, t, -1.627907258e+00f);
+    return copysignf(1.0f - __builtin_amdgcn_exp2f(p * t), x);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_abs7(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+    return 0.5f * (1.0f + erf_abs7(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -60,8 +60,18 @@ __global__ __launch_bounds__(256) void dts_meansub_fwd_kernel(const float* __res
     const int b = blockIdx.x;
     const float* xb = x3 + (long long)b * L * D;
     const int d = threadIdx.x % D, rg = threadIdx.x / D, ngroups = 256 / D;
+    constexpr int KEEP = 64;                        // a thread's values stay in registers between the sum and the subtraction (L <= 64 * 256 / D)
+    const bool keep = 256 % D == 0 && (L + ngroups - 1) / ngroups <= KEEP;
+    float v[KEEP];
     float s = 0.0f;
-    for (int l = rg; l < L; l += ngroups) s += xb[l * D + d];
+    if (keep) {
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) v[u] = rg + u * ngroups < L ? xb[(rg + u * ngroups) * D + d] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) s += v[u];
+    } else {
+        for (int l = rg; l < L; l += ngroups) s += xb[l * D + d];
+    }
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x < D) {
@@ -70,7 +80,14 @@ __global__ __launch_bounds__(256) void dts_meansub_fwd_kernel(const float* __res
         mean[threadIdx.x] = t / (float)L;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < L * D; i += 256) xout[(long long)b * L * D + i] = xb[i] - mean[i % D];
+    if (keep) {
+        const float m = mean[d];
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u)
+            if (rg + u * ngroups < L) xout[(long long)b * L * D + (rg + u * ngroups) * D + d] = v[u] - m;
+    } else {
+        for (int i = threadIdx.x; i < L * D; i += 256) xout[(long long)b * L * D + i] = xb[i] - mean[i % D];
+    }
     for (int f = threadIdx.x; f < F; f += 256) {
         float a = blin[f];
         for (int k = 0; k < D; ++k) a += wlin[f * D + k] * mean[k];
@@ -88,8 +105,18 @@ __global__ __launch_bounds__(256) void dts_meansub_bwd_kernel(const float* __res
     const int b = blockIdx.x;
     const float* gb = dout + (long long)b * L * D;
     const int d = threadIdx.x % D, rg = threadIdx.x / D, ngroups = 256 / D;
+    constexpr int KEEP = 64;
+    const bool keep = 256 % D == 0 && (L + ngroups - 1) / ngroups <= KEEP;
+    float v[KEEP];
     float s = 0.0f;
-    for (int l = rg; l < L; l += ngroups) s += gb[l * D + d];
+    if (keep) {
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) v[u] = rg + u * ngroups < L ? gb[(rg + u * ngroups) * D + d] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) s += v[u];
+    } else {
+        for (int l = rg; l < L; l += ngroups) s += gb[l * D + d];
+    }
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x < D) {
@@ -99,7 +126,14 @@ __global__ __launch_bounds__(256) void dts_meansub_bwd_kernel(const float* __res
         corr[threadIdx.x] = (t - sum) / (float)L;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < L * D; i += 256) dx3[(long long)b * L * D + i] = gb[i] + corr[i % D];
+    if (keep) {
+        const float c = corr[d];
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u)
+            if (rg + u * ngroups < L) dx3[(long long)b * L * D + (rg + u * ngroups) * D + d] = v[u] + c;
+    } else {
+        for (int i = threadIdx.x; i < L * D; i += 256) dx3[(long long)b * L * D + i] = gb[i] + corr[i % D];
+    }
 }
 
 // ---- TrendBlock (transformer.py:12-34).  x1 = rows [0, L) of the projected [2L][D] block (token axis = conv channels).
@@ -117,21 +151,32 @@ __global__ __launch_bounds__(256) void dts_trend_fwd_kernel(const float* __restr
     const int b = blockIdx.x;
     const float* x1 = pr + (long long)b * pr_stride;
     // the 3 D outputs are 600-term sums: four token ranges per output (all 256 threads busy), loads issued 8 tokens ahead
+    // (one thread per (token range, channel) forms all three poly terms from one read of its x values)
     const int Lq = (L + 3) / 4;
-    for (int i = threadIdx.x; i < 4 * 3 * D; i += 256) {
-        const int q = i / (3 * D), pd = i - q * 3 * D, p = pd / D, d = pd - p * D;
+    for (int i = threadIdx.x; i < 4 * D; i += 256) {
+        const int q = i / D, d = i - q * D;
         const int l1 = min(L, (q + 1) * Lq);
-        float s = 0.0f;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
 #pragma unroll 8
         for (int l = q * Lq; l < l1; ++l) {
-            const float* wr = w0 + (p * L + l) * 3;
             const float* xr = x1 + (long long)l * D;
             const float xm = d > 0 ? xr[d - 1] : 0.0f, xc = xr[d], xp = d + 1 < D ? xr[d + 1] : 0.0f;
-            s += wr[0] * xm;
-            s += wr[1] * xc;
-            s += wr[2] * xp;
+            const float* wr = w0 + l * 3;
+            s0 += wr[0] * xm;
+            s0 += wr[1] * xc;
+            s0 += wr[2] * xp;
+            wr += L * 3;
+            s1 += wr[0] * xm;
+            s1 += wr[1] * xc;
+            s1 += wr[2] * xp;
+            wr += L * 3;
+            s2 += wr[0] * xm;
+            s2 += wr[1] * xc;
+            s2 += wr[2] * xp;
         }
-        part[i] = s;
+        part[q * 3 * D + d] = s0;
+        part[q * 3 * D + D + d] = s1;
+        part[q * 3 * D + 2 * D + d] = s2;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 3 * D; i += 256) {
@@ -190,16 +235,25 @@ __global__ __launch_bounds__(256) void dts_trend_bwd_kernel(const float* __restr
     }
     __syncthreads();
     float* out = dpr + (long long)b * pr_stride;
-    for (int i = threadIdx.x; i < L * D; i += 256) {
-        const int l = i / D, d = i - l * D;
-        float s = 0.0f;
-        for (int p = 0; p < 3; ++p) {
-            const float* wr = w0 + (p * L + l) * 3;
-            if (d + 1 < D) s += wr[0] * dt3[p * D + d + 1];          // tap 0 reads x1[d'-1] for output d' = d+1
-            s += wr[1] * dt3[p * D + d];
-            if (d > 0) s += wr[2] * dt3[p * D + d - 1];
+    constexpr int NB = 5;                                             // outputs per thread whose old values are requested together
+    for (int i0 = threadIdx.x; i0 < L * D; i0 += 256 * NB) {
+        float old[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) old[u] = i0 + 256 * u < L * D ? out[i0 + 256 * u] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int i = i0 + 256 * u;
+            if (i >= L * D) break;
+            const int l = i / D, d = i - l * D;
+            float s = 0.0f;
+            for (int p = 0; p < 3; ++p) {
+                const float* wr = w0 + (p * L + l) * 3;
+                if (d + 1 < D) s += wr[0] * dt3[p * D + d + 1];      // tap 0 reads x1[d'-1] for output d' = d+1
+                s += wr[1] * dt3[p * D + d];
+                if (d > 0) s += wr[2] * dt3[p * D + d - 1];
+            }
+            out[i] = old[u] + s;
         }
-        out[i] += s;
     }
 }
 
@@ -257,25 +311,56 @@ __global__ void dts_fourier_select_kernel(const float* __restrict__ spec, int NF
 
 // season[b][t][d] += sum_j amp cos(2 pi f_j t + phase_j) over the selected bins AND their conjugates, with the reference's
 // fp32 operation order for the argument (transformer.py:84-86): ((2 pi) * f) * t + phase, then cos, then amp * cos.
-__global__ void dts_fourier_synth_kernel(const int* __restrict__ idx, const float* __restrict__ amp, const float* __restrict__ phase,
-                                         const float* __restrict__ freq /*rfftfreq[1 + k]*/, int L, int D, int topk, long long n, float* season) {
+// cos(x) for |x| < 2^13 (here: 2 pi f t + phase, at most pi (L + 1)): three-term Cody-Waite reduction by pi/2 in fused multiply-adds, then the
+// minimax polynomials of sin and cos on [-pi/4, pi/4] (Cephes sinf / cosf coefficients, < 2 ulp), selected by the quadrant -- a third of
+// the instructions of the library cosf, whose generic argument reduction the synthesis kernel spent its time in (336 us per launch at
+// 3200 x 200 x 64 for 1.6e8 cosines against 164 MB read and written).
+__device__ __forceinline__ float cos_medium(float x) {
+    const float k = rintf(x * 0.636619772367581343f);                    // 2 / pi
+    float r = __builtin_fmaf(-k, 1.57079601287841796875f, x);
+    r = __builtin_fmaf(-k, 3.1391647326017846353352069854736328125e-7f, r);
+    r = __builtin_fmaf(-k, 5.390302529957764765544681040410068817436695098876953125e-15f, r);
+    const int q = (int)k;
+    const float z = r * r;
+    const float c = __builtin_fmaf(z * z, __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
+                                   __builtin_fmaf(-0.5f, z, 1.0f));
+    const float sn = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float v = (q & 1) ? sn : c;                                     // quadrant 0: cos r, 1: -sin r, 2: -cos r, 3: sin r
+    return ((q + 1) & 2) ? -v : v;
+}
+
+// block per sequence: thread (channel d, quarter) keeps the selected bins of its channel -- angular frequency, phase, amplitude -- in registers
+// and runs over the time steps t = quarter, quarter + 4, ...; the argument is formed exactly as the reference forms it (fp32, (2 pi f) t + phase).
+__global__ __launch_bounds__(256) void dts_fourier_synth_kernel(const int* __restrict__ idx, const float* __restrict__ amp, const float* __restrict__ phase,
+                                                                const float* __restrict__ freq /*rfftfreq[1 + k]*/, int L, int D, int topk, float* season) {
 #pragma clang fp contract(off)
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // (b*L + t)*D + d
-    if (i >= n) return;
-    const int d = (int)(i % D);
-    const long long bt = i / D;
-    const int t = (int)(bt % L);
-    const long long b = bt / L;
+    constexpr int MAXK = 8;
+    const int b = blockIdx.x, dl = threadIdx.x & 63, qu = threadIdx.x >> 6;
+    const float two_pi = 6.283185307179586f;
     // the conjugate half has f -> -f, phase -> -phase: the same cosines again (rounding is symmetric), so the sum over the 2*topk
     // terms is twice the sum over the selected bins (to within the order of the additions)
-    float s = 0.0f;
-    const float tf = (float)t, two_pi = 6.283185307179586f;
-    for (int j = 0; j < topk; ++j) {
-        const long long o = (b * topk + j) * D + d;
-        const float arg = (two_pi * freq[idx[o]]) * tf + phase[o];
-        s += amp[o] * cosf(arg);
+    for (int d = dl; d < D; d += 64) {
+        for (int j0 = 0; j0 < topk; j0 += MAXK) {               // (one pass for topk <= 8; more bins: one more pass over the sequence per eight)
+            float w[MAXK], ph[MAXK], am[MAXK];
+#pragma unroll
+            for (int j = 0; j < MAXK; ++j) {
+                const long long o = ((long long)b * topk + min(j0 + j, topk - 1)) * D + d;
+                w[j] = two_pi * freq[idx[o]];
+                ph[j] = phase[o];
+                am[j] = j0 + j < topk ? amp[o] : 0.0f;
+            }
+            for (int t = qu; t < L; t += 4) {
+                const float tf = (float)t;
+                float s = 0.0f;
+#pragma unroll
+                for (int j = 0; j < MAXK; ++j) {
+                    if (j0 + j >= topk) break;
+                    s += am[j] * cos_medium(w[j] * tf + ph[j]);
+                }
+                season[((long long)b * L + t) * D + d] += 2.0f * s;
+            }
+        }
     }
-    season[i] += 2.0f * s;
 }
 
 // exact-arithmetic transpose of the layer: out[t] = 2 sum_j (Re_j cos th_j t - Im_j sin th_j t) is linear in x through the
@@ -285,24 +370,58 @@ __global__ __launch_bounds__(256) void dts_fourier_bwd_kernel(const float* __res
                                                               const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                               const float* __restrict__ wdft_t /*[L][2 NFp]*/, int L, int D, int topk, int NFp, float* dx,
                                                               long long dx_stride) {
-    extern __shared__ float sm[];                 // C[topk][D], S[topk][D]
+    extern __shared__ float sm[];                 // C[topk][D], S[topk][D], then the basis tables cos / sin [L] and the partial sums [4][2][topk][D]
     float* Cs = sm;
     float* Ss = sm + topk * D;
+    float* ct = Ss + topk * D;
+    float* st = ct + L;
+    float* part = st + L;
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < topk * D; i += 256) {
-        const int j = i / D, d = i - j * D;
-        const int k = idx[((long long)b * topk + j) * D + d] + 1;      // rfft bin number
-        float c = 0.0f, s = 0.0f;
-        int m = 0;
-        for (int t = 0; t < L; ++t) {
-            const float gv = g[((long long)b * L + t) * D + d];
-            c += gv * cosT[m];
-            s += gv * sinT[m];
-            m += k;
-            if (m >= L) m -= L;
+    for (int i = threadIdx.x; i < L; i += 256) {
+        ct[i] = cosT[i];
+        st[i] = sinT[i];
+    }
+    __syncthreads();
+    // C_j[d], S_j[d]: thread (d, quarter) runs over the time steps t = quarter, quarter + 4, ... for every selected bin of channel d (g is read
+    // once for all bins), the four partial sums of a (j, d) are added in quarter order.  D <= 64 channels per pass of 256 threads.
+    const int dl = threadIdx.x & 63, qu = threadIdx.x >> 6;
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + dl;
+        if (d < D) {
+            for (int j0 = 0; j0 < topk; j0 += 8) {
+                const int nj = min(8, topk - j0);
+                int kk[8], m[8];
+                float c[8], sa[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    kk[j] = j < nj ? idx[((long long)b * topk + j0 + j) * D + d] + 1 : 0;      // rfft bin number
+                    m[j] = (int)(((long long)kk[j] * qu) % L);
+                    kk[j] = (int)(((long long)kk[j] * 4) % L);
+                    c[j] = sa[j] = 0.0f;
+                }
+                for (int t = qu; t < L; t += 4) {
+                    const float gv = g[((long long)b * L + t) * D + d];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        c[j] += gv * ct[m[j]];
+                        sa[j] += gv * st[m[j]];
+                        m[j] += kk[j];
+                        if (m[j] >= L) m[j] -= L;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < nj) {
+                        part[((qu * 2 + 0) * topk + j0 + j) * D + d] = c[j];
+                        part[((qu * 2 + 1) * topk + j0 + j) * D + d] = sa[j];
+                    }
+            }
         }
-        Cs[i] = c;
-        Ss[i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < topk * D; i += 256) {
+        Cs[i] = ((part[(0 * 2 + 0) * topk * D + i] + part[(1 * 2 + 0) * topk * D + i]) + part[(2 * 2 + 0) * topk * D + i]) + part[(3 * 2 + 0) * topk * D + i];
+        Ss[i] = ((part[(0 * 2 + 1) * topk * D + i] + part[(1 * 2 + 1) * topk * D + i]) + part[(2 * 2 + 1) * topk * D + i]) + part[(3 * 2 + 1) * topk * D + i];
     }
     __syncthreads();
     // d_x2part[t'] = 2 sum_j (C_j cos th_j t' + S_j sin th_j t') pulled back through proj[L:]: with Mre = cos-basis x proj, Mim = -sin-basis x proj
