@@ -2,6 +2,7 @@
 // where does the time of a 128x128 output tile go -- main loop, global loads, epilogue?
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -I <pkg>/csrc tools/ubench/gemm_h3.hip -o /tmp/gemm_h3 && /tmp/gemm_h3
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "nst_gemm.h"
 
@@ -23,6 +24,21 @@ float run(const NstGemmHArgs& a, int reps) {
     return ms / reps;
 }
 
+float run64(const NstGemmHArgs& a, int reps) {
+    const long long tiles = ((a.M + 63) / 64) * ((a.N + G_BN - 1) / G_BN);
+    const dim3 grid((unsigned)(8 * ((tiles + 7) / 8)));
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((nst_gemm_h3_kernel<0, 64>), grid, dim3(256), 0, 0, a);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((nst_gemm_h3_kernel<0, 64>), grid, dim3(256), 0, 0, a);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+
 int main() {
     const long long M = 216800;
     struct Shape { int N, K; int act; bool res; const char* name; } shapes[] = {
@@ -33,6 +49,23 @@ int main() {
     CK(hipMalloc(&Wh, 1536 * 512 * 2)); CK(hipMalloc(&Wl, 1536 * 512 * 2));
     CK(hipMemset(X, 0, M * 1536 * 4)); CK(hipMemset(R, 0, M * 512 * 4)); CK(hipMemset(bias, 0, 1536 * 4)); CK(hipMemset(Wh, 0, 1536 * 512 * 2));
     CK(hipMemset(Wl, 0, 1536 * 512 * 2));
+    // DiffSTG at BASELINE configs[4] (4 windows x 6400 node rows per launch; C = Td_h c_out, k = T + 1 convolutions as [rows][c_out T] x [c_out T][C])
+    if (getenv("GEMM_STG")) {
+        const long long Ms = 25600;
+        struct S2 { int N, K; bool res; const char* name; } sh2[] = {
+            {80, 1600, false, "down T200"}, {160, 3200, false, "down cat"}, {80, 800, false, "down T100"}, {320, 80, false, "gate"},
+            {1600, 80, true, "up T200"}, {3200, 80, true, "up x2"}};
+        for (const S2& s : sh2) {
+            const int ldw = (s.K + 31) & ~31;
+            NstGemmHArgs a{X, s.K, Wh, Wl, 1.0f, bias, s.res ? R : nullptr, s.N, Y, s.N, Ms, s.N, s.K, 0, ldw};
+            const double mb = (double)Ms * (s.K + s.N * (s.res ? 2 : 1)) * 4 / 1e6;
+            const float full = run<0>(a, 5);
+            const float t64 = run64(a, 5);
+            printf("%-10s M=%lld N=%4d K=%4d: 128-row tiles %.1f us, 64-row tiles %.1f us  (%.0f MB algorithmic -> %.2f / %.2f TB/s)\n", s.name, Ms, s.N, s.K, full * 1e3,
+                   t64 * 1e3, mb, mb / full / 1e3, mb / t64 / 1e3);
+        }
+        return 0;
+    }
     for (const Shape& s : shapes) {
         NstGemmHArgs a{X, s.K, Wh, Wl, 1.0f, bias, s.res ? R : nullptr, 512, Y, s.N, M, s.N, s.K, s.act, s.K};
         const double gf = 2.0 * M * s.N * s.K / 1e9;

@@ -24,7 +24,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-f
 # per-file additions.  dts.hip: MFMA results stay in VGPRs -- the short 16x16 products of the attention / MLP kernels are consumed by the
 # VALU at once, and with accumulation registers as destination every tile paid 8-16 v_accvgpr_read/write (attention forward: 89 -> 77
 # instructions per key tile)
-EXTRA = {"dts.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA = {"dts.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "stg.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}   # (DiffSTG: 8.43 -> 8.58 windows/s)
 
 
 def sources():

@@ -553,7 +553,7 @@ int gemm(mpv_ctx* ctx, const NstEngine& e, const float* X, long long ldx, const 
         hipLaunchKernelGGL(nst_gemm_kernel, grid, dim3(256), lds, ctx->stream, a);
     } else {
         NstGemmHArgs a{X, ldx, W.h + (size_t)row0 * K, W.l + (size_t)row0 * K, W.inv_scale, bias, R, ldr, Y, ldy, M, N, K, act, K};
-        hipLaunchKernelGGL(nst_gemm_h3_kernel<0>, grid, dim3(256), 0, ctx->stream, a);
+        nst_gemm_h3_launch(a, ctx->stream);
     }
     MPV_HIP_TRY(ctx, hipGetLastError());
     return MPV_OK;

@@ -2,6 +2,7 @@
 // tools/ubench/gemm_h3.hip, which times the kernels alone).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 namespace {
 
@@ -30,12 +31,13 @@ constexpr int G_BM = 128, G_BN = 128, G_BK = 32, G_LD = G_BK + 4;
 // contiguous eighth of the tile list, in which the N tiles of one 128-row block of X are neighbours -- they run at the same time
 // on the same XCD, so the X block is fetched from HBM once and served to the others by that L2 (the weights, a few MB, stay
 // resident in every L2).  Returns false for the padding workgroups of the last chunk.
+template <int BM = G_BM>
 __device__ __forceinline__ bool gemm_tile(long long M, int N, long long& m0, int& n0) {
-    const long long n_n = (N + G_BN - 1) / G_BN, total = ((M + G_BM - 1) / G_BM) * n_n;
+    const long long n_n = (N + G_BN - 1) / G_BN, total = ((M + BM - 1) / BM) * n_n;
     const long long per = (total + 7) / 8, id = blockIdx.x;
     const long long t = (id & 7) * per + (id >> 3);
     if ((id >> 3) >= per || t >= total) return false;
-    m0 = (t / n_n) * G_BM;
+    m0 = (t / n_n) * BM;
     n0 = (int)(t % n_n) * G_BN;
     return true;
 }
@@ -45,25 +47,39 @@ constexpr int C_LD = G_BN + 4;                  // floats per row of the output 
 // Output tile: accumulators -> LDS [128][C_LD] -> rows of 512 contiguous bytes (a wave writes two whole rows per instruction; the
 // accumulator layout itself would give 128-byte pieces of 64 different rows).  Bias, activation and residual are applied on the way out.
 // N must be a multiple of 4.
-template <bool PROBE_NO_STORE = false>
-__device__ __forceinline__ void gemm_store_tile(float* Cs, const v16f (&acc)[2][2], float scale, long long m0, int n0, long long M, int N, const float* bias,
+template <bool PROBE_NO_STORE = false, int MT = 2>      // MT: 32-row accumulator tiles per wave (the workgroup tile has BM = 64 MT rows)
+__device__ __forceinline__ void gemm_store_tile(float* Cs, const v16f (&acc)[MT][2], float scale, long long m0, int n0, long long M, int N, const float* bias,
                                                 int act, const float* R, long long ldr, float* Y, long long ldy) {
+    constexpr int BM = 64 * MT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    // the residual tile is requested first, all 16 row pieces of this thread at once: the loads fly while the accumulators go through LDS (a
+    // product with a short K -- DiffSTG's up-sampling maps, K = 80..160 against N = 3200 -- is all epilogue: 237 us per launch with the loads
+    // issued four at a time inside the store loop)
+    const int c4e = (tid & 31) * 4;
+    const bool add_r = R && act != 3 && n0 + c4e < N;
+    v4f rr[BM / 8];
+    if (add_r) {
+#pragma unroll
+        for (int it = 0; it < BM / 8; ++it) {
+            const long long m = m0 + it * 8 + (tid >> 5);
+            rr[it] = m < M ? *reinterpret_cast<const v4f*>(R + (size_t)m * ldr + n0 + c4e) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
     __syncthreads();                              // every wave is done with the operand tiles
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                Cs[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * C_LD + wn * 64 + j * 32 + li] = acc[i][j][r] * scale;
+                Cs[(wm * 32 * MT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * C_LD + wn * 64 + j * 32 + li] = acc[i][j][r] * scale;
     __syncthreads();
     const int c4 = (tid & 31) * 4, n = n0 + c4;
     if (n >= N) return;
     v4f b4 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (bias) b4 = *reinterpret_cast<const v4f*>(bias + n);
-#pragma unroll 4
-    for (int it = 0; it < G_BM / 8; ++it) {
+#pragma unroll
+    for (int it = 0; it < BM / 8; ++it) {
         const int row = it * 8 + (tid >> 5);
         const long long m = m0 + row;
         if (m >= M) break;
@@ -80,7 +96,7 @@ __device__ __forceinline__ void gemm_store_tile(float* Cs, const v16f (&acc)[2][
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 y[c] *= 0.5f * (1.0f + erff(u[c] * 0.70710678118654752f)) + u[c] * 0.39894228040143268f * __expf(-0.5f * u[c] * u[c]);
-        } else if (R) y += *reinterpret_cast<const v4f*>(R + (size_t)m * ldr + n);
+        } else if (add_r) y += rr[it];
         if (!PROBE_NO_STORE || y[0] == 1.2345e30f) *reinterpret_cast<v4f*>(Y + (size_t)m * ldy + n) = y;
     }
 }
@@ -190,25 +206,30 @@ struct NstGemmHArgs {
 constexpr int H_LD = G_BK + 8;                  // halves per LDS row
 
 // PROBE (tools/ubench/gemm_h3.hip only): 1 no epilogue stores, 2 one k-tile, 4 no global loads inside the loop
-template <int PROBE = 0>
-__global__ __launch_bounds__(256, 2) void nst_gemm_h3_kernel(const NstGemmHArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[G_BM * C_LD];           // operand tiles (40 KB of it), then the output tile
+// BM = 128 (four waves of 64 x 64; the shipped shape) or 64 (four waves of 32 x 64: half the registers and LDS, three workgroups per CU; see
+// nst_gemm_h3_launch).
+template <int PROBE = 0, int BM = G_BM>
+__global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(const NstGemmHArgs p) {
+    constexpr int MT = BM / 64;
+    static_assert(BM == 64 || BM == 128, "workgroup tile rows");
+    static_assert((2 * BM + 2 * G_BN) * H_LD * 2 <= BM * C_LD * 4, "the operand tiles fit the output tile's LDS");
+    __shared__ __attribute__((aligned(16))) float smem[BM * C_LD];             // operand tiles, then the output tile
     _Float16* Ah = reinterpret_cast<_Float16*>(smem);
-    _Float16* Al = Ah + G_BM * H_LD;
-    _Float16* Bh = Al + G_BM * H_LD;
+    _Float16* Al = Ah + BM * H_LD;
+    _Float16* Bh = Al + BM * H_LD;
     _Float16* Bl = Bh + G_BN * H_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     long long m0;
     int n0;
-    if (!gemm_tile(p.M, p.N, m0, n0)) return;
+    if (!gemm_tile<BM>(p.M, p.N, m0, n0)) return;
     const int lr = tid >> 3, lk = (tid & 7) * 4;           // X: rows lr + 32 j, 4 floats at lk
     const int wr = tid >> 2, wk = (tid & 3) * 8;           // W: rows wr + 64 j, 8 halves at wk
-    const float* xa[4];
+    const float* xa[2 * MT];
     const _Float16* wh[2];
     const _Float16* wl[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2 * MT; ++j) {
         long long r = m0 + lr + 32 * j;
         if (r >= p.M) r = p.M - 1;
         xa[j] = p.X + (size_t)r * p.ldx + lk;
@@ -221,11 +242,11 @@ __global__ __launch_bounds__(256, 2) void nst_gemm_h3_kernel(const NstGemmHArgs 
         wl[j] = p.Wl + (size_t)n * p.ldw + wk;
     }
     // Two register sets of staged tiles, so that a global load has two compute phases to land before it is written to LDS.
-    struct Stage { v4f x[4]; h8 h[2], l[2]; };
+    struct Stage { v4f x[2 * MT]; h8 h[2], l[2]; };
     Stage sa, sb;
     auto fetch = [&](Stage& st, int kt) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2 * MT; ++j)
             st.x[j] = (kt * G_BK + lk < p.K) ? *reinterpret_cast<const v4f*>(xa[j] + (size_t)kt * G_BK) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -235,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void nst_gemm_h3_kernel(const NstGemmHArgs 
     };
     auto stash = [&](const Stage& st) {                    // split the activations, write the tile to LDS
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2 * MT; ++j) {
             float hi[4], lo[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -257,30 +278,33 @@ __global__ __launch_bounds__(256, 2) void nst_gemm_h3_kernel(const NstGemmHArgs 
             *reinterpret_cast<h8*>(Bl + (wr + 64 * j) * H_LD + wk) = st.l[j];
         }
     };
-    v16f acc[2][2];
+    v16f acc[MT][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const int nk = (PROBE & 2) ? 1 : p.ldw / G_BK;
     const int li = lane & 31, lh = lane >> 5;
-    const int a_off = (wm * 64 + li) * H_LD + 8 * lh;
+    const int a_off = (wm * 32 * MT + li) * H_LD + 8 * lh;
     const int b_off = (wn * 64 + li) * H_LD + 8 * lh;
     auto compute = [&]() {
 #pragma unroll
         for (int ks = 0; ks < G_BK / 16; ++ks) {
-            h8 ah[2], al[2], bh[2], bl[2];
+            h8 ah[MT], al[MT], bh[2], bl[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < MT; ++i) {
                 ah[i] = *reinterpret_cast<const h8*>(Ah + a_off + i * 32 * H_LD + 16 * ks);
                 al[i] = *reinterpret_cast<const h8*>(Al + a_off + i * 32 * H_LD + 16 * ks);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
                 bh[i] = *reinterpret_cast<const h8*>(Bh + b_off + i * 32 * H_LD + 16 * ks);
                 bl[i] = *reinterpret_cast<const h8*>(Bl + b_off + i * 32 * H_LD + 16 * ks);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
@@ -308,7 +332,21 @@ __global__ __launch_bounds__(256, 2) void nst_gemm_h3_kernel(const NstGemmHArgs 
         __syncthreads();
         if (!(PROBE & 4) && kt + 4 < nk) fetch(sb, kt + 4);
     }
-    gemm_store_tile<(PROBE & 1) != 0>(smem, acc, p.inv_scale, m0, n0, p.M, p.N, p.bias, p.act, p.R, p.ldr, p.Y, p.ldy);
+    gemm_store_tile<(PROBE & 1) != 0, MT>(smem, acc, p.inv_scale, m0, n0, p.M, p.N, p.bias, p.act, p.R, p.ldr, p.Y, p.ldy);
+}
+
+// Launch on `stream`.  MPV_GEMM_BM=64 selects the 64-row workgroup tiles for every product (a tuning aid: at DiffSTG's BASELINE shapes they are
+// 5 % faster on the N = 80 products and 40 % slower on N = 160, K = 3200; the whole step 8.7 against 9.1 windows/s with 128 rows).
+inline void nst_gemm_h3_launch(const NstGemmHArgs& a, hipStream_t stream) {
+    const long long n_n = (a.N + G_BN - 1) / G_BN;
+    static const bool rows64 = getenv("MPV_GEMM_BM") && atoi(getenv("MPV_GEMM_BM")) == 64;
+    if (rows64) {
+        const long long tiles = ((a.M + 63) / 64) * n_n;
+        hipLaunchKernelGGL((nst_gemm_h3_kernel<0, 64>), dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(256), 0, stream, a);
+    } else {
+        const long long tiles = ((a.M + G_BM - 1) / G_BM) * n_n;
+        hipLaunchKernelGGL((nst_gemm_h3_kernel<0, 128>), dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(256), 0, stream, a);
+    }
 }
 
 }  // namespace

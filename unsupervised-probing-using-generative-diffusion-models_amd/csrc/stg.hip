@@ -653,8 +653,7 @@ int gemm(mpv_ctx* ctx, const StgEngine& e, const float* X, long long ldx, const 
     if (e.d.gemm != MPV_GEMM_F32 && sp != e.split.end() && K % 4 == 0 && N % 4 == 0) {
         // two-term f16 split on the f16 matrix pipe, fp32-equivalent: the k = T+1 convolutions and the graph-conv Linear maps
         NstGemmHArgs a{X, ldx, sp->second.h, sp->second.l, sp->second.inv_scale, bias, r1, ldy, Y, ldy, rows, N, K, relu, sp->second.ldw};
-        const long long tiles = ((rows + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
-        hipLaunchKernelGGL(nst_gemm_h3_kernel<0>, dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(256), 0, ctx->stream, a);
+        nst_gemm_h3_launch(a, ctx->stream);
         MPV_HIP_TRY(ctx, hipGetLastError());
         return MPV_OK;
     }
