@@ -4,10 +4,12 @@
 // ONE v_mfma_f32_16x16x16_f16 per term of the two-term split x = hi + lo of power-of-two scaled operands (22 significant bits; products
 // hi*hi + hi*lo + lo*hi, fp32 accumulate; the dropped lo*lo is 2^-22 relative) instead of four v_mfma_f32_16x16x4_f32: 3 x 16.5 cycles against 4 x 32
 // (tools/ubench/mfma_rates.hip).  The fp32 kernels spent 56 % (forward), 70 % (dQ) and 76 % (dK-dV) of their time on the matrix pipe.
-// K / V (Q / dO in the dK-dV pass) are split ONCE while they are staged into LDS, as f16 hi / lo planes.  Operands indexed by (token, 4 head
-// columns) are one ds_read_b64 per plane out of the row-major planes; operands indexed by (head column, 4 tokens) are read column-wise out of the
-// SAME planes in the backward kernels (four 2-byte reads per plane; a transposed copy would cost a workgroup per CU, and these kernels live on
-// occupancy), and from a transposed plane in the forward kernel, where V is used in no other way.
+// K / V (Q / dO in the dK-dV pass) are split ONCE while they are staged into LDS, as f16 hi / lo planes, row-major [tokens][16].  Operands indexed by
+// (token, 4 head columns) are one ds_read_b64 per plane.  Operands indexed by (head column, 4 tokens) -- K^T in dQ, Q^T and dO^T in dK-dV -- come out
+// of the SAME planes through gfx950's transposed LDS read (ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 columns and each lane receives one
+// column): one instruction per plane where four 2-byte reads and two v_perm were needed (dK-dV: 151 -> 127 instructions per query tile, 540 -> 485 us
+// per launch at configs[2]); a transposed copy would cost a workgroup per CU, and these kernels live on occupancy.  The forward kernel, where V is used
+// in no other way, keeps a transposed plane [16][tokens] read with ds_read_b64 (measured: 274 us against 285 us with transposed reads of a row-major V).
 #pragma once
 #include <type_traits>
 
@@ -135,10 +137,14 @@ __device__ __forceinline__ void wg_scales(float (&m)[NT], float* red, float (&sc
     for (int k = 0; k < NT; ++k) sc[k] = pow2_scale(fmaxf(fmaxf(red[k], red[NT + k]), fmaxf(red[2 * NT + k], red[3 * NT + k])));
 }
 
-// four tokens' values of head column `col` out of a row-major plane: p[(row0 + j) * AH_RS + col], j = 0..3
-__device__ __forceinline__ ah4 column4(const _Float16* p, int row0, int col) {
-    const _Float16* q = p + row0 * AH_RS + col;
-    return ah4{q[0], q[AH_RS], q[2 * AH_RS], q[3 * AH_RS]};
+// Four tokens' values of one head column out of a row-major plane, p[(r0 + j) * AH_RS + col], j = 0..3, for all 16 columns at once as ONE gfx950
+// transposed LDS read (ds_read_b64_tr_b16): a group of 16 lanes reads the block rows r0 .. r0 + 3 x 16 columns and lane i of the group receives
+// column i of the four rows.  Lane 4 q + p of the group supplies the address of row r0 + q, columns 4 p ..: `lane_addr` below.  All 64 lanes must be
+// active (the gather crosses lanes).
+__device__ __forceinline__ ah4 column4_tr(const _Float16* lane_addr) {
+    typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    const fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(lane_addr));
+    return __builtin_bit_cast(ah4, v);
 }
 
 __device__ __forceinline__ void load_split4(const float* p, float scale, ah4& hi, ah4& lo) {
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(256) void dts_attn_dq_h_kernel(const AttnArgs p) {
         const int nkt = Lkp >> 4, tail = (p.Lk & 15) ? nkt - 1 : nkt;  // key tile with padded keys (only that one is masked)
         const int plane = Lkp * AH_RS;                                 // Kh -> Kl -> Vh -> Vl are consecutive planes
         const _Float16* kp = Kh + r16 * AH_RS + 4 * g;
-        const _Float16* kc = Kh + (4 * g) * AH_RS + r16;               // column reads: keys 4 g .. 4 g + 3, head column r16
+        const _Float16* kc = Kh + (4 * g + (r16 >> 2)) * AH_RS + 4 * (r16 & 3);      // transposed reads of the key block 4 g .. 4 g + 3: this lane's address
         auto key_tile = [&](int it, auto masked) {
             const _Float16* kr = kp + 16 * AH_RS * it;
             const ah4 kh = *reinterpret_cast<const ah4*>(kr), kl = *reinterpret_cast<const ah4*>(kr + plane);
@@ -302,8 +308,7 @@ __global__ __launch_bounds__(256) void dts_attn_dq_h_kernel(const AttnArgs p) {
             float issc;
             (void)tile_split(s, sh, sl, issc);                          // dS^T of this tile times its own power of two
             const _Float16* kq = kc + 16 * AH_RS * it;
-            const ah4 th = ah4{kq[0], kq[AH_RS], kq[2 * AH_RS], kq[3 * AH_RS]};                          // sK K^T[d = r16][keys 4 g ..]
-            const ah4 tl = ah4{kq[plane], kq[plane + AH_RS], kq[plane + 2 * AH_RS], kq[plane + 3 * AH_RS]};
+            const ah4 th = column4_tr(kq), tl = column4_tr(kq + plane);                                    // sK K^T[d = r16][keys 4 g ..]
             f32x4 part = {0, 0, 0, 0};
             DTS_MMH3(part, th, tl, sh, sl);
             dq += part * (kinv * issc);
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_h_kernel(const AttnArgs p) {
         f32x4 dk = {0, 0, 0, 0}, dv = {0, 0, 0, 0};
         const int plane = Lqp * AH_RS;                                 // Qh -> Ql -> Dh -> Dl are consecutive planes
         const _Float16* qp = Qh + r16 * AH_RS + 4 * g;                 // row reads: query 16 it + r16, head columns 4 g ..
-        const _Float16* qc = Qh + (4 * g) * AH_RS + r16;               // column reads: queries 16 it + 4 g .., head column r16
+        const _Float16* qc = Qh + (4 * g + (r16 >> 2)) * AH_RS + 4 * (r16 & 3);      // transposed reads of the query block 16 it + 4 g ..: this lane's address
         for (int it = 0; it < (Lqp >> 4); ++it) {
             const _Float16* qr = qp + 16 * AH_RS * it;
             const ah4 qh = *reinterpret_cast<const ah4*>(qr), ql = *reinterpret_cast<const ah4*>(qr + plane);
@@ -373,10 +378,8 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_h_kernel(const AttnArgs p) {
             float issc;
             (void)tile_split(ds, sh, sl, issc);
             const _Float16* qq = qc + 16 * AH_RS * it;
-            const ah4 qth = ah4{qq[0], qq[AH_RS], qq[2 * AH_RS], qq[3 * AH_RS]};
-            const ah4 qtl = ah4{qq[plane], qq[plane + AH_RS], qq[plane + 2 * AH_RS], qq[plane + 3 * AH_RS]};
-            const ah4 dth = ah4{qq[2 * plane], qq[2 * plane + AH_RS], qq[2 * plane + 2 * AH_RS], qq[2 * plane + 3 * AH_RS]};      // sdO dO^T[d = r16][queries 4 g ..]
-            const ah4 dtl = ah4{qq[3 * plane], qq[3 * plane + AH_RS], qq[3 * plane + 2 * AH_RS], qq[3 * plane + 3 * AH_RS]};
+            const ah4 qth = column4_tr(qq), qtl = column4_tr(qq + plane);
+            const ah4 dth = column4_tr(qq + 2 * plane), dtl = column4_tr(qq + 3 * plane);                  // sdO dO^T[d = r16][queries 4 g ..]
             DTS_MMH3(dv, dth, dtl, ph, pl);
             f32x4 part = {0, 0, 0, 0};
             DTS_MMH3(part, qth, qtl, sh, sl);
@@ -472,18 +475,30 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_fwd_h_kernel(const Mlp
         lb[s] = *reinterpret_cast<const f32x4*>(p.lnb + 16 * s + 4 * g);
     }
     const long long n_tiles = (p.rows + 15) / 16;
-    for (long long tile = (long long)blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * MLP_WAVES) {
+    // one workgroup per CU (the weights fill its LDS), two waves per SIMD: the X tile of the wave's next iteration is requested before this one's
+    // products, and the residual add at the end uses the copy in registers instead of reading X again
+    const long long tile0 = (long long)blockIdx.x * MLP_WAVES + wave, tstep = (long long)gridDim.x * MLP_WAVES;
+    auto load_tile = [&](long long tile, f32x4 (&dst)[DT]) {
+        const long long tok = tile * 16 + r16;
+        const bool live = tile < n_tiles && tok < p.rows;
+        const float* xr = p.X + (live ? tok : 0) * (long long)D + 4 * g;
+#pragma unroll
+        for (int s = 0; s < DT; ++s) dst[s] = live ? *reinterpret_cast<const f32x4*>(xr + 16 * s) : f32x4{0, 0, 0, 0};
+    };
+    f32x4 xn[DT];
+    load_tile(tile0, xn);
+    for (long long tile = tile0; tile < n_tiles; tile += tstep) {
         asm volatile("" ::: "memory");        // the weight fragments are re-read from LDS every tile
         const long long tok = tile * 16 + r16;
         const bool live = tok < p.rows;
-        const float* xr = p.X + (live ? tok : 0) * (long long)D + 4 * g;
-        f32x4 xb[DT];
+        f32x4 xb[DT], xres[DT];
         float sum = 0.0f;
 #pragma unroll
         for (int s = 0; s < DT; ++s) {
-            xb[s] = live ? *reinterpret_cast<const f32x4*>(xr + 16 * s) : f32x4{0, 0, 0, 0};
+            xb[s] = xres[s] = xn[s];
             sum += (xb[s][0] + xb[s][1]) + (xb[s][2] + xb[s][3]);
         }
+        load_tile(tile + tstep, xn);
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float mean = sum / (float)D;
@@ -552,7 +567,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_fwd_h_kernel(const Mlp
             for (int mt = 0; mt < DT; ++mt) {
                 const int n0 = 16 * mt + 4 * g;
                 f32x4 v = out[mt] + *reinterpret_cast<const f32x4*>(p.b2 + n0);
-                v += *reinterpret_cast<const f32x4*>(p.X + tok * (long long)D + n0);
+                v += xres[mt];                                          // x + mlp(ln(x)): columns 16 mt + 4 g .. of this lane's token
                 *reinterpret_cast<f32x4*>(p.Y + tok * (long long)D + n0) = v;
             }
         }
@@ -574,26 +589,50 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_bwd_h_kernel(const Mlp
     __syncthreads();
     const float i2 = 1.0f / s2, i0 = 1.0f / s0;
     const long long n_tiles = (p.rows + 15) / 16;
-    for (long long tile = (long long)blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += (long long)gridDim.x * MLP_WAVES) {
+    constexpr int HB = MT < MLP_HB ? MT : MLP_HB;
+    // two waves per SIMD: the G tile of the wave's next iteration and the saved pre-activations of the next block of hidden units are requested a
+    // phase ahead of their use
+    const long long tile0 = (long long)blockIdx.x * MLP_WAVES + wave, tstep = (long long)gridDim.x * MLP_WAVES;
+    auto load_g = [&](long long tile, f32x4 (&dst)[DT]) {
+        const long long tok = tile * 16 + r16;
+        const bool live = tile < n_tiles && tok < p.rows;
+        const float* gr = p.G + (live ? tok : 0) * (long long)D + 4 * g;
+#pragma unroll
+        for (int s = 0; s < DT; ++s) dst[s] = live ? *reinterpret_cast<const f32x4*>(gr + 16 * s) : f32x4{0, 0, 0, 0};
+    };
+    auto load_u = [&](long long tile, int hb, f32x4 (&dst)[HB]) {
+        const long long tok = tile * 16 + r16;
+        const bool live = tile < n_tiles && tok < p.rows && hb < MT;
+#pragma unroll
+        for (int j = 0; j < HB; ++j)
+            dst[j] = live ? *reinterpret_cast<const f32x4*>(p.U + tok * (long long)M + 16 * (hb + j) + 4 * g) : f32x4{0, 0, 0, 0};
+    };
+    f32x4 gn[DT], un[HB];
+    load_g(tile0, gn);
+    load_u(tile0, 0, un);
+    for (long long tile = tile0; tile < n_tiles; tile += tstep) {
         asm volatile("" ::: "memory");
         const long long tok = tile * 16 + r16;
         const bool live = tok < p.rows;
-        const float* gr = p.G + (live ? tok : 0) * (long long)D + 4 * g;
         f32x4 gb[DT];
 #pragma unroll
-        for (int s = 0; s < DT; ++s) gb[s] = live ? *reinterpret_cast<const f32x4*>(gr + 16 * s) : f32x4{0, 0, 0, 0};
+        for (int s = 0; s < DT; ++s) gb[s] = gn[s];
+        load_g(tile + tstep, gn);
         const float sg = token_scale<DT>(gb);                         // gradients carry the batch normaliser (1e-9 at full size): the token's own power of two
         const float ig = i2 / sg;
         ah4 gh[DT], gl[DT];
 #pragma unroll
         for (int s = 0; s < DT; ++s) attn_split4(gb[s][0] * sg, gb[s][1] * sg, gb[s][2] * sg, gb[s][3] * sg, gh[s], gl[s]);
-        constexpr int HB = MT < MLP_HB ? MT : MLP_HB;
         f32x4 out[DT];
 #pragma unroll
         for (int mt = 0; mt < DT; ++mt) out[mt] = f32x4{0, 0, 0, 0};
 #pragma unroll 1
         for (int hb = 0; hb < MT; hb += HB) {
-            f32x4 e[HB];
+            f32x4 e[HB], uc[HB];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) uc[j] = un[j];
+            if (hb + HB < MT) load_u(tile, hb + HB, un);
+            else load_u(tile + tstep, 0, un);
 #pragma unroll
             for (int j = 0; j < HB; ++j) {
                 const int nt = hb + j;
@@ -604,7 +643,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_bwd_h_kernel(const Mlp
                     const ah4 ah = *reinterpret_cast<const ah4*>(W2h + wo + 16 * s), al = *reinterpret_cast<const ah4*>(W2l + wo + 16 * s);
                     DTS_MMH3(acc, ah, al, gh[s], gl[s]);
                 }
-                const f32x4 u = live ? *reinterpret_cast<const f32x4*>(p.U + tok * (long long)M + 16 * nt + 4 * g) : f32x4{0, 0, 0, 0};
+                const f32x4 u = uc[j];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] = acc[q] * ig * gelu_grad_f(u[q]);
                 e[j] = acc;
