@@ -507,8 +507,9 @@ def roofline(gemm, achieved, kernel_ms, launches, flop_per_launch, n_windows, st
             "peak_source": "dense f16 MFMA peak 2500 TFLOP/s / 3 MFMA products per algorithmic product (f16x3 split)",
             "mfma_executed_tflops": 3.0 * achieved * 65536.0 / 66816.0,
             "vs_fp32_matrix_peak": achieved / FP32_MATRIX_PEAK_TFLOPS,
-            "note": "live bound is vector-instruction issue (about 12.6 k issue cycles per 32-chain step against 6.5 k of matrix "
-                    "pipe, shader clock 1.9 GHz under load), not the matrix pipe: DESIGN.md 3.1 item 3"}
+            "note": "live bound is vector-instruction issue under a power limit (12.2 k SIMD cycles per 32-chain step against 6.8 k of matrix "
+                    "pipe, VALU issue active 89 %, shader clock 1.87 GHz under load: profiles/r03/pmc_util_f16x3.json), not the matrix pipe: "
+                    "DESIGN.md 3.1"}
 
 
 def cpu_baseline_and_parity(model, sampled, n_cpu_windows, modes):
