@@ -25,6 +25,17 @@ typedef _Float16 ah4 __attribute__((ext_vector_type(4)));
         DTS_MMH(acc, ah, bh);         \
     } while (0)
 
+// the same on v_mfma_f32_16x16x32_f16: eight k per lane (k = 8 (lane >> 4) + j), twice the work of the x16 shape in the same 16.5 cycles
+typedef _Float16 ah8 __attribute__((ext_vector_type(8)));
+#define DTS_MMH32(acc, a, b) (acc) = __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (acc), 0, 0, 0)
+#define DTS_MMH3_32(acc, ah, al, bh, bl) \
+    do {                                 \
+        DTS_MMH32(acc, al, bh);          \
+        DTS_MMH32(acc, ah, bl);          \
+        DTS_MMH32(acc, ah, bh);          \
+    } while (0)
+__device__ __forceinline__ ah8 ah8_of(const ah4& a, const ah4& b) { return ah8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+
 #ifndef DTS_SPLIT_RNE
 #define DTS_SPLIT_RNE 0              // 1: both halves rounded to nearest (24 bits, 4 + conversions per element); 0: truncating split (22 bits, 3 per element)
 #endif
@@ -432,14 +443,23 @@ __device__ __forceinline__ void mlp_stage_weights(const float* Wa /*[M][D]*/, co
         *reinterpret_cast<ah4*>(Ah + n * KSH + 4 * c) = hi;
         *reinterpret_cast<ah4*>(Al + n * KSH + 4 * c) = lo;
     }
+    // Wb's columns are the k of the second product, whose B operand is the hidden tile in accumulator layout.  With 32-wide products a lane's eight k
+    // are its accumulator quads of TWO neighbouring 16-blocks of hidden units: inside every 32-column group the quad (block w, rows 4 q ..) sits at 8 q + 4 w.
+    constexpr bool K32 = (DT % 2 == 0) && (MT % 2 == 0);
     for (int i = threadIdx.x; i < D * (M / 4); i += 64 * MLP_WAVES) {
         const int n = i / (M / 4), c = i - n * (M / 4);
         ah4 hi, lo;
         load_split4(Wb + (size_t)n * M + 4 * c, sb, hi, lo);
-        *reinterpret_cast<ah4*>(Bh + n * MSH + 4 * c) = hi;
-        *reinterpret_cast<ah4*>(Bl + n * MSH + 4 * c) = lo;
+        const int col = K32 ? 32 * (c >> 3) + 8 * (c & 3) + 4 * ((c >> 2) & 1) : 4 * c;
+        *reinterpret_cast<ah4*>(Bh + n * MSH + col) = hi;
+        *reinterpret_cast<ah4*>(Bl + n * MSH + col) = lo;
     }
 }
+
+// column of a token row that float4 number s of lane group g holds: 16-wide products: 16 s + 4 g; 32-wide: the lane's eight k of chunk s / 2 are
+// 32 (s / 2) + 8 g .. + 7, as two float4
+template <bool K32>
+__device__ __forceinline__ int mlp_col(int s, int g) { return K32 ? 32 * (s >> 1) + 8 * g + 4 * (s & 1) : 16 * s + 4 * g; }
 
 // power of two for the values a token's four lanes hold (n f32x4 each): the B-operand column of that token
 template <int N>
@@ -468,22 +488,23 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_fwd_h_kernel(const Mlp
     mlp_stage_weights<DT, MT>(p.W0, p.W2, W0h, W0l, W2h, W2l, red, s0, s2);
     __syncthreads();
     const float i0 = 1.0f / s0, i2 = 1.0f / s2;
+    constexpr int HB = MT < MLP_HB ? MT : MLP_HB;
+    constexpr bool K32 = (DT % 2 == 0) && (MT % 2 == 0) && (HB % 2 == 0);      // both products on v_mfma_f32_16x16x32_f16
     f32x4 lw[DT], lb[DT];
 #pragma unroll
     for (int s = 0; s < DT; ++s) {
-        lw[s] = *reinterpret_cast<const f32x4*>(p.lnw + 16 * s + 4 * g);
-        lb[s] = *reinterpret_cast<const f32x4*>(p.lnb + 16 * s + 4 * g);
+        lw[s] = *reinterpret_cast<const f32x4*>(p.lnw + mlp_col<K32>(s, g));
+        lb[s] = *reinterpret_cast<const f32x4*>(p.lnb + mlp_col<K32>(s, g));
     }
     const long long n_tiles = (p.rows + 15) / 16;
-    // one workgroup per CU (the weights fill its LDS), two waves per SIMD: the X tile of the wave's next iteration is requested before this one's
-    // products, and the residual add at the end uses the copy in registers instead of reading X again
+    // one workgroup per CU (the weights fill its LDS), two waves per SIMD: the X tile of the wave's next iteration is requested before this one's products
     const long long tile0 = (long long)blockIdx.x * MLP_WAVES + wave, tstep = (long long)gridDim.x * MLP_WAVES;
     auto load_tile = [&](long long tile, f32x4 (&dst)[DT]) {
         const long long tok = tile * 16 + r16;
         const bool live = tile < n_tiles && tok < p.rows;
-        const float* xr = p.X + (live ? tok : 0) * (long long)D + 4 * g;
+        const float* xr = p.X + (live ? tok : 0) * (long long)D;
 #pragma unroll
-        for (int s = 0; s < DT; ++s) dst[s] = live ? *reinterpret_cast<const f32x4*>(xr + 16 * s) : f32x4{0, 0, 0, 0};
+        for (int s = 0; s < DT; ++s) dst[s] = live ? *reinterpret_cast<const f32x4*>(xr + mlp_col<K32>(s, g)) : f32x4{0, 0, 0, 0};
     };
     f32x4 xn[DT];
     load_tile(tile0, xn);
@@ -491,11 +512,11 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_fwd_h_kernel(const Mlp
         asm volatile("" ::: "memory");        // the weight fragments are re-read from LDS every tile
         const long long tok = tile * 16 + r16;
         const bool live = tok < p.rows;
-        f32x4 xb[DT], xres[DT];
+        f32x4 xb[DT];
         float sum = 0.0f;
 #pragma unroll
         for (int s = 0; s < DT; ++s) {
-            xb[s] = xres[s] = xn[s];
+            xb[s] = xn[s];
             sum += (xb[s][0] + xb[s][1]) + (xb[s][2] + xb[s][3]);
         }
         load_tile(tile + tstep, xn);
@@ -522,7 +543,6 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_fwd_h_kernel(const Mlp
         ah4 xh[DT], xl[DT];
 #pragma unroll
         for (int s = 0; s < DT; ++s) attn_split4(xb[s][0] * sx, xb[s][1] * sx, xb[s][2] * sx, xb[s][3] * sx, xh[s], xl[s]);
-        constexpr int HB = MT < MLP_HB ? MT : MLP_HB;
         f32x4 out[DT];
 #pragma unroll
         for (int mt = 0; mt < DT; ++mt) out[mt] = f32x4{0, 0, 0, 0};
@@ -533,11 +553,20 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_fwd_h_kernel(const Mlp
             for (int j = 0; j < HB; ++j) {
                 const int nt = hb + j;
                 f32x4 acc = {0, 0, 0, 0};
-                const int wo = (16 * nt + r16) * KSH + 4 * g;
+                if constexpr (K32) {
+                    const int wo = (16 * nt + r16) * KSH + 8 * g;
 #pragma unroll
-                for (int s = 0; s < DT; ++s) {
-                    const ah4 ah = *reinterpret_cast<const ah4*>(W0h + wo + 16 * s), al = *reinterpret_cast<const ah4*>(W0l + wo + 16 * s);
-                    DTS_MMH3(acc, ah, al, xh[s], xl[s]);
+                    for (int s = 0; s < DT / 2; ++s) {
+                        const ah8 ah = *reinterpret_cast<const ah8*>(W0h + wo + 32 * s), al = *reinterpret_cast<const ah8*>(W0l + wo + 32 * s);
+                        DTS_MMH3_32(acc, ah, al, ah8_of(xh[2 * s], xh[2 * s + 1]), ah8_of(xl[2 * s], xl[2 * s + 1]));
+                    }
+                } else {
+                    const int wo = (16 * nt + r16) * KSH + 4 * g;
+#pragma unroll
+                    for (int s = 0; s < DT; ++s) {
+                        const ah4 ah = *reinterpret_cast<const ah4*>(W0h + wo + 16 * s), al = *reinterpret_cast<const ah4*>(W0l + wo + 16 * s);
+                        DTS_MMH3(acc, ah, al, xh[s], xl[s]);
+                    }
                 }
                 acc = acc * ix + *reinterpret_cast<const f32x4*>(p.b0 + 16 * nt + 4 * g);
                 if (p.U && live) *reinterpret_cast<f32x4*>(p.U + tok * (long long)M + 16 * nt + 4 * g) = acc;
@@ -553,11 +582,20 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_fwd_h_kernel(const Mlp
 #pragma unroll
             for (int mt = 0; mt < DT; ++mt) {
                 f32x4 part = {0, 0, 0, 0};
+                if constexpr (K32) {
 #pragma unroll
-                for (int j = 0; j < HB; ++j) {
-                    const int wo = (16 * mt + r16) * MSH + 16 * (hb + j) + 4 * g;
-                    const ah4 ah = *reinterpret_cast<const ah4*>(W2h + wo), al = *reinterpret_cast<const ah4*>(W2l + wo);
-                    DTS_MMH3(part, ah, al, uh[j], ul[j]);
+                    for (int j = 0; j < HB; j += 2) {
+                        const int wo = (16 * mt + r16) * MSH + 16 * (hb + j) + 8 * g;
+                        const ah8 ah = *reinterpret_cast<const ah8*>(W2h + wo), al = *reinterpret_cast<const ah8*>(W2l + wo);
+                        DTS_MMH3_32(part, ah, al, ah8_of(uh[j], uh[j + 1]), ah8_of(ul[j], ul[j + 1]));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < HB; ++j) {
+                        const int wo = (16 * mt + r16) * MSH + 16 * (hb + j) + 4 * g;
+                        const ah4 ah = *reinterpret_cast<const ah4*>(W2h + wo), al = *reinterpret_cast<const ah4*>(W2l + wo);
+                        DTS_MMH3(part, ah, al, uh[j], ul[j]);
+                    }
                 }
                 out[mt] += part * iu;
             }
@@ -567,7 +605,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_fwd_h_kernel(const Mlp
             for (int mt = 0; mt < DT; ++mt) {
                 const int n0 = 16 * mt + 4 * g;
                 f32x4 v = out[mt] + *reinterpret_cast<const f32x4*>(p.b2 + n0);
-                v += xres[mt];                                          // x + mlp(ln(x)): columns 16 mt + 4 g .. of this lane's token
+                v += *reinterpret_cast<const f32x4*>(p.X + tok * (long long)D + n0);
                 *reinterpret_cast<f32x4*>(p.Y + tok * (long long)D + n0) = v;
             }
         }
@@ -590,15 +628,16 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_bwd_h_kernel(const Mlp
     const float i2 = 1.0f / s2, i0 = 1.0f / s0;
     const long long n_tiles = (p.rows + 15) / 16;
     constexpr int HB = MT < MLP_HB ? MT : MLP_HB;
+    constexpr bool K32 = (DT % 2 == 0) && (MT % 2 == 0) && (HB % 2 == 0);      // both products on v_mfma_f32_16x16x32_f16
     // two waves per SIMD: the G tile of the wave's next iteration and the saved pre-activations of the next block of hidden units are requested a
     // phase ahead of their use
     const long long tile0 = (long long)blockIdx.x * MLP_WAVES + wave, tstep = (long long)gridDim.x * MLP_WAVES;
     auto load_g = [&](long long tile, f32x4 (&dst)[DT]) {
         const long long tok = tile * 16 + r16;
         const bool live = tile < n_tiles && tok < p.rows;
-        const float* gr = p.G + (live ? tok : 0) * (long long)D + 4 * g;
+        const float* gr = p.G + (live ? tok : 0) * (long long)D;
 #pragma unroll
-        for (int s = 0; s < DT; ++s) dst[s] = live ? *reinterpret_cast<const f32x4*>(gr + 16 * s) : f32x4{0, 0, 0, 0};
+        for (int s = 0; s < DT; ++s) dst[s] = live ? *reinterpret_cast<const f32x4*>(gr + mlp_col<K32>(s, g)) : f32x4{0, 0, 0, 0};
     };
     auto load_u = [&](long long tile, int hb, f32x4 (&dst)[HB]) {
         const long long tok = tile * 16 + r16;
@@ -637,11 +676,20 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_bwd_h_kernel(const Mlp
             for (int j = 0; j < HB; ++j) {
                 const int nt = hb + j;
                 f32x4 acc = {0, 0, 0, 0};
-                const int wo = (16 * nt + r16) * KSH + 4 * g;
+                if constexpr (K32) {
+                    const int wo = (16 * nt + r16) * KSH + 8 * g;
 #pragma unroll
-                for (int s = 0; s < DT; ++s) {
-                    const ah4 ah = *reinterpret_cast<const ah4*>(W2h + wo + 16 * s), al = *reinterpret_cast<const ah4*>(W2l + wo + 16 * s);
-                    DTS_MMH3(acc, ah, al, gh[s], gl[s]);
+                    for (int s = 0; s < DT / 2; ++s) {
+                        const ah8 ah = *reinterpret_cast<const ah8*>(W2h + wo + 32 * s), al = *reinterpret_cast<const ah8*>(W2l + wo + 32 * s);
+                        DTS_MMH3_32(acc, ah, al, ah8_of(gh[2 * s], gh[2 * s + 1]), ah8_of(gl[2 * s], gl[2 * s + 1]));
+                    }
+                } else {
+                    const int wo = (16 * nt + r16) * KSH + 4 * g;
+#pragma unroll
+                    for (int s = 0; s < DT; ++s) {
+                        const ah4 ah = *reinterpret_cast<const ah4*>(W2h + wo + 16 * s), al = *reinterpret_cast<const ah4*>(W2l + wo + 16 * s);
+                        DTS_MMH3(acc, ah, al, gh[s], gl[s]);
+                    }
                 }
                 const f32x4 u = uc[j];
 #pragma unroll
@@ -656,11 +704,20 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_bwd_h_kernel(const Mlp
 #pragma unroll
             for (int mt = 0; mt < DT; ++mt) {
                 f32x4 part = {0, 0, 0, 0};
+                if constexpr (K32) {
 #pragma unroll
-                for (int j = 0; j < HB; ++j) {
-                    const int wo = (16 * mt + r16) * MSH + 16 * (hb + j) + 4 * g;
-                    const ah4 ah = *reinterpret_cast<const ah4*>(W0h + wo), al = *reinterpret_cast<const ah4*>(W0l + wo);
-                    DTS_MMH3(part, ah, al, eh[j], el[j]);
+                    for (int j = 0; j < HB; j += 2) {
+                        const int wo = (16 * mt + r16) * MSH + 16 * (hb + j) + 8 * g;
+                        const ah8 ah = *reinterpret_cast<const ah8*>(W0h + wo), al = *reinterpret_cast<const ah8*>(W0l + wo);
+                        DTS_MMH3_32(part, ah, al, ah8_of(eh[j], eh[j + 1]), ah8_of(el[j], el[j + 1]));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < HB; ++j) {
+                        const int wo = (16 * mt + r16) * MSH + 16 * (hb + j) + 4 * g;
+                        const ah4 ah = *reinterpret_cast<const ah4*>(W0h + wo), al = *reinterpret_cast<const ah4*>(W0l + wo);
+                        DTS_MMH3(part, ah, al, eh[j], el[j]);
+                    }
                 }
                 out[mt] += part * ie;
             }
