@@ -70,11 +70,42 @@ int set_lds(mpv_ctx* ctx, K kernel, size_t bytes) {
     return MPV_OK;
 }
 
+// Linear layers follow the engine's gemm mode (set by forward / backward / the sampler on entry): split-f16 products unless MPV_GEMM_F32
+thread_local bool t_lin_f16 = false;
+
 int lin(mpv_ctx* ctx, const float* X, int ldx, const float* W, const float* bias, int K, int N, long long rows, float* Y, int ldy, int pro = PRO_NONE,
         const float* P1 = nullptr, const float* P2 = nullptr, int ldp = 0, const float* R = nullptr, int ldr = 0, int accumulate = 0, long long xblk = 0,
         long long yblk = 0) {
     LinArgs a{X, ldx, W, bias, R, ldr, Y, ldy, P1, P2, ldp, rows, K, N, pro, accumulate, xblk, yblk};
     static const bool tile_kernel = getenv("MPV_DTS_LIN_TILE") != nullptr;              // validation aid: the workgroup-tile kernel for every call
+    static const bool lin_exact = getenv("MPV_DTS_LIN_F32") != nullptr;                 // A/B aid: keep the Linear layers on the fp32 matrix pipe
+    if (t_lin_f16 && !lin_exact && !tile_kernel && K % 32 == 0 && N % 16 == 0) {        // split-f16 products (gemm mode f16x3), dts_attn_h.h
+        const size_t wl = 2 * sizeof(_Float16) * (size_t)N * (K + 8) + sizeof(float) * LINW_WAVES;
+        const long long wtiles = ((rows + 15) / 16 + LINW_WAVES - 1) / LINW_WAVES;
+        const dim3 wblock(64 * LINW_WAVES);
+#define DTS_LINWH(KT_)                                                                                                               \
+    do {                                                                                                                             \
+        if (int rc = set_lds(ctx, dts_lin_wave_h_kernel<KT_>, wl)) return rc;                                                        \
+        static thread_local std::map<size_t, int> known;                      /* LDS bytes -> resident workgroups per CU */         \
+        int& resident = known[wl];                                                                                                   \
+        if (!resident)                                                                                                               \
+            MPV_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, dts_lin_wave_h_kernel<KT_>, 64 * LINW_WAVES, wl)); \
+        const dim3 wgrid((unsigned)std::min<long long>(wtiles, (long long)std::max(1, resident) * ctx->cu_count));                   \
+        hipLaunchKernelGGL(dts_lin_wave_h_kernel<KT_>, wgrid, wblock, wl, ctx->stream, a);                                           \
+        MPV_HIP_TRY(ctx, hipGetLastError());                                                                                         \
+        return MPV_OK;                                                                                                               \
+    } while (0)
+        switch (K / 16) {
+            case 2: DTS_LINWH(2);
+            case 4: DTS_LINWH(4);
+            case 6: DTS_LINWH(6);
+            case 8: DTS_LINWH(8);
+            case 12: DTS_LINWH(12);
+            case 16: DTS_LINWH(16);
+            default: break;
+        }
+#undef DTS_LINWH
+    }
     if (!tile_kernel && K % 16 == 0 && N % 16 == 0) {
         const size_t wl = sizeof(float) * (size_t)N * (K + 4);
         const long long wtiles = ((rows + 15) / 16 + LINW_WAVES - 1) / LINW_WAVES;
@@ -344,6 +375,7 @@ int mlp_block(mpv_ctx* ctx, DtsEngine& e, const float* x, const float* lnw, cons
 // ---- forward: Transformer.forward (transformer.py:422-438); save = the input-gradient pass follows ----------------------------
 int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t, bool save) {
     const int L = e.L, F = e.F, D = e.D, H = e.H, M = e.M;
+    t_lin_f16 = e.d.gemm != MPV_GEMM_F32;
     const long long T = (long long)B * L;
     const float scale = 1.0f / std::sqrt((float)e.hd);
     const float* ada_t = e.ada + (size_t)t * e.n_ada * 2 * D;
@@ -422,6 +454,7 @@ int attn_bwd(mpv_ctx* ctx, DtsEngine& e, int B, const float* Q, int ldq, const f
 // ---- input gradient: gout = dLoss/d(trend + season_error) [B][L][F] -> gx = dLoss/dx [B][L][F]; uses the saved forward --------
 int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, int t) {
     const int L = e.L, F = e.F, D = e.D, M = e.M;
+    t_lin_f16 = e.d.gemm != MPV_GEMM_F32;
     const long long T = (long long)B * L;
     const float* ada_t = e.ada + (size_t)t * e.n_ada * 2 * D;
     hipStream_t st = ctx->stream;

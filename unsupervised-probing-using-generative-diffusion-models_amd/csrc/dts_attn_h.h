@@ -729,4 +729,160 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_bwd_h_kernel(const Mlp
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Token-wise Linear (dts_lin_wave_kernel of dts_kernels.h: same arguments, prologues, epilogues, persistent grid and load order) on the f16 matrix
+// pipe: K a multiple of 32, X and W as power-of-two scaled two-term f16 splits (X per token, W per matrix while it is staged into LDS as hi / lo
+// planes -- the same bytes as its fp32 image), three v_mfma_f32_16x16x32_f16 per 32 k.  A lane holds the eight consecutive columns 32 c + 8 g ..
+// of its token (two float4 loads), which is the B operand as it stands.  The exact kernel's 16 x 16 x 4 fp32 products were 40 us of its 118 us per launch.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(64 * LINW_WAVES) void dts_lin_wave_h_kernel(const LinArgs p) {
+    static_assert(KT % 2 == 0, "K must be a multiple of 32");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    constexpr int K = 16 * KT, KSH = K + 8;
+    _Float16* Wh = reinterpret_cast<_Float16*>(ldsb);      // [N][KSH]
+    _Float16* Wlo = Wh + p.N * KSH;
+    float* red = reinterpret_cast<float*>(Wlo + p.N * KSH);  // [LINW_WAVES]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    float mx = 0.0f;
+    for (int i = tid; i < p.N * (K / 4); i += 64 * LINW_WAVES) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(p.W + 4 * (size_t)i);
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(w[0]), fabsf(w[1])), fmaxf(fabsf(w[2]), fabsf(w[3]))));
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = 0.0f;
+    for (int w = 0; w < LINW_WAVES; ++w) mx = fmaxf(mx, red[w]);
+    const float sw = pow2_scale(mx), iw = 1.0f / sw;
+    for (int i = tid; i < p.N * (K / 4); i += 64 * LINW_WAVES) {
+        const int n = i / (K / 4), c = i - n * (K / 4);
+        ah4 hi, lo;
+        load_split4(p.W + (size_t)n * K + 4 * c, sw, hi, lo);
+        *reinterpret_cast<ah4*>(Wh + n * KSH + 4 * c) = hi;
+        *reinterpret_cast<ah4*>(Wlo + n * KSH + 4 * c) = lo;
+    }
+    __syncthreads();
+    const long long n_tiles = (p.rows + 15) / 16;
+    const long long ys = p.yblk ? p.yblk : 16;
+    // float4 number s of the lane: columns 32 (s / 2) + 8 g + 4 (s & 1) ..; in the 16-column blocked layout that is block 2 (s / 2) + (g >> 1)
+    auto x_off = [&](int s) -> long long {
+        const int col = 32 * (s >> 1) + 8 * g + 4 * (s & 1);
+        return p.xblk ? (long long)(col >> 4) * p.xblk + (col & 15) : col;
+    };
+    constexpr bool AHEAD = KT <= 4;
+    const long long tile0 = (long long)blockIdx.x * LINW_WAVES + wave, tstep = (long long)gridDim.x * LINW_WAVES;
+    auto load_tile = [&](long long tile, f32x4 (&dst)[KT]) {
+        const long long tok = tile * 16 + r16;
+        const bool live = tile < n_tiles && tok < p.rows;
+        const float* xr = p.X + (live ? tok : 0) * (long long)p.ldx;
+#pragma unroll
+        for (int s = 0; s < KT; ++s) dst[s] = live ? *reinterpret_cast<const f32x4*>(xr + x_off(s)) : f32x4{0, 0, 0, 0};
+    };
+    f32x4 xn[AHEAD ? KT : 1];
+    if constexpr (AHEAD) load_tile(tile0, xn);
+    for (long long tile = tile0; tile < n_tiles; tile += tstep) {
+        asm volatile("" ::: "memory");              // weight fragments stay in LDS
+        const long long tok = tile * 16 + r16;
+        const bool live = tok < p.rows;
+        f32x4 xb[KT];
+        if constexpr (AHEAD) {
+#pragma unroll
+            for (int s = 0; s < KT; ++s) xb[s] = xn[s];
+        } else {
+            load_tile(tile, xb);
+        }
+        if (p.pro == PRO_LN || p.pro == PRO_ADALN) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KT; ++s) sum += (xb[s][0] + xb[s][1]) + (xb[s][2] + xb[s][3]);
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum / (float)K;
+            float q = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KT; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xb[s][e] -= mean;
+                    q += xb[s][e] * xb[s][e];
+                }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            const float rstd = 1.0f / sqrtf(q / (float)K + 1e-5f);
+#pragma unroll
+            for (int s = 0; s < KT; ++s) {
+                const int col = 32 * (s >> 1) + 8 * g + 4 * (s & 1);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(p.P1 + col), b = *reinterpret_cast<const f32x4*>(p.P2 + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = xb[s][e] * rstd;
+                    xb[s][e] = (p.pro == PRO_ADALN) ? xh * (1.0f + a[e]) + b[e] : xh * a[e] + b[e];
+                }
+            }
+        } else if (p.pro == PRO_GELUGRAD) {
+            const float* ur = p.P1 + (live ? tok : 0) * (long long)p.ldp;
+#pragma unroll
+            for (int s = 0; s < KT; ++s) {
+                const f32x4 u = live ? *reinterpret_cast<const f32x4*>(ur + 32 * (s >> 1) + 8 * g + 4 * (s & 1)) : f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xb[s][e] *= gelu_grad_f(u[e]);
+            }
+        } else if (p.pro == PRO_GELU) {
+#pragma unroll
+            for (int s = 0; s < KT; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xb[s][e] = gelu_f(xb[s][e]);
+        }
+        const float sx = token_scale<KT>(xb);
+        const float ix = iw / sx;
+        ah8 xh[KT / 2], xl[KT / 2];
+#pragma unroll
+        for (int c = 0; c < KT / 2; ++c) {
+            ah4 h0, l0, h1, l1;
+            attn_split4(xb[2 * c][0] * sx, xb[2 * c][1] * sx, xb[2 * c][2] * sx, xb[2 * c][3] * sx, h0, l0);
+            attn_split4(xb[2 * c + 1][0] * sx, xb[2 * c + 1][1] * sx, xb[2 * c + 1][2] * sx, xb[2 * c + 1][3] * sx, h1, l1);
+            xh[c] = ah8_of(h0, h1);
+            xl[c] = ah8_of(l0, l1);
+        }
+        // output blocks four at a time: everything the four epilogues add (residual, accumulation target) is requested up front, ahead of the next
+        // tile's X (see dts_lin_wave_kernel)
+        const int NT = p.N >> 4;
+        for (int nt0 = 0; nt0 < NT; nt0 += 4) {
+            f32x4 addend[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int nt = nt0 + i;
+                addend[i] = f32x4{0, 0, 0, 0};
+                if (live && nt < NT) {
+                    if (p.R) addend[i] = *reinterpret_cast<const f32x4*>(p.R + tok * (long long)p.ldr + 16 * nt + 4 * g);
+                    if (p.accumulate) addend[i] += *reinterpret_cast<const f32x4*>(p.Y + tok * (long long)p.ldy + ys * nt + 4 * g);
+                }
+            }
+            if constexpr (AHEAD) {
+                if (nt0 == 0) load_tile(tile + tstep, xn);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int nt = nt0 + i;
+                if (nt >= NT) break;
+                const int n0 = 16 * nt + 4 * g;
+                f32x4 acc = {0, 0, 0, 0};
+                const int wo = (16 * nt + r16) * KSH + 8 * g;
+#pragma unroll
+                for (int c = 0; c < KT / 2; ++c) {
+                    const ah8 ah = *reinterpret_cast<const ah8*>(Wh + wo + 32 * c), al = *reinterpret_cast<const ah8*>(Wlo + wo + 32 * c);
+                    DTS_MMH3_32(acc, ah, al, xh[c], xl[c]);
+                }
+                if (live) {
+                    f32x4 v = acc * ix;
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n0);
+                    v += addend[i];
+                    *reinterpret_cast<f32x4*>(p.Y + tok * (long long)p.ldy + ys * nt + 4 * g) = v;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace dts
