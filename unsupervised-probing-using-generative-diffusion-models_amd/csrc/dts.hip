@@ -75,25 +75,35 @@ thread_local bool t_lin_f16 = false;
 
 int lin(mpv_ctx* ctx, const float* X, int ldx, const float* W, const float* bias, int K, int N, long long rows, float* Y, int ldy, int pro = PRO_NONE,
         const float* P1 = nullptr, const float* P2 = nullptr, int ldp = 0, const float* R = nullptr, int ldr = 0, int accumulate = 0, long long xblk = 0,
-        long long yblk = 0) {
+        long long yblk = 0, const float* lnx = nullptr, const float* lng = nullptr, int ln_ada = 0) {
     LinArgs a{X, ldx, W, bias, R, ldr, Y, ldy, P1, P2, ldp, rows, K, N, pro, accumulate, xblk, yblk};
+    a.lnx = lnx; a.lng = lng; a.ln_ada = ln_ada;
+    // (lnx: the fused LayerNorm backward of dts_lin_wave_h_kernel; -100 = not available for this shape / mode, the caller runs the two kernels)
+    if (lnx && !(t_lin_f16 && !getenv("MPV_DTS_LIN_F32") && !getenv("MPV_DTS_LIN_TILE") && !getenv("MPV_DTS_NO_LNFUSE") && K % 32 == 0 && N % 16 == 0 && N <= 64 &&
+                 !R && !yblk && ldy == N))
+        return -100;
     static const bool tile_kernel = getenv("MPV_DTS_LIN_TILE") != nullptr;              // validation aid: the workgroup-tile kernel for every call
     static const bool lin_exact = getenv("MPV_DTS_LIN_F32") != nullptr;                 // A/B aid: keep the Linear layers on the fp32 matrix pipe
     if (t_lin_f16 && !lin_exact && !tile_kernel && K % 32 == 0 && N % 16 == 0) {        // split-f16 products (gemm mode f16x3), dts_attn_h.h
         const size_t wl = 2 * sizeof(_Float16) * (size_t)N * (K + 8) + sizeof(float) * LINW_WAVES;
         const long long wtiles = ((rows + 15) / 16 + LINW_WAVES - 1) / LINW_WAVES;
         const dim3 wblock(64 * LINW_WAVES);
-#define DTS_LINWH(KT_)                                                                                                               \
+#define DTS_LINWH_(KT_, LNB_)                                                                                                        \
     do {                                                                                                                             \
-        if (int rc = set_lds(ctx, dts_lin_wave_h_kernel<KT_>, wl)) return rc;                                                        \
+        if (int rc = set_lds(ctx, dts_lin_wave_h_kernel<KT_, LNB_>, wl)) return rc;                                                  \
         static thread_local std::map<size_t, int> known;                      /* LDS bytes -> resident workgroups per CU */         \
         int& resident = known[wl];                                                                                                   \
         if (!resident)                                                                                                               \
-            MPV_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, dts_lin_wave_h_kernel<KT_>, 64 * LINW_WAVES, wl)); \
+            MPV_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, dts_lin_wave_h_kernel<KT_, LNB_>, 64 * LINW_WAVES, wl)); \
         const dim3 wgrid((unsigned)std::min<long long>(wtiles, (long long)std::max(1, resident) * ctx->cu_count));                   \
-        hipLaunchKernelGGL(dts_lin_wave_h_kernel<KT_>, wgrid, wblock, wl, ctx->stream, a);                                           \
+        hipLaunchKernelGGL((dts_lin_wave_h_kernel<KT_, LNB_>), wgrid, wblock, wl, ctx->stream, a);                                   \
         MPV_HIP_TRY(ctx, hipGetLastError());                                                                                         \
         return MPV_OK;                                                                                                               \
+    } while (0)
+#define DTS_LINWH(KT_)                  \
+    do {                                \
+        if (lnx) DTS_LINWH_(KT_, true); \
+        else DTS_LINWH_(KT_, false);    \
     } while (0)
         switch (K / 16) {
             case 2: DTS_LINWH(2);
@@ -105,6 +115,7 @@ int lin(mpv_ctx* ctx, const float* X, int ldx, const float* W, const float* bias
             default: break;
         }
 #undef DTS_LINWH
+#undef DTS_LINWH_
     }
     if (!tile_kernel && K % 16 == 0 && N % 16 == 0) {
         const size_t wl = sizeof(float) * (size_t)N * (K + 4);
@@ -272,8 +283,12 @@ int mlp_fwd(mpv_ctx* ctx, int D, int M, const float* X, const float* W0, const f
 }
 
 // d_ln = W0^T (gelu'(u) * (W2^T g)) in one kernel (see dts_mlp_bwd_kernel); -100 when no fused instance exists
-int mlp_bwd(mpv_ctx* ctx, int D, int M, const float* G, const float* U, const float* W2T, const float* W0T, float* Y, long long rows, bool f16) {
+// lnx / lng: the fused LayerNorm backward of dts_mlp_bwd_h_kernel (Y accumulates the LayerNorm's input gradient; f16 instances only: -100 otherwise)
+int mlp_bwd(mpv_ctx* ctx, int D, int M, const float* G, const float* U, const float* W2T, const float* W0T, float* Y, long long rows, bool f16,
+            const float* lnx = nullptr, const float* lng = nullptr) {
     MlpBwdArgs a{G, U, W2T, W0T, Y, rows};
+    if (lnx && (!f16 || getenv("MPV_DTS_NO_LNFUSE"))) return -100;
+    a.lnx = lnx; a.lng = lng;
     const size_t lds = f16 ? 2 * sizeof(_Float16) * ((size_t)M * (D + 8) + (size_t)D * (M + 8)) + sizeof(float) * 2 * MLP_WAVES
                            : sizeof(float) * ((size_t)M * (D + 4) + (size_t)D * (M + 4));
     const long long tiles = ((rows + 15) / 16 + MLP_WAVES - 1) / MLP_WAVES;
@@ -461,6 +476,13 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
     const long long blk = e.blocked ? T * 16 : 0;                       // blocked attention operands, as in forward()
     const long long qo = e.blocked ? (long long)e.H * T * 16 : D;
     const int l3 = e.blocked ? 16 : 3 * D, l2 = e.blocked ? 16 : 2 * D, l1 = e.blocked ? 16 : D;
+    // dx += LayerNorm-backward(x, gamma)(G Wt^T): one kernel where the split-f16 Linear has the fused epilogue, else the product into gC and dts_ln_bwd_kernel
+    auto lin_ln = [&](const float* G, int ldg, const float* Wt, int K, const float* x, const float* gam, int ada, float* dx) -> int {
+        const int rc = lin(ctx, G, ldg, Wt, nullptr, K, D, T, dx, D, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 1, blk, 0, x, gam, ada);
+        if (rc != -100) return rc;
+        DTS_TRY(lin(ctx, G, ldg, Wt, nullptr, K, D, T, e.gC, D, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 0, blk));
+        return ln_bwd(ctx, D, e.gC, x, gam, ada, dx, 1, T);
+    };
     // tail: d_h (decoder output) -> gA, d_season, d_means
     hipLaunchKernelGGL(dts_tail_bwd_kernel, dim3(B), dim3(256), 0, st, gout, e.winv, e.wcs, e.wcm, L, F, D, e.d.combine_taps, e.d.n_dec, e.gA, e.gseason,
                        e.gmeans);
@@ -479,7 +501,10 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
         MPV_HIP_TRY(ctx, hipGetLastError());
         std::swap(gcur, gnext);                                          // gcur = d_x3
         // x3 = x2 + mlp(ln2(x2))
-        const int fused = mlp_bwd(ctx, D, M, gcur, s.u, w.w2_t, w.w0_t, e.gC, T, e.d.gemm != MPV_GEMM_F32);       // d_ln = W0^T (gelu'(u) * (W2^T g)), hidden gradient on chip
+        // d_ln = W0^T (gelu'(u) * (W2^T g)), hidden gradient on chip; in split-f16 mode the kernel also finishes ln2's input gradient into gcur
+        const int both = mlp_bwd(ctx, D, M, gcur, s.u, w.w2_t, w.w0_t, gcur, T, e.d.gemm != MPV_GEMM_F32, s.x2, w.ln2w);
+        if (both != MPV_OK && both != -100) return both;
+        const int fused = both == MPV_OK ? MPV_OK : mlp_bwd(ctx, D, M, gcur, s.u, w.w2_t, w.w0_t, e.gC, T, e.d.gemm != MPV_GEMM_F32);
         if (fused == MPV_OK) {
         } else if (fused != -100) {
             return fused;
@@ -490,7 +515,7 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
             DTS_TRY(lin(ctx, gcur, D, w.w2_t, nullptr, D, M, T, e.gwide, M));
             DTS_TRY(lin(ctx, e.gwide, M, w.w0_t, nullptr, M, D, T, e.gC, D, PRO_GELUGRAD, s.u, nullptr, M));
         }
-        DTS_TRY(ln_bwd(ctx, D, e.gC, s.x2, w.ln2w, 0, gcur, 1, T));     // gcur = d_x2 (so far)
+        if (both != MPV_OK) DTS_TRY(ln_bwd(ctx, D, e.gC, s.x2, w.ln2w, 0, gcur, 1, T));     // gcur = d_x2 (so far)
         // trend / season branches through proj
         hipLaunchKernelGGL(dts_trend_bwd_kernel, dim3(B), dim3(256), sizeof(float) * (3 * F + 3 * D), st, gout, s.t3, w.tw0, w.tw3, e.poly, L, F, D, gcur,
                            (long long)L * D);
@@ -501,13 +526,11 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
         DTS_TRY(lin(ctx, gcur, D, w.wp2_t, nullptr, D, D, T, e.gC, l1, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0, blk));      // d_att2
         DTS_TRY(attn_bwd(ctx, e, B, s.q2, l1, s.kv2, s.kv2 + qo, l2, s.att2, e.gC, s.lse2, e.gqkv, l1, e.gkv, e.gkv + qo, l2));
         DTS_TRY(lin(ctx, e.gkv, l2, w.wkv2_t, nullptr, 2 * D, D, T, e.genc, D, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 1, blk));
-        DTS_TRY(lin(ctx, e.gqkv, l1, w.wq2_t, nullptr, D, D, T, e.gC, D, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 0, blk));
-        DTS_TRY(ln_bwd(ctx, D, e.gC, s.x1, sc2, 1, gcur, 1, T));       // gcur = d_x1
+        DTS_TRY(lin_ln(e.gqkv, l1, w.wq2_t, D, s.x1, sc2, 1, gcur));    // gcur = d_x1
         // x1 = x0 + proj1(attn1(qkv1(ln1(x0))))
         DTS_TRY(lin(ctx, gcur, D, w.wp1_t, nullptr, D, D, T, e.gC, l1, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0, blk));
         DTS_TRY(attn_bwd(ctx, e, B, s.qkv1, l3, s.qkv1 + qo, s.qkv1 + 2 * qo, l3, s.att1, e.gC, s.lse1, e.gqkv, l3, e.gqkv + qo, e.gqkv + 2 * qo, l3));
-        DTS_TRY(lin(ctx, e.gqkv, l3, w.wqkv1_t, nullptr, 3 * D, D, T, e.gC, D, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 0, blk));
-        DTS_TRY(ln_bwd(ctx, D, e.gC, e.xd[i], sc1, 1, gcur, 1, T));    // gcur = d_x0 = gradient w.r.t. the previous block's output
+        DTS_TRY(lin_ln(e.gqkv, l3, w.wqkv1_t, 3 * D, e.xd[i], sc1, 1, gcur));      // gcur = d_x0 = gradient w.r.t. the previous block's output
     }
     if (e.snapshots)                                                     // "g_enc" of mpv_dts_debug_tensor (gseason is free from here on)
         MPV_HIP_TRY(ctx, hipMemcpyAsync(e.gseason, e.genc, sizeof(float) * T * D, hipMemcpyDeviceToDevice, st));
@@ -518,7 +541,9 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
         const EncW& w = e.enc[i];
         const DtsEngine::EncS& s = e.es[i];
         const float* sc = ada_t + (size_t)i * 2 * D;
-        const int fused = mlp_bwd(ctx, D, M, genc, s.u, w.w2_t, w.w0_t, e.gC, T, e.d.gemm != MPV_GEMM_F32);
+        const int both = mlp_bwd(ctx, D, M, genc, s.u, w.w2_t, w.w0_t, genc, T, e.d.gemm != MPV_GEMM_F32, s.x1, w.ln2w);
+        if (both != MPV_OK && both != -100) return both;
+        const int fused = both == MPV_OK ? MPV_OK : mlp_bwd(ctx, D, M, genc, s.u, w.w2_t, w.w0_t, e.gC, T, e.d.gemm != MPV_GEMM_F32);
         if (fused == MPV_OK) {
         } else if (fused != -100) {
             return fused;
@@ -529,11 +554,10 @@ int backward(mpv_ctx* ctx, DtsEngine& e, const float* gout, float* gx, int B, in
             DTS_TRY(lin(ctx, genc, D, w.w2_t, nullptr, D, M, T, e.gwide, M));
             DTS_TRY(lin(ctx, e.gwide, M, w.w0_t, nullptr, M, D, T, e.gC, D, PRO_GELUGRAD, s.u, nullptr, M));
         }
-        DTS_TRY(ln_bwd(ctx, D, e.gC, s.x1, w.ln2w, 0, genc, 1, T));    // genc = d_x1
+        if (both != MPV_OK) DTS_TRY(ln_bwd(ctx, D, e.gC, s.x1, w.ln2w, 0, genc, 1, T));    // genc = d_x1
         DTS_TRY(lin(ctx, genc, D, w.wp_t, nullptr, D, D, T, e.gC, l1, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0, blk));
         DTS_TRY(attn_bwd(ctx, e, B, s.qkv, l3, s.qkv + qo, s.qkv + 2 * qo, l3, s.att, e.gC, s.lse, e.gqkv, l3, e.gqkv + qo, e.gqkv + 2 * qo, l3));
-        DTS_TRY(lin(ctx, e.gqkv, l3, w.wqkv_t, nullptr, 3 * D, D, T, e.gC, D, PRO_NONE, nullptr, nullptr, 0, nullptr, 0, 0, blk));
-        DTS_TRY(ln_bwd(ctx, D, e.gC, e.xe[i], sc, 1, genc, 1, T));     // genc = d_x0
+        DTS_TRY(lin_ln(e.gqkv, l3, w.wqkv_t, 3 * D, e.xe[i], sc, 1, genc));        // genc = d_x0
     }
     (void)tmp;
     hipLaunchKernelGGL(dts_embed_bwd_kernel, g1d(T * F * 16), dim3(256), 0, st, genc, gdec0, e.wemb, L, F, D, T * F, gx);

@@ -722,12 +722,65 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_bwd_h_kernel(const Mlp
                 out[mt] += part * ie;
             }
         }
-        if (live) {
+        if (p.lnx) {                                                     // fused LayerNorm backward (one workgroup per CU: the registers are there)
+            f32x4 lx[DT], old[DT];
+#pragma unroll
+            for (int mt = 0; mt < DT; ++mt) {
+                lx[mt] = live ? *reinterpret_cast<const f32x4*>(p.lnx + tok * (long long)D + 16 * mt + 4 * g) : f32x4{0, 0, 0, 0};
+                old[mt] = live ? *reinterpret_cast<const f32x4*>(p.Y + tok * (long long)D + 16 * mt + 4 * g) : f32x4{0, 0, 0, 0};
+            }
+            float sum = 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < DT; ++mt) sum += (lx[mt][0] + lx[mt][1]) + (lx[mt][2] + lx[mt][3]);
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum / (float)D;
+            float q = 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < DT; ++mt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lx[mt][e] -= mean;
+                    q += lx[mt][e] * lx[mt][e];
+                }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
+            float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < DT; ++mt) {
+                const f32x4 gw = *reinterpret_cast<const f32x4*>(p.lng + 16 * mt + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lx[mt][e] *= rstd;                                   // xhat
+                    out[mt][e] *= gw[e];
+                    m1 += out[mt][e];
+                    m2 += out[mt][e] * lx[mt][e];
+                }
+            }
+            m1 += __shfl_xor(m1, 16);
+            m1 += __shfl_xor(m1, 32);
+            m2 += __shfl_xor(m2, 16);
+            m2 += __shfl_xor(m2, 32);
+            m1 /= (float)D;
+            m2 /= (float)D;
+            if (live) {
+#pragma unroll
+                for (int mt = 0; mt < DT; ++mt) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = old[mt][e] + rstd * (out[mt][e] - m1 - lx[mt][e] * m2);
+                    *reinterpret_cast<f32x4*>(p.Y + tok * (long long)D + 16 * mt + 4 * g) = v;
+                }
+            }
+        } else if (live) {
 #pragma unroll
             for (int mt = 0; mt < DT; ++mt) *reinterpret_cast<f32x4*>(p.Y + tok * (long long)D + 16 * mt + 4 * g) = out[mt];
         }
     }
 }
+
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Token-wise Linear (dts_lin_wave_kernel of dts_kernels.h: same arguments, prologues, epilogues, persistent grid and load order) on the f16 matrix
@@ -735,7 +788,8 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_bwd_h_kernel(const Mlp
 // planes -- the same bytes as its fp32 image), three v_mfma_f32_16x16x32_f16 per 32 k.  A lane holds the eight consecutive columns 32 c + 8 g ..
 // of its token (two float4 loads), which is the B operand as it stands.  The exact kernel's 16 x 16 x 4 fp32 products were 40 us of its 118 us per launch.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KT>
+// LNB: the fused LayerNorm-backward epilogue (LinArgs::lnx), a separate instance so that the plain one keeps its registers (124 VGPRs: two workgroups per CU)
+template <int KT, bool LNB = false>
 __global__ __launch_bounds__(64 * LINW_WAVES) void dts_lin_wave_h_kernel(const LinArgs p) {
     static_assert(KT % 2 == 0, "K must be a multiple of 32");
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -859,12 +913,20 @@ __global__ __launch_bounds__(64 * LINW_WAVES) void dts_lin_wave_h_kernel(const L
                     if (p.accumulate) addend[i] += *reinterpret_cast<const f32x4*>(p.Y + tok * (long long)p.ldy + ys * nt + 4 * g);
                 }
             }
+            f32x4 lx[4];                                                 // fused LayerNorm backward: the LayerNorm's input row, requested with the addends
+            if constexpr (LNB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    lx[i] = (live && i < NT) ? *reinterpret_cast<const f32x4*>(p.lnx + tok * (long long)p.N + 16 * i + 4 * g) : f32x4{0, 0, 0, 0};
+            }
             if constexpr (AHEAD) {
                 if (nt0 == 0) load_tile(tile + tstep, xn);
             }
+            f32x4 res[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int nt = nt0 + i;
+                res[i] = f32x4{0, 0, 0, 0};
                 if (nt >= NT) break;
                 const int n0 = 16 * nt + 4 * g;
                 f32x4 acc = {0, 0, 0, 0};
@@ -874,11 +936,63 @@ __global__ __launch_bounds__(64 * LINW_WAVES) void dts_lin_wave_h_kernel(const L
                     const ah8 ah = *reinterpret_cast<const ah8*>(Wh + wo + 32 * c), al = *reinterpret_cast<const ah8*>(Wlo + wo + 32 * c);
                     DTS_MMH3_32(acc, ah, al, xh[c], xl[c]);
                 }
-                if (live) {
-                    f32x4 v = acc * ix;
-                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n0);
+                f32x4 v = acc * ix;
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n0);
+                if constexpr (LNB) {
+                    res[i] = v;                                          // finished below, once the token's whole row is there
+                } else if (live) {
                     v += addend[i];
                     *reinterpret_cast<f32x4*>(p.Y + tok * (long long)p.ldy + ys * nt + 4 * g) = v;
+                }
+            }
+            if constexpr (LNB) {                                         // (N <= 64: one pass of this loop holds the row; the launcher checks)
+                const float inv_n = 1.0f / (float)p.N;
+                float sum = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sum += (lx[i][0] + lx[i][1]) + (lx[i][2] + lx[i][3]);
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float mean = sum * inv_n;
+                float q = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lx[i][e] = i < NT ? lx[i][e] - mean : 0.0f;
+                        q += lx[i][e] * lx[i][e];
+                    }
+                q += __shfl_xor(q, 16);
+                q += __shfl_xor(q, 32);
+                const float rstd = 1.0f / sqrtf(q * inv_n + 1e-5f);
+                float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i >= NT) break;
+                    const f32x4 gw = *reinterpret_cast<const f32x4*>(p.lng + 16 * i + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lx[i][e] *= rstd;                                // xhat
+                        res[i][e] *= p.ln_ada ? 1.0f + gw[e] : gw[e];
+                        m1 += res[i][e];
+                        m2 += res[i][e] * lx[i][e];
+                    }
+                }
+                m1 += __shfl_xor(m1, 16);
+                m1 += __shfl_xor(m1, 32);
+                m2 += __shfl_xor(m2, 16);
+                m2 += __shfl_xor(m2, 32);
+                m1 *= inv_n;
+                m2 *= inv_n;
+                if (live) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (i >= NT) break;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = rstd * (res[i][e] - m1 - lx[i][e] * m2);
+                        v += addend[i];                                  // (accumulate: the old value of Y)
+                        *reinterpret_cast<f32x4*>(p.Y + tok * (long long)p.ldy + ys * i + 4 * g) = v;
+                    }
                 }
             }
         }

@@ -67,6 +67,10 @@ struct LinArgs {
     // yblk; 0 = plain row-major.  The attention operands (Q | K | V, the attention output and their gradients) live in this layout, so that one
     // (sequence, head) tile is contiguous: [block = which * H + head][rows][16].
     long long xblk, yblk;
+    // dts_lin_wave_h_kernel only, N <= 64: the product is the gradient w.r.t. a LayerNorm OUTPUT and the kernel finishes the LayerNorm's input gradient
+    // (dts_ln_bwd_kernel fused): lnx = the LayerNorm's input rows [rows][N], lng = its weight (ln_ada: 1 + scale of an AdaLayerNorm); Y then receives
+    // (accumulate: +=) rstd (g' - mean(g') - xhat mean(g' xhat)), g' = product x weight.  null: plain epilogue.
+    const float* lnx = nullptr; const float* lng = nullptr; int ln_ada = 0;
 };
 
 constexpr int LIN_TM = 64;          // tokens per workgroup pass
@@ -775,6 +779,9 @@ struct MlpBwdArgs {
     const float *G, *U, *W2T, *W0T;
     float* Y;                       // [rows][D]
     long long rows;
+    // dts_mlp_bwd_h_kernel only: finish the input gradient of the block's LayerNorm (dts_ln_bwd_kernel fused): lnx = the LayerNorm's input rows,
+    // lng = its weight; Y then ACCUMULATES rstd (g' - mean(g') - xhat mean(g' xhat)), g' = d_ln x weight (Y may be G itself).  null: Y = d_ln.
+    const float* lnx = nullptr; const float* lng = nullptr;
 };
 
 template <int DT, int MT>
