@@ -457,8 +457,11 @@ int attn_bwd(mpv_ctx* ctx, DtsEngine& e, int B, const float* Q, int ldq, const f
     const float scale = 1.0f / std::sqrt((float)e.hd);
     const long long hs = e.blocked ? (long long)B * e.L * 16 : e.hd;
     const int ldo = e.blocked ? 16 : e.D;
-    hipLaunchKernelGGL(dts_attn_delta_kernel, g1d(n), dim3(256), 0, ctx->stream, dO, O, ldo, hs, e.H, e.L, e.hd, n, e.delta);   // n = tokens * heads
-    MPV_HIP_TRY(ctx, hipGetLastError());
+    const bool f16 = e.d.gemm != MPV_GEMM_F32 && e.hd == 16 && e.L <= 64 * AH_MAXQ;   // (attn()'s condition) the split-f16 dQ kernel forms delta itself, for dK-dV too
+    if (!f16) {
+        hipLaunchKernelGGL(dts_attn_delta_kernel, g1d(n), dim3(256), 0, ctx->stream, dO, O, ldo, hs, e.H, e.L, e.hd, n, e.delta);   // n = tokens * heads
+        MPV_HIP_TRY(ctx, hipGetLastError());
+    }
     AttnArgs a{Q, K, V, ldq, ldkv, ldkv, dO, O, ldo, dq, lddq, nullptr, 0, lse, e.delta, e.H, e.L, e.L, e.hd, scale, hs};
     DTS_TRY(attn(ctx, 1, a, B, e.d.gemm != MPV_GEMM_F32));
     a.out = dk; a.ldout = lddkv; a.out2 = dv; a.ldout2 = lddkv;

@@ -175,6 +175,16 @@ __device__ __forceinline__ float load_split_col(const float* p, ah4& hi, ah4& lo
     return sc;
 }
 
+// the same for values already in registers
+__device__ __forceinline__ float split_col(const f32x4& v, ah4& hi, ah4& lo) {
+    float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    const float sc = pow2_scale(m);
+    attn_split4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc, hi, lo);
+    return sc;
+}
+
 // a 16 x 16 tile of gradient-like values in accumulator layout [row 4 g + r][column r16] -> split with a power of two per COLUMN (the four lanes of
 // a column agree on it with two shuffles; returned).  A column of the B operand scales the same column of the product, which is on the same lanes:
 // the caller divides it out of the zero-initialised product that consumes the tile.
@@ -290,9 +300,16 @@ __global__ __launch_bounds__(256) void dts_attn_dq_h_kernel(const AttnArgs p) {
         const bool jl = j < p.Lq;
         ah4 qh, ql, dh, dl;
         const float c = c0 / load_split_col(Qb + (long long)(jl ? j : 0) * p.ldq + 4 * g, qh, ql);
-        const float dpinv = 1.0f / (sc[1] * load_split_col(Db + (long long)(jl ? j : 0) * p.ldo + 4 * g, dh, dl));      // V . dO comes out times sV sdO(query)
+        // delta[query] = dO[query] . O[query] is formed here, from the dO row the kernel loads anyway and the matching O row (four lanes per query, two
+        // shuffles), and left in p.delta for the dK-dV pass: the separate pass over dO and O (dts_attn_delta_kernel) is gone in this mode
+        const f32x4 dov = *reinterpret_cast<const f32x4*>(Db + (long long)(jl ? j : 0) * p.ldo + 4 * g);
+        const f32x4 ov = *reinterpret_cast<const f32x4*>(p.O + ((long long)b * p.Lq + (jl ? j : 0)) * p.ldo + h * p.hs + 4 * g);
+        float del = (dov[0] * ov[0] + dov[1] * ov[1]) + (dov[2] * ov[2] + dov[3] * ov[3]);
+        del += __shfl_xor(del, 16);
+        del += __shfl_xor(del, 32);
+        if (jl && g == 0) const_cast<float*>(p.delta)[((long long)b * p.H + h) * p.Lq + j] = del;
+        const float dpinv = 1.0f / (sc[1] * split_col(dov, dh, dl));      // V . dO comes out times sV sdO(query)
         const float lse = p.lse[((long long)b * p.H + h) * p.Lq + (jl ? j : 0)];
-        const float del = p.delta[((long long)b * p.H + h) * p.Lq + (jl ? j : 0)];
         f32x4 dq = {0, 0, 0, 0};
         const int nkt = Lkp >> 4, tail = (p.Lk & 15) ? nkt - 1 : nkt;  // key tile with padded keys (only that one is masked)
         const int plane = Lkp * AH_RS;                                 // Kh -> Kl -> Vh -> Vl are consecutive planes
