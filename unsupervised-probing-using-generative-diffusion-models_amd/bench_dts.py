@@ -111,7 +111,7 @@ def record_c3(args, log, rk):
                    "passes_per_window": {"forward": n_fwd, "backward": n_bwd}},
         "roofline": multi_kernel_roofline(
             tr if short == 0 else None, rk.world * wps * args.steps / elapsed / rk.world, achieved, FP32_MATRIX_PEAK_TFLOPS,
-            "fp32 matrix pipe (algorithmic FLOPs of the whole call; attention and MLP products run as 3x f16 MFMA unless gemm_mode='f32')",
+            "fp32 matrix pipe (algorithmic FLOPs of the whole call; Linear, attention and MLP products run as 3x f16 MFMA unless gemm_mode='f32')",
             "dts_lin_wave + dts_attn_{fwd,dq,dkv}_h + dts_mlp_{fwd,bwd}_h + dts_ln_bwd + dts_seqmix + Fourier / trend kernels (whole sampler call)",
             {"flop_per_window": flop_per_window, "flop_per_sequence_forward": ff, "flop_per_sequence_backward": fb, "traffic_detail": slim_traffic(tr),
              "note": "356 transformer passes of about 100 kernels each over [3200 x 200 x 64] activations; achieved compute = algorithmic FLOPs of the "
