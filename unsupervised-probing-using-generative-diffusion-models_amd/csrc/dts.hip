@@ -24,6 +24,8 @@ struct DecW {
     // proj (Conv1d L -> 2L over the token axis) is never applied on its own: its first half is folded into the trend block's first
     // convolution (tw0 / tb0x below are the composites) and its second half into the real-DFT basis of the Fourier layer
     const float *wdft, *bdft, *wdft_t;             // [2 NFp][Lp] = DFT basis x proj[L:], its row bias, and the transpose [L][2 NFp]
+    const _Float16 *wdft_h = nullptr, *wdft_l = nullptr;   // the same matrix as scaled f16 hi / lo planes [2 NFp][Lp32] (split-f16 token mixing)
+    float wdft_isw = 1.0f;                         // 1 / its power of two
     const float *wlin, *blin;
 };
 
@@ -170,6 +172,28 @@ int wide_gemm(mpv_ctx* ctx, const float* X, int ldx, const float* W, int K, int 
     if (int rc = set_lds(ctx, nst_gemm_kernel, lds)) return rc;
     const long long tiles = ((rows + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
     hipLaunchKernelGGL(nst_gemm_kernel, dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(256), lds, ctx->stream, a);
+    MPV_HIP_TRY(ctx, hipGetLastError());
+    return MPV_OK;
+}
+
+// split-f16 token mixing (dts_seqmix_h_kernel): W as pre-split planes [Mp][Kp32]
+int seqmix_h(mpv_ctx* ctx, int D, const _Float16* Wh, const _Float16* Wl, float isw, int Mp, int Kp32, const float* bias, const float* X, long long xs, int ldx,
+             int K, float* Y, long long ys, int ldy, int M, int B) {
+    if (Mp > 256) return -100;
+    SeqmixHArgs a{Wh, Wl, Mp, Kp32, isw, bias, X, xs, ldx, K, Y, ys, ldy, M};
+    const size_t lds = 2 * sizeof(_Float16) * (size_t)Kp32 * (D + 8) + 64;
+    if (D == 64) {
+        if (int rc = set_lds(ctx, dts_seqmix_h_kernel<4>, lds)) return rc;
+        hipLaunchKernelGGL(dts_seqmix_h_kernel<4>, dim3(B), dim3(256), lds, ctx->stream, a);
+    } else if (D == 32) {
+        if (int rc = set_lds(ctx, dts_seqmix_h_kernel<2>, lds)) return rc;
+        hipLaunchKernelGGL(dts_seqmix_h_kernel<2>, dim3(B), dim3(256), lds, ctx->stream, a);
+    } else if (D == 16) {
+        if (int rc = set_lds(ctx, dts_seqmix_h_kernel<1>, lds)) return rc;
+        hipLaunchKernelGGL(dts_seqmix_h_kernel<1>, dim3(B), dim3(256), lds, ctx->stream, a);
+    } else {
+        return -100;
+    }
     MPV_HIP_TRY(ctx, hipGetLastError());
     return MPV_OK;
 }
@@ -434,7 +458,15 @@ int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t, bool save)
         hipLaunchKernelGGL(dts_trend_fwd_kernel, dim3(B), dim3(256), sizeof(float) * (15 * D + 3 * F), st, s.x2, (long long)L * D, w.tw0, w.tb0, w.tw3, w.tb3,
                            e.poly, L, F, D, s.t3, e.trend_sum);
         MPV_HIP_TRY(ctx, hipGetLastError());
-        DTS_TRY(seqmix(ctx, D, w.wdft, 2 * e.NFp, e.Lp, w.bdft, s.x2, (long long)L * D, D, L, e.spec, 2LL * e.NFp * D, D, 2 * e.NFp, B));
+        {
+            static const bool mix_exact = getenv("MPV_DTS_MIX_F32") != nullptr;          // A/B aid: the token mixing on the fp32 matrix pipe
+            int rc = -100;
+            if (e.d.gemm != MPV_GEMM_F32 && !mix_exact)
+                rc = seqmix_h(ctx, D, w.wdft_h, w.wdft_l, w.wdft_isw, 2 * e.NFp, (L + 31) & ~31, w.bdft, s.x2, (long long)L * D, D, L, e.spec, 2LL * e.NFp * D, D,
+                              2 * e.NFp, B);
+            if (rc == -100) rc = seqmix(ctx, D, w.wdft, 2 * e.NFp, e.Lp, w.bdft, s.x2, (long long)L * D, D, L, e.spec, 2LL * e.NFp * D, D, 2 * e.NFp, B);
+            if (rc) return rc;
+        }
         hipLaunchKernelGGL(dts_fourier_select_kernel, g1d((long long)B * D), dim3(256), 0, st, e.spec, e.NF, e.NFp, D, e.topk, (long long)B * D, s.fidx,
                            e.famp, e.fph);
         hipLaunchKernelGGL(dts_fourier_synth_kernel, dim3(B), dim3(256), 0, st, s.fidx, e.famp, e.fph, e.freq + 1, L, D, e.topk, e.season_sum);
@@ -629,6 +661,7 @@ int mpv_dts_load(mpv_ctx* ctx, const mpv_dts_desc* d, const float* const* tensor
     const float* const* T_ = tensors;
     const size_t DD = (size_t)D * D, MD = (size_t)e->M * D;
     std::vector<size_t> o;                                               // offsets in `host`, consumed in the same order below
+    std::vector<float> dft_isw;                                          // per decoder block: 1 / (power of two of its split DFT composite)
     o.push_back(put(T_[0], (size_t)D * F * 3)); o.push_back(put(T_[1], D)); o.push_back(put(T_[2], (size_t)F * D * 3)); o.push_back(put(T_[3], F));
     o.push_back(put(T_[4], (size_t)F * D * d->combine_taps)); o.push_back(put(T_[5], d->n_dec)); o.push_back(put(T_[6], (size_t)L * D));
     o.push_back(put(T_[7], (size_t)L * D));
@@ -709,6 +742,27 @@ int mpv_dts_load(mpv_ctx* ctx, const mpv_dts_desc* d, const float* const* tensor
                     }
                 }
             o.push_back(putv(wd)); o.push_back(putv(bd)); o.push_back(putv(wdt));
+            {   // two-term f16 split of the composite, one power of two for the matrix (max in [2^13, 2^14)), rows padded to a multiple of 32 columns
+                const int Lp32 = (L + 31) & ~31, Mp = 2 * e->NFp;
+                float mx = 0.0f;
+                for (float v : wd) mx = std::fmax(mx, std::fabs(v));
+                int ex = 0;
+                if (mx > 0.0f) (void)std::frexp(mx, &ex);
+                const float sw = mx > 0.0f ? std::ldexp(1.0f, 14 - ex) : 1.0f;
+                std::vector<float> planes((size_t)Mp * Lp32, 0.0f);               // 2 planes x Mp x Lp32 halves
+                _Float16* ph = reinterpret_cast<_Float16*>(planes.data());
+                _Float16* pl = ph + (size_t)Mp * Lp32;
+                for (int r = 0; r < Mp; ++r)
+                    for (int lp = 0; lp < L; ++lp) {
+                        const float x = wd[(size_t)r * e->Lp + lp] * sw;
+                        unsigned u; std::memcpy(&u, &x, 4); u &= 0xFFFFE000u;
+                        float hi; std::memcpy(&hi, &u, 4);
+                        ph[(size_t)r * Lp32 + lp] = (_Float16)hi;
+                        pl[(size_t)r * Lp32 + lp] = (_Float16)(x - hi);
+                    }
+                o.push_back(putv(planes));
+                dft_isw.push_back(1.0f / sw);
+            }
         }
         o.push_back(put(T_[k + 28], (size_t)F * D)); o.push_back(put(T_[k + 29], F));
     }
@@ -738,7 +792,10 @@ int mpv_dts_load(mpv_ctx* ctx, const mpv_dts_desc* d, const float* const* tensor
         w.wq2 = nx(); w.bq2 = nx(); w.wkv2 = nx(); w.bkv2 = nx(); w.wp2 = nx(); w.bp2 = nx(); w.wq2_t = nx(); w.wkv2_t = nx(); w.wp2_t = nx();
         w.tw0 = nx(); w.tb0 = nx(); w.tw3 = nx(); w.tb3 = nx();
         w.w0 = nx(); w.b0 = nx(); w.w2 = nx(); w.b2 = nx(); w.w0_t = nx(); w.w2_t = nx();
-        w.wdft = nx(); w.bdft = nx(); w.wdft_t = nx(); w.wlin = nx(); w.blin = nx();
+        w.wdft = nx(); w.bdft = nx(); w.wdft_t = nx();
+        w.wdft_h = reinterpret_cast<const _Float16*>(nx()); w.wdft_l = w.wdft_h + (size_t)2 * e->NFp * ((L + 31) & ~31);
+        w.wdft_isw = dft_isw[&w - e->dec.data()];
+        w.wlin = nx(); w.blin = nx();
     }
     e->ada = e->blob + o_ada; e->freq = e->blob + o_freq; e->poly = e->blob + o_poly; e->cosT = e->blob + o_cos;
     e->sinT = e->blob + o_sin;

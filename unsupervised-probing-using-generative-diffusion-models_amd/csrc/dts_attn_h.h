@@ -1016,4 +1016,94 @@ __global__ __launch_bounds__(64 * LINW_WAVES) void dts_lin_wave_h_kernel(const L
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-sequence mixing along the token axis (dts_seqmix_kernel of dts_kernels.h: Y_b[m][d] = bias[m] + sum_k W[m][k] X_b[k][d]) on the f16 matrix pipe:
+// W arrives pre-split (hi / lo f16 planes [Mp][Kp32], one power of two for the matrix, made at load), X_b is scaled by its own power of two and
+// split while it is staged into LDS as row-major planes [Kp32][D + 8]; the B operand of a 32-wide product -- eight consecutive k (tokens) of one
+// channel -- is two transposed LDS reads (ds_read_b64_tr_b16) per plane.  A wave owns every fourth 16-row block of W and keeps the X fragments of a
+// k-chunk in registers across its blocks.  The exact kernel was bound by its 16 x 16 x 4 fp32 products (135 us of matrix pipe in 286 us per launch).
+// ---------------------------------------------------------------------------------------------------------------------
+struct SeqmixHArgs {
+    const _Float16* Wh; const _Float16* Wl; int Mp, Kp32; float isw;     // planes [Mp][Kp32]; isw = 1 / (the matrix's power of two)
+    const float* bias;              // [M] | null
+    const float* X; long long xs; int ldx; int K;     // X_b = X + b*xs, rows k < K, row stride ldx
+    float* Y; long long ys; int ldy; int M;           // Y_b = Y + b*ys, rows m < M
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void dts_seqmix_h_kernel(const SeqmixHArgs p) {
+    constexpr int D = 16 * DT, XS = D + 8, MAXB = 4;                   // MAXB: 16-row blocks of W per wave (Mp <= 256)
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    _Float16* Xh = reinterpret_cast<_Float16*>(ldsb);      // [Kp32][XS]
+    _Float16* Xl = Xh + p.Kp32 * XS;
+    float* red = reinterpret_cast<float*>(Xl + p.Kp32 * XS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    const float* xb = p.X + (long long)blockIdx.x * p.xs;
+    float mx = 0.0f;
+    for (int i = tid; i < p.K * (D / 4); i += 256) {
+        const int k = i / (D / 4), c = i - k * (D / 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long long)k * p.ldx + 4 * c);
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    const float sx = pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    for (int i = tid; i < p.Kp32 * (D / 4); i += 256) {
+        const int k = i / (D / 4), c = i - k * (D / 4);
+        ah4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
+        if (k < p.K) load_split4(xb + (long long)k * p.ldx + 4 * c, sx, hi, lo);
+        *reinterpret_cast<ah4*>(Xh + k * XS + 4 * c) = hi;
+        *reinterpret_cast<ah4*>(Xl + k * XS + 4 * c) = lo;
+    }
+    __syncthreads();
+    const int nmt = p.Mp >> 4;
+    f32x4 acc[MAXB][DT];
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[i][dt] = f32x4{0, 0, 0, 0};
+    const int plane = p.Kp32 * XS;
+    const _Float16* xt = Xh + (8 * g + (r16 >> 2)) * XS + 4 * (r16 & 3);      // transposed reads: this lane's address in the block rows 8 g .. of a chunk
+    for (int c = 0; c < (p.Kp32 >> 5); ++c) {
+        ah8 ah[MAXB], al[MAXB];
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) {
+            const int mt = wave + 4 * i;
+            const long long wo = (long long)(16 * (mt < nmt ? mt : 0) + r16) * p.Kp32 + 32 * c + 8 * g;
+            ah[i] = *reinterpret_cast<const ah8*>(p.Wh + wo);
+            al[i] = *reinterpret_cast<const ah8*>(p.Wl + wo);
+        }
+        ah8 bh[DT], bl[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const _Float16* q = xt + 32 * c * XS + 16 * dt;
+            bh[dt] = ah8_of(column4_tr(q), column4_tr(q + 4 * XS));
+            bl[dt] = ah8_of(column4_tr(q + plane), column4_tr(q + plane + 4 * XS));
+        }
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) {
+            if (wave + 4 * i >= nmt) break;                              // (wave-uniform)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) DTS_MMH3_32(acc[i][dt], ah[i], al[i], bh[dt], bl[dt]);
+        }
+    }
+    const float inv = p.isw / sx;
+    float* yb = p.Y + (long long)blockIdx.x * p.ys;
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int mt = wave + 4 * i;
+        if (mt >= nmt) break;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 16 * mt + 4 * g + r;
+            if (m < p.M) {
+                const float bm = p.bias ? p.bias[m] : 0.0f;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) yb[(long long)m * p.ldy + 16 * dt + r16] = acc[i][dt][r] * inv + bm;
+            }
+        }
+    }
+}
+
 }  // namespace dts
