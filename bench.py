@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=("c2", "c3", "c4", "c5"), default="c2",
+    ap.add_argument("--config", choices=("c2", "c3", "c4", "c5", "nss", "tmdm"), default="c2",
                     help="c2 (default, the headline): NsDiff 100-node biomass, N=32, T=50; c3: DiffusionTS 100-node SIS, N=32, T=100; "
                          "c4: NsDiff 500-node Wilson-Cowan, N=64, T=50, ONE trajectory split over the ranks (strong scaling); "
                          "c5: DiffSTG 200-node small-world biomass, N=32, 50 inference steps")
@@ -163,6 +163,16 @@ def main():
     if args.config == "c4":
         from mpv_amd.bench_c4 import main_c4
         return main_c4(args, log)
+    if args.config in ("nss", "tmdm"):             # the `other_families` records on their own (N = 1; profiling passes: tools/r3_pmc.sh nss)
+        import mpv_amd  # noqa: F401
+        from mpv_amd import bench_families as BF
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU")
+        fn = BF.record_nsdiff_spatial if args.config == "nss" else BF.record_tmdm
+        rec = fn(torch.device("cuda", 0), log, cpu=not args.no_cpu_baseline)
+        rec.update(n_gpus=1, steps=2, warmup=1, higher_is_better=True, scaling="weak", vs_baseline=None)
+        print(json.dumps(rec), flush=True)
+        return 0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

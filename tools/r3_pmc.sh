@@ -1,5 +1,5 @@
 # round 3: per-kernel HBM traffic of one bench step of c5 / c3 / c4 (three separate rocprofv3 runs each: stats, FETCH_SIZE, WRITE_SIZE)
-# usage (on the GPU box): bash tools/r3_pmc.sh c5|c3|c4
+# usage (on the GPU box): bash tools/r3_pmc.sh c5|c3|c4|nss
 set -o pipefail
 CFG=$1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r3pmc_$CFG
@@ -9,6 +9,7 @@ case $CFG in
   c5) ARGS="--config c5 --steps 1 --warmup 0 --stg-windows 4 --no-cpu-baseline"; WIN=4 ;;
   c3) ARGS="--config c3 --steps 1 --warmup 0 --dts-windows 1 --no-cpu-baseline"; WIN=1 ;;
   c4) ARGS="--config c4 --steps 1 --warmup 0 --no-cpu-baseline"; WIN=181 ;;
+  nss) ARGS="--config nss --no-cpu-baseline"; WIN=12 ;;      # NsDiff_spatial family record: 1 warm-up + 2 timed steps of 4 windows
 esac
 PMCENV=""
 [ $CFG = c3 ] && PMCENV=10      # c3: the counter passes run a 10-step plan (same launches, 10x fewer: a counter pass of the 36 k launches of the full plan takes > 7 min)

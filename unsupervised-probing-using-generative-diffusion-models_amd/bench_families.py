@@ -78,6 +78,12 @@ def record_nsdiff_spatial(device, log, cpu=True):
                         "compute": {"achieved_tflops": achieved, "peak_tflops": FP32_MATRIX_PEAK_TFLOPS, "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
                                     "flop_per_window": flop_per_window},
                         "note": "no PMC pass of its own: the step is the c5 kernel mix at half the time length (c5: 3.0 TB/s measured)"}}
+    from mpv_amd.bench_common import measured_traffic
+    tr = measured_traffic("nss")                     # profiles/*/pmc_traffic_nss.json (tools/r3_pmc.sh nss), bytes per window
+    if tr:
+        gbps = tr["bytes_per_window"] * rec["value"] / 1e9
+        rec["roofline"].update(achieved=gbps, frac=gbps / 8000.0, traffic=tr["bytes_per_window"], traffic_source=tr["source"],
+                               note="HBM bytes per window from separate FETCH_SIZE / WRITE_SIZE passes over this record's own step")
     if cpu:
         from oracle import nsdiff_spatial_oracle as O
         from oracle import nsdiff_oracle as NS
