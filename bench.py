@@ -11,10 +11,14 @@ series, weights) are resident in HBM before the timed region.  With N ranks ever
 trajectory of the same size (weak scaling: windows shard with no data-path collective) and one
 all-gather reassembles the curves.
 
-Prints ONE JSON line (rank 0): metric/value/unit as BASELINE.json names them, plus
-  roofline     -- the chain kernel against the fp32 matrix-pipe peak, timed live with HIP events
+Prints ONE short JSON line on stdout (rank 0; < 4 KB, checked before it is printed): metric/value/unit as BASELINE.json names them, plus
+  roofline     -- the chain kernel against the matrix-pipe peak of the mode it runs in, timed live with HIP events
   cpu_baseline -- the CPU oracle (a torch-CPU port of the reference path) on a bounded sample
   mpv_*_err    -- MPV of the HIP path vs that CPU run on the SAME noise
+  other        -- value / unit / roofline fraction of every secondary record
+The secondary records themselves (other GEMM modes, sample-writing path, trained checkpoints, full NsDiff with f(x), BASELINE
+configs[2..4], the NsDiff_spatial and TMDM families; each with its own roofline and CPU baseline) go to STDERR as `[bench record] {...}`
+lines and to gpurun_out/bench_records.jsonl (MPV_BENCH_RECORDS overrides) -- never into the stdout line.
 """
 import argparse
 import json
@@ -154,6 +158,8 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_workers(args))
+    if os.environ.get("MPV_BENCH_FAIL_RANK") is not None and os.environ.get("MPV_BENCH_FAIL_RANK") == os.environ.get("RANK"):
+        raise SystemExit(3)                     # test hook (tests/test_bench_launch_gpu.py): a rank that dies before the rendezvous
     if args.config == "c3":
         from mpv_amd.bench_dts import main_c3
         return main_c3(args, log)
@@ -163,15 +169,17 @@ def main():
     if args.config == "c4":
         from mpv_amd.bench_c4 import main_c4
         return main_c4(args, log)
-    if args.config in ("nss", "tmdm"):             # the `other_families` records on their own (N = 1; profiling passes: tools/r3_pmc.sh nss)
+    if args.config in ("nss", "tmdm"):             # the `other_families` records on their own (N = 1; profiling passes: tools/pmc_pass.sh nss)
         import mpv_amd  # noqa: F401
         from mpv_amd import bench_families as BF
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU")
         fn = BF.record_nsdiff_spatial if args.config == "nss" else BF.record_tmdm
+        from mpv_amd.bench_common import emit_record, print_line
         rec = fn(torch.device("cuda", 0), log, cpu=not args.no_cpu_baseline)
         rec.update(n_gpus=1, steps=2, warmup=1, higher_is_better=True, scaling="weak", vs_baseline=None)
-        print(json.dumps(rec), flush=True)
+        emit_record(args.config, rec, fresh=True)
+        print_line(rec)
         return 0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -295,10 +303,14 @@ def main():
     if use_dist:
         out["collective"] = {"backend": dist.get_backend(), "forced_world_of_one": world == 1}
 
-    # ---- separately reported runs: the other GEMM modes, the sample-writing path; never the headline
+    # ---- separately reported runs: the other GEMM modes, the sample-writing path, trained checkpoints, full NsDiff, the
+    # other BASELINE configs and model families.  Each is ONE record on stderr + in the records file; the stdout line keeps a digest.
+    from mpv_amd.bench_common import digest, emit_record, print_line, records_path
+    if rank == 0:
+        emit_record("run", {"argv": sys.argv[1:], "n_gpus": world, "records_file": records_path()}, fresh=True)
     extras = world == 1 and not args.no_other_modes
     others = [g for g in ("f32", "f16x2", "f16") if g != args.gemm] if extras else []
-    other_modes = {}
+    other_modes, other = {}, {}
     for g in others:
         n_steps = max(1, min(args.steps, 3 if g != "f32" else 2))
         step(7, gemm=g)
@@ -309,27 +321,27 @@ def main():
         other_modes[g] = {"value": n_windows * n_steps / dt, "unit": "windows/s", "steps": n_steps, "ms_per_step": dt / n_steps * 1e3,
                           "dtype": DTYPES[g], "kernel_avg_ms": kms, "achieved_tflops": ach, "mfma_peak_tflops": peak, "frac": ach / peak}
         log("mode %s: %.1f windows/s" % (g, other_modes[g]["value"]))
-    if other_modes:
-        out["other_modes"] = other_modes
     if extras:
         step(8, store=not args.store_samples)
         dt, kms, _, _ = timed(3, 300, store=not args.store_samples)
-        out["other_summary_path"] = {"summary": "sample tensor written + stand-alone reduction" if not args.store_samples else "fused",
-                                     "value": n_windows * 3 / dt, "unit": "windows/s", "kernel_avg_ms": kms}
-        log("other summary path: %.1f windows/s" % out["other_summary_path"]["value"])
+        rec = {"summary": "sample tensor written + stand-alone reduction" if not args.store_samples else "fused",
+               "value": n_windows * 3 / dt, "unit": "windows/s", "kernel_avg_ms": kms}
+        emit_record("other_summary_path", rec)
+        other["other_summary_path"] = digest(rec)
         for key, fn in (("trained_checkpoints", lambda: trained_checkpoint_records(device)),
                         ("full_nsdiff", lambda: full_nsdiff_record(device, sampled, n_windows))):
             try:                                   # secondary records never take the headline line down with them
-                out[key] = fn()
+                rec = fn()
             except Exception as exc:               # noqa: BLE001
-                out[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-                log("%s failed: %s" % (key, out[key]["error"]))
-        if "value" in out["full_nsdiff"]:
-            log("full NsDiff (f + g + sampler): %.1f windows/s" % out["full_nsdiff"]["value"])
+                rec = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                log("%s failed: %s" % (key, rec["error"]))
+            emit_record(key, rec)
+            other[key] = digest(rec) if key == "full_nsdiff" else {k: digest(v) for k, v in rec.items()} if "error" not in rec else digest(rec)
 
     if extras and not args.no_other_configs and args.max_windows is None:
-        out["other_configs"] = other_config_records(args, device)
-        out["other_families"] = other_family_records(args, device)
+        for key, rec in list(other_config_records(args, device).items()) + list(other_family_records(args, device).items()):
+            emit_record(key, rec)
+            other[key] = digest(rec)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         parity = cpu_baseline_and_parity(model, sampled, args.cpu_windows, [args.gemm] + others)
         for g, err in parity.pop("per_mode").items():
@@ -338,8 +350,15 @@ def main():
             else:
                 other_modes[g].update(err)
         out.update(parity)
+    for g, rec in other_modes.items():
+        emit_record("mode_" + g, rec)
+        other["mode_" + g] = digest(rec)
+    if other:
+        out["other"] = other
+        out["records_file"] = os.path.relpath(records_path(), str(ROOT)) if records_path() else None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit_record("headline", out)               # the complete headline record (with traffic_detail, notes)
+        print_line(out)                            # ... and its short form: THE stdout line
     if use_dist:
         dist.destroy_process_group()
 
@@ -475,19 +494,20 @@ DTYPES = {"f32": "f32",
           "f16": "f32 elementwise + accumulate; 128x128 layers with f16 weights and f16 activations (1 MFMA product)"}
 
 
-def measured_traffic(kernel, n_windows):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*/pmc_traffic*.json, collected by
-    tools/run_pmc_traffic.sh with the guide's gfx950 corrections); None when no pass matches this workload."""
-    import glob
-    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "pmc_traffic*.json")), reverse=True):
-        try:
-            with open(f) as fh:
-                rec = json.load(fh).get(kernel)
-        except (OSError, ValueError):
-            continue
-        if rec and rec.get("windows") == n_windows:
-            return {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": rec["algorithmic_bytes_per_launch"],
-                    "source": os.path.relpath(f, os.path.dirname(os.path.abspath(__file__)))}
+def measured_traffic(n_windows, store_samples=False):
+    """HBM bytes per launch of the headline chain kernel from the committed PMC passes of THIS binary (profiles/*/pmc_traffic_c2.json, written
+    by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes with the guide's gfx950 corrections, carrying the sha256 of the library
+    it was measured on); None when there is no pass for this workload, `stale: True` when the pass belongs to another binary."""
+    from mpv_amd.bench_common import measured_traffic as mt
+    tr = mt("c2" + ("_store" if store_samples else ""))
+    if not tr or tr.get("windows_in_step") != n_windows:
+        return None
+    for name, rec in (tr.get("kernels") or {}).items():
+        if name.startswith("nsdiff_chain_f16_kernel"):
+            per_launch = rec["hbm_bytes"] / max(int(rec.get("launches", 1)), 1)
+            algorithmic = n_windows * CFG["nodes"] * CFG["pred_len"] * CFG["nf"] * 4 * (1 + (CFG["n_z"] if store_samples else 0)) + 256 * 150 * 1024
+            return {"hbm_bytes_per_launch": None if tr["stale"] else per_launch, "stale": tr["stale"], "measured_hbm_bytes_per_launch": per_launch,
+                    "algorithmic_bytes_per_launch": algorithmic, "source": tr["source"], "lib_sha256": tr.get("_lib_sha256"), "commit": tr.get("_commit")}
     return None
 
 
@@ -509,9 +529,10 @@ def roofline(gemm, achieved, kernel_ms, launches, flop_per_launch, n_windows, st
                 "peak_source": "dense f16 MFMA peak 2500 TFLOP/s / %d MFMA products per algorithmic product" % products,
                 "note": "reduced-precision operand mode; live bound is vector-instruction issue (DESIGN.md 3.1)"}
     peak = F16_MATRIX_PEAK_TFLOPS / 3.0
-    tr = measured_traffic("nsdiff_chain_f16_kernel<1,true>" + ("" if store_samples else " fused"), n_windows)
+    tr = measured_traffic(n_windows, store_samples)
     return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": (tr or {}).get("hbm_bytes_per_launch"), "traffic_detail": tr, "kernel": "nsdiff_chain_f16_kernel<1,true>",
+            "traffic": (tr or {}).get("hbm_bytes_per_launch"), "traffic_stale": bool((tr or {}).get("stale")), "traffic_detail": tr,
+            "kernel": "nsdiff_chain_f16_kernel<1,true>",
             "kernel_avg_ms": kernel_ms, "launches": launches,
             "flop_per_launch": flop_per_launch,
             "peak_source": "dense f16 MFMA peak 2500 TFLOP/s / 3 MFMA products per algorithmic product (f16x3 split)",

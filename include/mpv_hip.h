@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MPV_ABI_VERSION 2
+#define MPV_ABI_VERSION 3
 
 #define MPV_OK 0
 #define MPV_EINVAL (-1)   /* bad argument / unsupported shape            */
@@ -361,6 +361,10 @@ typedef struct {
     int32_t n_samples;     /* S = n_z_samples                                                       */
     int32_t chunk;         /* P = parallel_sample: graph copies per window in one pass; S % P == 0  */
     uint64_t seed;
+    int64_t rows_per_pass; /* ABI v3: windows are processed in blocks of at most this many node rows
+                              (P*V rows per window, at least one window per block); 0 = the library's
+                              default (32768).  Draws are keyed by (window, chunk, position), so the
+                              result does not depend on the blocking.                                */
 } mpv_nss_sample_shape;
 
 /* y0hat, gx: dev [W][V][O][F] (f(x) and the sigma head's g(x) per node).  noise: dev or NULL: the reference's draws in its order, laid out as

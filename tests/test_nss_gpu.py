@@ -83,6 +83,29 @@ def test_torch_cpu_stream_philox_mode_and_window_batching(z):
     assert bool(torch.isfinite(mpv).all()) and float(mpv.min()) > 0
 
 
+def test_window_blocks_do_not_change_the_samples(z, monkeypatch):
+    """mpv_nss_sample runs a long window list in blocks of at most rows_per_pass node rows (ABI v3): Philox keys and injected draws are
+    addressed by (window, chunk, position), so one window per pass, two per pass and all five at once give the same bits."""
+    m, net, V = build(z, "tiny")
+    edge, y0 = T(z["edge_tiny"]), T(z["y0eval_tiny"])
+    g = torch.Generator().manual_seed(8)
+    scale = 1.0 + 0.2 * torch.randn(5, 1, 1, 1, generator=g)
+    hist = (T(z["batch_tiny"]).unsqueeze(0) * scale).to(dev())
+    y0w = y0.unsqueeze(0) * scale
+    PV = net["parallel_sample"] * V
+    whole = m.sample_windows(hist, edge, y0w, seed=11)
+    for rows in (1, PV, 2 * PV + 1):                                                # 1 row: still one whole window per pass
+        monkeypatch.setenv("MPV_NSS_ROWS", str(rows))
+        assert torch.equal(m.sample_windows(hist, edge, y0w, seed=11), whole), "rows_per_pass = %d changed the samples" % rows
+    monkeypatch.delenv("MPV_NSS_ROWS")
+    mt, _, _ = build(z, "tiny", noise_source="torch_cpu")
+    torch.manual_seed(12)
+    whole = mt.sample_windows(hist, edge, y0w)
+    monkeypatch.setenv("MPV_NSS_ROWS", str(2 * PV))
+    torch.manual_seed(12)
+    assert torch.equal(mt.sample_windows(hist, edge, y0w), whole)
+
+
 def test_nss_c_abi_error_paths(z):
     import ctypes as C
     from mpv_amd import _native

@@ -13,6 +13,24 @@ import os
 import re
 import sys
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def binary_identity():
+    """sha256 of the library the passes ran on + the commit it was built from (build.py leaves build_info.json next to the .so; the GPU box has
+    no .git).  bench_common.measured_traffic quotes a traffic file only for the library with this hash."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_bc", os.path.join(ROOT, "unsupervised-probing-using-generative-diffusion-models_amd", "bench_common.py"))
+    bc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bc)
+    info = {}
+    try:
+        info = json.load(open(os.path.join(ROOT, "unsupervised-probing-using-generative-diffusion-models_amd", "build_info.json")))
+    except (OSError, ValueError):
+        pass
+    return bc.lib_sha256(), info.get("commit"), info.get("dirty")
+
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "")
@@ -60,7 +78,8 @@ def main():
         kernels[k] = rec
         total += rec["hbm_bytes"]
     top = sorted(kernels.items(), key=lambda kv: -kv[1].get("share_pct", 0.0))
-    res = {"_how": how, "_correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KB) x 1024 x 2 (gfx950 reports half of wide coalesced reads), "
+    sha, commit, dirty = binary_identity()
+    res = {"_how": how, "_lib_sha256": sha, "_commit": commit, "_commit_dirty": dirty, "_correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KB) x 1024 x 2 (gfx950 reports half of wide coalesced reads), "
                                        "WRITE_SIZE (KB) x 1024 exact; separate --pmc passes, durations from a third --kernel-trace --stats pass",
            "windows_in_step": windows, "hbm_bytes_total": total, "bytes_per_window": total / max(windows, 1),
            "dominant_kernel": top[0][0] if top else None, "kernels": dict(top)}

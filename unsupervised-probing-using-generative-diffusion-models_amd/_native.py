@@ -15,7 +15,7 @@ import torch
 PKG = Path(__file__).resolve().parent
 import os
 LIB_PATH = Path(os.environ.get("MPV_LIB", PKG / "libmpv_hip.so"))   # MPV_LIB: kernel-variant experiments only
-ABI_VERSION = 2
+ABI_VERSION = 3
 HIDDEN = 128
 MAX_NF = 4
 COEF_COLS = 20
@@ -90,7 +90,8 @@ class NssDesc(C.Structure):
 
 
 class NssSampleShape(C.Structure):
-    _fields_ = [("n_windows", C.c_int32), ("nodes", C.c_int32), ("n_samples", C.c_int32), ("chunk", C.c_int32), ("seed", C.c_uint64)]
+    _fields_ = [("n_windows", C.c_int32), ("nodes", C.c_int32), ("n_samples", C.c_int32), ("chunk", C.c_int32), ("seed", C.c_uint64),
+                ("rows_per_pass", C.c_int64)]
 
 
 class NstDesc(C.Structure):
@@ -632,8 +633,9 @@ class Context:
         return eps, sig
 
     def nss_sample(self, y0hat: torch.Tensor, gx: torch.Tensor, edge_index: torch.Tensor, n_samples: int, chunk: int,
-                   noise: Optional[torch.Tensor] = None, seed: int = 0) -> torch.Tensor:
-        """y0hat, gx [W, V, pred_len, F] on device -> samples [W, V, pred_len, F, n_samples] on device."""
+                   noise: Optional[torch.Tensor] = None, seed: int = 0, rows_per_pass: int = 0) -> torch.Tensor:
+        """y0hat, gx [W, V, pred_len, F] on device -> samples [W, V, pred_len, F, n_samples] on device.  Windows run in blocks of at most
+        `rows_per_pass` node rows (0: the library's default, MPV_NSS_ROWS overrides); the result does not depend on the blocking."""
         if self.nss is None:
             raise MpvError("NsDiff_spatial weights not loaded")
         if tuple(y0hat.shape) != tuple(gx.shape) or y0hat.dim() != 4 or y0hat.shape[2] != self.nss[0] or y0hat.shape[3] != self.nss[1]:
@@ -647,7 +649,10 @@ class Context:
             if noise.numel() != need:
                 raise MpvError("noise has {} elements, the draw order needs {}".format(noise.numel(), need))
         out = torch.empty((W, V, O, F, n_samples), device=self.device, dtype=torch.float32)
-        shape = NssSampleShape(W, V, n_samples, chunk, seed & (2 ** 64 - 1))
+        rows_per_pass = int(rows_per_pass or os.environ.get("MPV_NSS_ROWS", 0))
+        if rows_per_pass < 0:
+            raise MpvError("rows_per_pass must be >= 0")
+        shape = NssSampleShape(W, V, n_samples, chunk, seed & (2 ** 64 - 1), rows_per_pass)
         self._bind_stream()
         self._check(self.lib.mpv_nss_sample(self._h, C.byref(shape), _dev_ptr(y0hat, self.device, "y0hat"), _dev_ptr(gx, self.device, "gx"),
                                             _dev_ptr(noise, self.device, "noise"), _dev_ptr(out, self.device, "samples")), "mpv_nss_sample")

@@ -21,7 +21,9 @@ def main_c4(args, log):
     rk = Ranks(args)
     out = record_c4(args, log, rk)
     if rk.rank == 0:
-        print(json.dumps(out), flush=True)
+        from mpv_amd.bench_common import emit_record, print_line
+        emit_record("c4", out, fresh=True)
+        print_line(out)
     rk.close()
 
 
@@ -40,6 +42,9 @@ def record_c4(args, log, rk):
     gen.close()
     sampled = series.cpu().contiguous()
     n_windows = H.sliding_window_count(sampled.shape[1], cfg["windows"], cfg["window_step"])
+    cut = getattr(args, "max_windows", None)                 # profiling / test aid: the record says so (`truncated_for_profiling`)
+    if cut is not None:
+        n_windows = min(n_windows, int(cut))
     net_param = dict(device=device, scaler_type="StandardScaler", task_model="NsDiff_model_variants", rolling_length=cfg["rolling"],
                      diffusion_schedule="linear", diffusion_steps=cfg["steps"], beta_start=1e-4, beta_end=0.02, n_z_samples=cfg["n_z"],
                      parallel_sample=cfg["parallel_sample"], windows=cfg["windows"], pred_len=cfg["pred_len"], dataset_nf=cfg["nf"])
@@ -90,10 +95,11 @@ def record_c4(args, log, rk):
         "config": {"workload": "NsDiff cond_var on a 500-node Erdos-Renyi Wilson-Cowan trajectory (BASELINE configs[3]): windows=100, pred_len=100, "
                                "rolling=50, N=64 samples, T=50 steps, {} windows; ONE trajectory per step, its windows split in contiguous "
                                "blocks over {} rank(s), one all-gather of the curve".format(n_windows, world),
-                   "windows_per_step": n_windows, "windows_of_rank0": hi - lo, "noise": "on-device Philox4x32-10", "weights": "seeded default init",
+                   "windows_per_step": n_windows, "windows_of_rank0": hi - lo, "truncated_for_profiling": cut is not None, "noise": "on-device Philox4x32-10", "weights": "seeded default init",
                    "summary": "MPV reduction fused into the sampler epilogue, no sample tensor"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak if peak else None,
-                     "traffic": chain_traffic(tr), "traffic_detail": {k: v for k, v in (tr or {}).items() if k != "kernels"} or None,
+                     "traffic": None if (tr or {}).get("stale") else chain_traffic(tr), "traffic_stale": bool((tr or {}).get("stale")),
+                     "traffic_detail": {k: v for k, v in (tr or {}).items() if k != "kernels"} or None,
                      "kernel": "nsdiff_chain_f16_kernel<1,true> (rank 0's block)", "kernel_avg_ms": kernel_ms, "launches": launches,
                      "flop_per_launch": flop_per_launch},
     }

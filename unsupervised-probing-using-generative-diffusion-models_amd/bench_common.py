@@ -30,13 +30,39 @@ def init_group(backend, rank, world, device):
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timeout)
 
 
-def measured_traffic(key, repo_root=None):
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, 256 CUs x 4 SIMD x 64 flop/clk x 2.4 GHz
+F16_MATRIX_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16 / bf16 MFMA
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E, 8 TB/s peak (about 6.3 TB/s achievable)
+
+
+def repo_root() -> str:
+    return os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def lib_sha256(path=None):
+    """sha256 of the HIP library this process would load (MPV_LIB or the in-tree libmpv_hip.so); None when it does not exist.  PMC traffic
+    files carry the hash of the library they were measured on (tools/pmc_traffic.py) and are only quoted for that very binary."""
+    import hashlib
+    path = path or os.environ.get("MPV_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpv_hip.so")
+    try:
+        h = hashlib.sha256()
+        with open(path, "rb") as fh:
+            for blk in iter(lambda: fh.read(1 << 20), b""):
+                h.update(blk)
+        return h.hexdigest()
+    except OSError:
+        return None
+
+
+def measured_traffic(key, root=None, lib_hash=None):
     """Per-kernel HBM traffic of one bench step from the committed PMC passes (profiles/*/pmc_traffic_<key>.json, written by
     tools/pmc_traffic.py: separate FETCH_SIZE and WRITE_SIZE passes, FETCH doubled as the guide prescribes for gfx950); newest round
-    first, None when there is none."""
+    first, None when there is none.  A file measured on ANOTHER binary than the one loaded now (its `_lib_sha256` differs from this
+    library's, or it carries none) is returned with `stale = True`: the caller must not quote its bytes as this run's traffic."""
     import glob
     import json
-    root = repo_root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = root or repo_root()
+    lib_hash = lib_hash or lib_sha256()
     for f in sorted(glob.glob(os.path.join(root, "profiles", "*", "pmc_traffic_%s.json" % key)), reverse=True):
         try:
             with open(f) as fh:
@@ -44,28 +70,118 @@ def measured_traffic(key, repo_root=None):
         except (OSError, ValueError):
             continue
         rec["source"] = os.path.relpath(f, root)
+        rec["stale"] = not (rec.get("_lib_sha256") and rec.get("_lib_sha256") == lib_hash)
         return rec
     return None
 
 
-HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E, 8 TB/s peak (about 6.3 TB/s achievable)
+def split_peak(gemm_mode):
+    """(peak TFLOP/s for ALGORITHMIC flops, its description) of contractions evaluated in `gemm_mode`: the exact-fp32 matrix pipe, or the f16
+    matrix pipe executing 3 / 2 / 1 MFMA products per algorithmic product (two-term split of both operands / of one / plain f16)."""
+    if gemm_mode == "f32":
+        return FP32_MATRIX_PEAK_TFLOPS, "fp32 matrix pipe 157.3 TFLOP/s"
+    products = {"f16x3": 3, "f16x2": 2, "f16": 1}[gemm_mode]
+    return F16_MATRIX_PEAK_TFLOPS / products, "dense f16 MFMA peak 2500 TFLOP/s / %d executed products per algorithmic product" % products
 
 
-def multi_kernel_roofline(tr, windows_per_s, achieved_tflops, peak_tflops, peak_name, kernels, extra=None):
-    """Roofline object of a call made of many kernels (c3, c5).  With a committed PMC pass (`tr`, profiles/*/pmc_traffic_<cfg>.json) the
-    bound is stated against HBM: achieved = measured HBM bytes per window x windows/s (every kernel of these schedules streams its operands
-    once, so measured and algorithmic bytes coincide to within the L2 / Infinity-Cache hits the counters still see), `traffic` = those bytes
-    per window; the matrix-pipe view of the same run is kept under `compute`.  Without a PMC pass only the compute view exists."""
-    compute = {"achieved_tflops": achieved_tflops, "peak_tflops": peak_tflops, "peak": peak_name, "frac": achieved_tflops / peak_tflops}
-    if tr and tr.get("bytes_per_window"):
+def multi_kernel_roofline(tr, windows_per_s, achieved_tflops, gemm_mode, kernels, extra=None):
+    """Roofline object of a call made of many kernels (c3, c5, nss).  With a PMC pass of THIS binary (`tr`, profiles/*/pmc_traffic_<cfg>.json whose
+    library hash matches) the bound is stated against HBM: achieved = measured HBM bytes per window x windows/s, `traffic` = those bytes per window;
+    a pass of another binary is `traffic: None, traffic_stale: True` and the record falls back to the compute view.  The matrix-pipe view of the
+    same run is always kept under `compute`, against the pipe that executes the products (`split_peak`); the ratio to the fp32 matrix peak only
+    as `vs_fp32_matrix_peak`."""
+    peak, peak_name = split_peak(gemm_mode)
+    compute = {"achieved_tflops": achieved_tflops, "peak_tflops": peak, "peak": peak_name, "frac": achieved_tflops / peak,
+               "vs_fp32_matrix_peak": achieved_tflops / FP32_MATRIX_PEAK_TFLOPS}
+    if tr and tr.get("bytes_per_window") and not tr.get("stale"):
         gbps = tr["bytes_per_window"] * windows_per_s / 1e9
         out = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": tr["bytes_per_window"],
-               "kernel": kernels, "dominant_kernel": tr.get("dominant_kernel"), "compute": compute}
+               "traffic_source": tr.get("source"), "kernel": kernels, "dominant_kernel": tr.get("dominant_kernel"), "compute": compute}
     else:
-        out = {"bound": "mfma", "achieved": achieved_tflops, "peak": peak_tflops, "unit": "TFLOP/s", "frac": achieved_tflops / peak_tflops, "traffic": None,
+        out = {"bound": "mfma", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak, "traffic": None,
                "kernel": kernels, "compute": compute}
+        if tr:
+            out.update(traffic_stale=True, traffic_stale_source=tr.get("source"))
     out.update(extra or {})
     return out
+
+
+# ---- one short line on stdout, everything else on stderr + a records file ----------------------------------------------------------------
+VERBOSE_KEYS = ("traffic_detail", "note", "per_window_s", "peak_source", "parity", "kernels", "fx_peak", "passes_per_window", "traffic_stale_source",
+                "dominant_kernel", "flop_per_sequence_forward", "flop_per_sequence_backward", "flop_per_row_forward")
+LINE_LIMIT = 4000
+
+
+def records_path():
+    """Where the secondary records of a bench run go (JSON lines): MPV_BENCH_RECORDS, else gpurun_out/bench_records.jsonl under the repo."""
+    p = os.environ.get("MPV_BENCH_RECORDS")
+    if p:
+        return p
+    d = os.path.join(repo_root(), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        return os.path.join(d, "bench_records.jsonl")
+    except OSError:
+        return None
+
+
+def emit_record(name, rec, fresh=False):
+    """A secondary record (other GEMM modes, other configs / families, trained checkpoints ...): one JSON line on STDERR, prefixed
+    `[bench record]`, and appended to the records file -- never on stdout, which carries the headline line alone."""
+    import json
+    import sys
+    line = json.dumps({"record": name, **rec})
+    print("[bench record] " + line, file=sys.stderr, flush=True)
+    path = records_path()
+    if path:
+        try:
+            with open(path, "w" if fresh else "a") as fh:
+                fh.write(line + "\n")
+        except OSError:
+            pass
+
+
+def compact(rec, limit=LINE_LIMIT):
+    """The record as the ONE stdout line carries it: verbose members (per-kernel traffic tables, notes, long provenance strings) dropped at
+    every depth, strings clipped; raises when the result still exceeds `limit` characters, so an over-long line fails here and not in the
+    driver's parser (a 20 KB line was cut to its 8 000-character tail and could not be parsed)."""
+    import json
+
+    def walk(x):
+        if isinstance(x, dict):
+            return {k: walk(v) for k, v in x.items() if k not in VERBOSE_KEYS}
+        if isinstance(x, (list, tuple)):
+            return [walk(v) for v in x]
+        if isinstance(x, str) and len(x) > 400:
+            return x[:397] + "..."
+        if isinstance(x, float):
+            return float("%.6g" % x)
+        return x
+
+    out = walk(rec)
+    n = len(json.dumps(out))
+    if n > limit:
+        raise ValueError("bench line is %d characters (limit %d): move members into emit_record()" % (n, limit))
+    return out
+
+
+def digest(rec):
+    """value / unit / roofline fraction of a secondary record: what the headline line keeps of it (`other`)."""
+    if not isinstance(rec, dict) or "value" not in rec:
+        return {"error": (rec or {}).get("error", "no value")[:120]} if isinstance(rec, dict) else {"error": "no record"}
+    roof = rec.get("roofline") or {}
+    out = {"value": rec["value"], "unit": rec.get("unit")}
+    if roof.get("frac") is not None:
+        out.update(bound=roof.get("bound"), frac=roof["frac"])
+    elif rec.get("frac") is not None:
+        out.update(frac=rec["frac"])
+    return out
+
+
+def print_line(rec):
+    """THE stdout line of a bench run."""
+    import json
+    print(json.dumps(compact(rec)), flush=True)
 
 
 class Ranks:

@@ -13,7 +13,6 @@ import time
 import numpy as np
 import torch
 
-FP32_MATRIX_PEAK_TFLOPS = 157.3
 C3 = dict(nodes=100, ticks=10_000, sampling_t=0.1, windows=100, pred_len=100, window_step=50, n_z=32, parallel_sample=32, nf=1,
           d_model=64, n_heads=4, n_layer_enc=3, n_layer_dec=6, timesteps=100, diffusion_steps=100)
 
@@ -36,7 +35,9 @@ def main_c3(args, log):
     rk = Ranks(args)                                   # N ranks: every rank samples windows of its own trajectory (weak scaling)
     out = record_c3(args, log, rk)
     if rk.rank == 0:
-        print(json.dumps(out), flush=True)
+        from mpv_amd.bench_common import emit_record, print_line
+        emit_record("c3", out, fresh=True)             # the full record (per-kernel traffic table, notes): stderr + records file
+        print_line(out)
     rk.close()
 
 
@@ -102,7 +103,8 @@ def record_c3(args, log, rk):
         "metric": "rolling windows/sec (N=32, T=100), DiffusionTS", "value": rk.world * wps * args.steps / elapsed, "unit": "windows/s", "n_gpus": rk.world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 (every contraction on v_mfma_f32_16x16x4_f32)" if net["gemm_mode"] == "f32" else
-        "f32 (attention products as 3x f16 MFMA with fp32 accumulate, fp32-equivalent; Linear / MLP contractions on v_mfma_f32_16x16x4_f32)", "data": "synthetic",
+        "f32 (attention, fused MLP, token-wise Linear and token-mixing products as two-term f16 splits on the f16 matrix pipe: 3 MFMA products per "
+        "algorithmic product, fp32 accumulate, fp32-equivalent)", "data": "synthetic",
         "config": {"workload": "DiffusionTS on 100-node BA-graph SIS trajectory (BASELINE configs[2]): windows=100, pred_len=100, d_model=64, "
                                "4 heads, 3 enc + 6 dec blocks, N=32 samples in one chunk (3200 sequences x 200 tokens), T=100 DDIM steps with "
                                "Langevin infill; {} window(s) per step of the {} of the trajectory".format(wps, n_total),
@@ -110,8 +112,7 @@ def record_c3(args, log, rk):
                    "truncated_for_profiling": short > 0, "sampling_steps": cfg["diffusion_steps"],
                    "passes_per_window": {"forward": n_fwd, "backward": n_bwd}},
         "roofline": multi_kernel_roofline(
-            tr if short == 0 else None, rk.world * wps * args.steps / elapsed / rk.world, achieved, FP32_MATRIX_PEAK_TFLOPS,
-            "fp32 matrix pipe (algorithmic FLOPs of the whole call; Linear, attention and MLP products run as 3x f16 MFMA unless gemm_mode='f32')",
+            tr if short == 0 else None, rk.world * wps * args.steps / elapsed / rk.world, achieved, "f32" if net["gemm_mode"] == "f32" else "f16x3",
             "dts_lin_wave + dts_attn_{fwd,dq,dkv}_h + dts_mlp_{fwd,bwd}_h + dts_ln_bwd + dts_seqmix + Fourier / trend kernels (whole sampler call)",
             {"flop_per_window": flop_per_window, "flop_per_sequence_forward": ff, "flop_per_sequence_backward": fb, "traffic_detail": slim_traffic(tr),
              "note": "356 transformer passes of about 100 kernels each over [3200 x 200 x 64] activations; achieved compute = algorithmic FLOPs of the "

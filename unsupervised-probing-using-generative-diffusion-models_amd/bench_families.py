@@ -8,7 +8,6 @@ import time
 import numpy as np
 import torch
 
-FP32_MATRIX_PEAK_TFLOPS = 157.3
 F16_MATRIX_PEAK_TFLOPS = 2500.0
 
 NSS = dict(nodes=200, windows=100, pred_len=100, rolling=50, steps=50, n_z=32, parallel=32, d_h=4, Td_h=10, channel_multipliers=[2, 2], n_blocks=2, n_windows=4)
@@ -72,18 +71,14 @@ def record_nsdiff_spatial(device, log, cpu=True):
            "dtype": "f32 (k = T+1 convolutions, graph-conv Linear maps and TCN blocks as two-term f16 splits on the f16 matrix pipe, fp32 accumulate)",
            "data": "synthetic", "config": {"workload": "NsDiff_spatial on a 200-node small-world graph: windows=100, pred_len=100, d_h=4, multipliers [2,2], 2 blocks "
                                                        "per resolution, Td_h=10, parallel_sample=32 (6400 node rows per window), T=50 steps; f(x) supplied",
-                                           "weights": "seeded default init", "noise": "on-device Philox4x32-10"},
-           "roofline": {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
-                        "kernel": "the kernels of other_configs.c5 at time length 100 (stg_tcn_mfma_kernel, nst_gemm_h3_kernel, stg_gate_kernel) + nss_heads / nss_posterior",
-                        "compute": {"achieved_tflops": achieved, "peak_tflops": FP32_MATRIX_PEAK_TFLOPS, "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
-                                    "flop_per_window": flop_per_window},
-                        "note": "no PMC pass of its own: the step is the c5 kernel mix at half the time length (c5: 3.0 TB/s measured)"}}
-    from mpv_amd.bench_common import measured_traffic
-    tr = measured_traffic("nss")                     # profiles/*/pmc_traffic_nss.json (tools/r3_pmc.sh nss), bytes per window
-    if tr:
-        gbps = tr["bytes_per_window"] * rec["value"] / 1e9
-        rec["roofline"].update(achieved=gbps, frac=gbps / 8000.0, traffic=tr["bytes_per_window"], traffic_source=tr["source"],
-                               note="HBM bytes per window from separate FETCH_SIZE / WRITE_SIZE passes over this record's own step")
+                                           "weights": "seeded default init", "noise": "on-device Philox4x32-10"}
+           }
+    from mpv_amd.bench_common import measured_traffic, multi_kernel_roofline
+    tr = measured_traffic("nss")                     # profiles/*/pmc_traffic_nss.json (tools/pmc_pass.sh nss), bytes per window, bound to its binary
+    rec["roofline"] = multi_kernel_roofline(
+        tr, rec["value"], achieved, "f16x3",
+        "the kernels of c5 at time length 100 (stg_tcn_mfma_kernel, nst_gemm_h3_kernel, stg_gate_kernel) + nss_heads / nss_posterior",
+        {"flop_per_window": flop_per_window})
     if cpu:
         from oracle import nsdiff_spatial_oracle as O
         from oracle import nsdiff_oracle as NS

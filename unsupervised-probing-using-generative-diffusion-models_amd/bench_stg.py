@@ -13,7 +13,6 @@ import time
 import numpy as np
 import torch
 
-FP32_MATRIX_PEAK_TFLOPS = 157.3
 C5 = dict(nodes=200, ticks=20_000, sampling_t=1, windows=100, pred_len=100, window_step=50, parallel=32, sequential=1, steps=50,
           d_h=4, Td_h=10, channel_multipliers=[2, 2], n_blocks=2, diffusion_steps=200)
 
@@ -59,7 +58,9 @@ def main_c5(args, log):
     rk = Ranks(args)                                   # N ranks: every rank samples windows of its own trajectory (weak scaling), graph replicated
     out = record_c5(args, log, rk)
     if rk.rank == 0:
-        print(json.dumps(out), flush=True)
+        from mpv_amd.bench_common import emit_record, print_line
+        emit_record("c5", out, fresh=True)
+        print_line(out)
     rk.close()
 
 
@@ -126,13 +127,13 @@ def record_c5(args, log, rk):
     out = {
         "metric": "rolling windows/sec (N=32, 50 inference steps), DiffSTG", "value": rk.world * wps * args.steps / elapsed, "unit": "windows/s", "n_gpus": rk.world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (k = T+1 convolutions and graph-conv Linear maps as two-term f16 splits on v_mfma_f32_32x32x16_f16 with fp32 accumulate, rest fp32 VALU)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (k = T+1 convolutions, graph-conv Linear maps and TCN blocks as two-term f16 splits on the f16 matrix pipe: 3 MFMA products per algorithmic product, fp32 accumulate; rest fp32 VALU)", "data": "synthetic",
         "config": {"workload": "DiffSTG on 200-node small-world biomass trajectory (BASELINE configs[4]): T_h=T_p=100, d_h=4, multipliers [2,2], "
                                "2 blocks per resolution (12 residual blocks), Td_h=10, parallel_sampling=32 (6400 node rows per window), 50 DDIM steps; "
                                "{} window(s) per step of the {} of the trajectory".format(wps, n_total),
                    "windows_per_step_per_gpu": wps, "noise": "on-device Philox4x32-10", "weights": "seeded default init"},
         "roofline": multi_kernel_roofline(
-            tr, rk.world * wps * args.steps / elapsed / rk.world, achieved, FP32_MATRIX_PEAK_TFLOPS, "fp32 matrix pipe (algorithmic FLOPs of the whole call)",
+            tr, rk.world * wps * args.steps / elapsed / rk.world, achieved, "f16x3",     # bench_stg builds the model with the default gemm_mode
             "nst_gemm_h3_kernel (k = T+1 convolutions, graph-conv Linear maps) + stg_tcn_mfma_kernel (TCN blocks) + stg_gate_kernel",
             {"flop_per_window": flop_per_window, "flop_per_row_forward": fpr, "traffic_detail": slim_traffic(tr),
              "note": "60 kernels per inference step over [6400 rows x c x T] activations: every kernel is bound by the activation traffic it streams "

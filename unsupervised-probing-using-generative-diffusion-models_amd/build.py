@@ -77,7 +77,23 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError("link failed:\n" + proc.stdout + proc.stderr)
+    _write_build_info()
     return LIB
+
+
+def _write_build_info():
+    """build_info.json beside the library (git-ignored, travels to the GPU box, which has no .git): the commit the sources were at, whether the
+    tree was dirty, the library's sha256.  tools/pmc_traffic.py copies commit + hash into every PMC traffic file."""
+    import hashlib
+    import json
+    info = {"lib_sha256": hashlib.sha256(LIB.read_bytes()).hexdigest(), "commit": None, "dirty": None}
+    try:
+        info["commit"] = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+        info["dirty"] = bool(subprocess.run(["git", "-C", str(ROOT), "status", "--porcelain", "--", str(CSRC), str(ROOT / "include")],
+                                            capture_output=True, text=True, timeout=10).stdout.strip())
+    except (OSError, subprocess.SubprocessError):
+        pass
+    (PKG / "build_info.json").write_text(json.dumps(info, indent=1))
 
 
 if __name__ == "__main__":

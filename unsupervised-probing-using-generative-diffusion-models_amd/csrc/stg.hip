@@ -506,8 +506,9 @@ __global__ void nss_tile_kernel(const float* __restrict__ src, int V, int P, lon
 
 // draw k of chunk c for the rows of one pass: injected (the reference's stream, [W][C][T][P*V][O][F]) or Philox keyed by the element's
 // position in [W][C][P*V][O][F] with the draw index as the stream
+// (`inj` points at the block's first window, `w0` is that window's index in the call: Philox keys do not depend on the window blocking)
 __global__ void nss_noise_kernel(const float* __restrict__ inj, int C, int c, int Tn, int k, long long PV, long long OF, unsigned seed_lo, unsigned seed_hi,
-                                 long long n, float* z) {
+                                 long long w0, long long n, float* z) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // (w*PV + r)*OF + rem
     if (i >= n) return;
     const long long per = PV * OF, w = i / per, rest = i - w * per;
@@ -515,7 +516,7 @@ __global__ void nss_noise_kernel(const float* __restrict__ inj, int C, int c, in
         z[i] = inj[((w * C + c) * Tn + k) * per + rest];
         return;
     }
-    const unsigned long long id = (unsigned long long)((w * C + c) * per + rest);
+    const unsigned long long id = (unsigned long long)(((w0 + w) * C + c) * per + rest);
     float zz[4];
     chain::philox_normals(id >> 2, (unsigned)k, seed_lo, seed_hi, 0x4E535300u, zz);
     const unsigned e = (unsigned)(id & 3ull);
@@ -1234,26 +1235,37 @@ int mpv_nss_sample(mpv_ctx* ctx, const mpv_nss_sample_shape* s, const float* y0h
         return mpv_fail(ctx, MPV_EINVAL, "mpv_nss_sample: need n_windows >= 1, nodes = the graph's node count, n_samples a positive multiple of chunk");
     DeviceGuard dg(ctx->device);
     const int O = e.T0, F = e.d.nf, P = s->chunk, V = e.V, C = s->n_samples / P, Tn = e.steps_T;
-    const long long PV = (long long)P * V, N = (long long)s->n_windows * PV, OF = (long long)O * F, n = N * OF;
-    STG_TRY(carve(ctx, e, N));
+    if (s->rows_per_pass < 0) return mpv_fail(ctx, MPV_EINVAL, "mpv_nss_sample: rows_per_pass must be >= 0");
+    const long long PV = (long long)P * V, OF = (long long)O * F;
+    // windows in blocks of at most rows_per_pass node rows (at least one window): the workspace is carved for ONE block, so a long window list
+    // costs launches, not memory (the whole list used to be carved at once)
+    const long long limit = s->rows_per_pass > 0 ? s->rows_per_pass : 32768;
+    const long long wb_max = std::max<long long>(1, std::min<long long>(s->n_windows, limit / PV));
+    if (wb_max * PV * OF > (long long)INT32_MAX * 256) return mpv_fail(ctx, MPV_EINVAL, "mpv_nss_sample: a window block exceeds the grid limit; lower rows_per_pass");
+    STG_TRY(carve(ctx, e, wb_max * PV));
     hipStream_t st = ctx->stream;
     const unsigned seed_lo = (unsigned)s->seed, seed_hi = (unsigned)(s->seed >> 32);
     float *mu = e.xm, *g = e.gg, *y = e.xt, *z = e.noise;
-    hipLaunchKernelGGL(nss_tile_kernel, g1d(n), dim3(256), 0, st, y0hat, V, P, OF, n, mu);
-    hipLaunchKernelGGL(nss_tile_kernel, g1d(n), dim3(256), 0, st, gx, V, P, OF, n, g);
-    MPV_HIP_TRY(ctx, hipGetLastError());
-    for (int c = 0; c < C; ++c) {                                                  // chunks of parallel_sample graph copies (NsDiff_model.py:755)
-        hipLaunchKernelGGL(nss_noise_kernel, g1d(n), dim3(256), 0, st, noise, C, c, Tn, 0, PV, OF, seed_lo, seed_hi, n, z);
-        hipLaunchKernelGGL(nss_init_kernel, g1d(n), dim3(256), 0, st, g, z, mu, n, y);
+    for (long long w0 = 0; w0 < s->n_windows; w0 += wb_max) {
+        const long long wb = std::min<long long>(wb_max, s->n_windows - w0), N = wb * PV, n = N * OF;
+        const float* inj = noise ? noise + (size_t)w0 * C * Tn * PV * OF : nullptr;
+        float* out = samples + (size_t)w0 * V * OF * s->n_samples;
+        hipLaunchKernelGGL(nss_tile_kernel, g1d(n), dim3(256), 0, st, y0hat + (size_t)w0 * V * OF, V, P, OF, n, mu);
+        hipLaunchKernelGGL(nss_tile_kernel, g1d(n), dim3(256), 0, st, gx + (size_t)w0 * V * OF, V, P, OF, n, g);
         MPV_HIP_TRY(ctx, hipGetLastError());
-        for (int t = Tn - 1; t >= 0; --t) {                                        // p_sample for t = T-1 .. 1, p_sample_t_1to0 at t = 0
-            STG_TRY(forward_nss(ctx, e, y, mu, g, N, t));
-            if (t > 0) hipLaunchKernelGGL(nss_noise_kernel, g1d(n), dim3(256), 0, st, noise, C, c, Tn, Tn - t, PV, OF, seed_lo, seed_hi, n, z);   // drawn after the model call (:130)
-            hipLaunchKernelGGL(nss_posterior_kernel, g1d(n), dim3(256), 0, st, e.coef + (size_t)t * MPV_COEF_COLS, mu, g, e.eps, e.sig, z, t == 0 ? 1 : 0, n, y);
+        for (int c = 0; c < C; ++c) {                                                  // chunks of parallel_sample graph copies (NsDiff_model.py:755)
+            hipLaunchKernelGGL(nss_noise_kernel, g1d(n), dim3(256), 0, st, inj, C, c, Tn, 0, PV, OF, seed_lo, seed_hi, w0, n, z);
+            hipLaunchKernelGGL(nss_init_kernel, g1d(n), dim3(256), 0, st, g, z, mu, n, y);
+            MPV_HIP_TRY(ctx, hipGetLastError());
+            for (int t = Tn - 1; t >= 0; --t) {                                        // p_sample for t = T-1 .. 1, p_sample_t_1to0 at t = 0
+                STG_TRY(forward_nss(ctx, e, y, mu, g, N, t));
+                if (t > 0) hipLaunchKernelGGL(nss_noise_kernel, g1d(n), dim3(256), 0, st, inj, C, c, Tn, Tn - t, PV, OF, seed_lo, seed_hi, w0, n, z);   // drawn after the model call (:130)
+                hipLaunchKernelGGL(nss_posterior_kernel, g1d(n), dim3(256), 0, st, e.coef + (size_t)t * MPV_COEF_COLS, mu, g, e.eps, e.sig, z, t == 0 ? 1 : 0, n, y);
+                MPV_HIP_TRY(ctx, hipGetLastError());
+            }
+            hipLaunchKernelGGL(nss_gather_kernel, g1d(n), dim3(256), 0, st, y, V, P, OF, s->n_samples, c, n, out);
             MPV_HIP_TRY(ctx, hipGetLastError());
         }
-        hipLaunchKernelGGL(nss_gather_kernel, g1d(n), dim3(256), 0, st, y, V, P, OF, s->n_samples, c, n, samples);
-        MPV_HIP_TRY(ctx, hipGetLastError());
     }
     return MPV_OK;
 }
