@@ -251,10 +251,23 @@ int attn_launch_h(mpv_ctx* ctx, int mode, const AttnArgs& a, int B) {
         const size_t lds = sizeof(_Float16) * (4 * (size_t)Lkp * AH_RS) + 64;
         if (int rc = set_lds(ctx, dts_attn_dq_h_kernel, lds)) return rc;
         hipLaunchKernelGGL(dts_attn_dq_h_kernel, grid, block, lds, ctx->stream, a);
-    } else {
+    } else if (mode == 2) {
         const size_t lds = sizeof(_Float16) * (4 * (size_t)Lqp * AH_RS) + sizeof(float) * 2 * Lqp + 64;
         if (int rc = set_lds(ctx, dts_attn_dkv_h_kernel, lds)) return rc;
         hipLaunchKernelGGL(dts_attn_dkv_h_kernel, grid, block, lds, ctx->stream, a);
+    } else {                                                                  // 3: dQ, dK, dV in one pass (round 4)
+        const size_t lds = attn_bwd_h_lds(a.Lq);
+        const int nqt = Lqp >> 4;
+#define DTS_ABWD(NT_)                                                                         \
+    do {                                                                                      \
+        if (int rc = set_lds(ctx, dts_attn_bwd_h_kernel<NT_>, lds)) return rc;                \
+        hipLaunchKernelGGL(dts_attn_bwd_h_kernel<NT_>, grid, block, lds, ctx->stream, a);     \
+    } while (0)
+        if (nqt <= 4) DTS_ABWD(4);
+        else if (nqt <= 8) DTS_ABWD(8);
+        else if (nqt <= 13) DTS_ABWD(13);
+        else DTS_ABWD(AH_MAXT);
+#undef DTS_ABWD
     }
     MPV_HIP_TRY(ctx, hipGetLastError());
     return MPV_OK;
@@ -495,6 +508,15 @@ int attn_bwd(mpv_ctx* ctx, DtsEngine& e, int B, const float* Q, int ldq, const f
         MPV_HIP_TRY(ctx, hipGetLastError());
     }
     AttnArgs a{Q, K, V, ldq, ldkv, ldkv, dO, O, ldo, dq, lddq, nullptr, 0, lse, e.delta, e.H, e.L, e.L, e.hd, scale, hs};
+    // Round 4: dQ + dK + dV in ONE pass over the (query tile, key tile) pairs (dts_attn_bwd_h_kernel).  Measured at configs[2] (profiles/r04/
+    // c3_attn_bwd_variants.txt): 875 us per launch against 477 + 382 for the two-pass pair -- its 64 dQ-partial registers leave two waves per SIMD where
+    // the pair runs five, and at two waves the 15 MFMAs of a pair no longer hide behind the vector work (6.0 cycles per instruction against 4.3);
+    // held to three waves it spills the partials (1358 us).  It moves 1 GB less per launch, so it is kept as MPV_DTS_ATTN_ONE_PASS=1; the default is the pair.
+    const bool one_pass = getenv("MPV_DTS_ATTN_ONE_PASS") != nullptr;          // (read per call: tests switch it)
+    if (f16 && one_pass) {
+        a.out = dk; a.ldout = lddkv; a.out2 = dv; a.ldout2 = lddkv; a.out3 = dq; a.ldout3 = lddq;
+        return attn_launch_h(ctx, 3, a, B);
+    }
     DTS_TRY(attn(ctx, 1, a, B, e.d.gemm != MPV_GEMM_F32));
     a.out = dk; a.ldout = lddkv; a.out2 = dv; a.ldout2 = lddkv;
     DTS_TRY(attn(ctx, 2, a, B, e.d.gemm != MPV_GEMM_F32));

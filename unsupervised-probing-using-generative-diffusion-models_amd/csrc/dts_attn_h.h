@@ -92,6 +92,42 @@ __device__ __forceinline__ float pow2_scale(float mx, float& inv) {
     return ldexpf(1.0f, 14 - e);
 }
 
+// ---- the four lanes of a column (r16, r16 + 16, r16 + 32, r16 + 48) without the LDS crossbar (round 4) -------------------------------------------
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows of two registers in the VALU: with both operands = v the pair holds
+// (v, v xor-16) resp. (v, v xor-32) afterwards.  __shfl_xor(v, 16 / 32) compiles to ds_bpermute_b32 + s_waitcnt: an LDS round trip of > 100 cycles
+// in the middle of every tile step's dependency chain; the kernels that live on few waves per SIMD (dts_attn_bwd_h_kernel) are bound by that chain.
+__device__ __forceinline__ float vmax_raw(float a, float b) {          // v_max_f32 without the canonicalising v_max(v, v) clang puts in front of fmaxf
+    float r;                                                           // for values that come out of a permute (NaNs still propagate: IEEE mode off is
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));            // not assumed -- v_max_f32 returns the non-NaN operand, as fmaxf does)
+    return r;
+}
+#ifndef DTS_COL4_SWAP
+#define DTS_COL4_SWAP 0              // measured (round 4, 10-step c3 plan): the swap forms are 2 % SLOWER in the issue-bound kernels (forward 273 -> 281 us, dQ 373
+#endif                               // -> 382: each swap needs a v_mov of its second operand) and shorten the merged backward's chain (935 -> 875 us with the
+                                     // one-tile-behind dQ product); kept as a compile-time choice
+__device__ __forceinline__ float col4_max(float v) {
+#if !DTS_COL4_SWAP
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return fmaxf(v, __shfl_xor(v, 32));
+#else
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = vmax_raw(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return vmax_raw(__uint_as_float(b[0]), __uint_as_float(b[1]));
+#endif
+}
+__device__ __forceinline__ float col4_sum(float v) {                   // (v + v^16) + (that ^ 32): the association of the two-shuffle form
+#if !DTS_COL4_SWAP
+    v += __shfl_xor(v, 16);
+    return v + __shfl_xor(v, 32);
+#else
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+#endif
+}
+
 __device__ __forceinline__ float wave_max(float m) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -167,9 +203,7 @@ __device__ __forceinline__ void load_split4(const float* p, float scale, ah4& hi
 // power of two (its four lanes agree on it with two shuffles; returned) -- no pass over the head tile is needed for operands that enter as columns
 __device__ __forceinline__ float load_split_col(const float* p, ah4& hi, ah4& lo) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-    float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
+    const float m = col4_max(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     const float sc = pow2_scale(m);
     attn_split4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc, hi, lo);
     return sc;
@@ -177,9 +211,7 @@ __device__ __forceinline__ float load_split_col(const float* p, ah4& hi, ah4& lo
 
 // the same for values already in registers
 __device__ __forceinline__ float split_col(const f32x4& v, ah4& hi, ah4& lo) {
-    float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
+    const float m = col4_max(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     const float sc = pow2_scale(m);
     attn_split4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc, hi, lo);
     return sc;
@@ -189,9 +221,7 @@ __device__ __forceinline__ float split_col(const f32x4& v, ah4& hi, ah4& lo) {
 // a column agree on it with two shuffles; returned).  A column of the B operand scales the same column of the product, which is on the same lanes:
 // the caller divides it out of the zero-initialised product that consumes the tile.
 __device__ __forceinline__ float tile_split(const f32x4& t, ah4& hi, ah4& lo, float& inv) {
-    float m = fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3])));
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
+    const float m = col4_max(fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3]))));
     const float sc = pow2_scale(m, inv);
     attn_split4(t[0] * sc, t[1] * sc, t[2] * sc, t[3] * sc, hi, lo);
     return sc;
@@ -220,7 +250,9 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_h_kernel(const AttnArgs p) {
     const float c0 = p.scale * LOG2E / sc[0];
     const float oinv = 1.0f / sc[1];                                   // O = (2^13 sV O) / (sV 2^13 l)
     const int nkt = Lkp >> 4, tail = (p.Lk & 15) ? nkt - 1 : nkt;      // key tile with padded keys (only that one is masked)
-    for (int jt = wave; jt < ((p.Lq + 15) >> 4); jt += 4) {
+    // 13 query tiles over 4 waves = 4 + 3 + 3 + 3: the wave with the extra tile rotates from workgroup to workgroup, or SIMD 0 (wave 0 of every
+    // resident workgroup) carries a third more than the others
+    for (int jt = (wave + blockIdx.x) & 3; jt < ((p.Lq + 15) >> 4); jt += 4) {
         const int j = 16 * jt + r16;
         const bool jl = j < p.Lq;
         ah4 qh, ql;
@@ -241,9 +273,7 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_h_kernel(const AttnArgs p) {
                 for (int r = 0; r < 4; ++r)
                     if (16 * it + 4 * g + r >= p.Lk) s[r] = -INFINITY;
             }
-            float tmax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float tmax = col4_max(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
             const float mn = fmaxf(mr, tmax);                      // finite from the first tile on (Lk >= 1)
             const float alpha = __builtin_amdgcn_exp2f((mr - mn) * c);
             const float nb = __builtin_fmaf(-mn, c, AH_PLOG);      // probabilities come out times 2^13 (the split's scale); l carries the same factor
@@ -261,8 +291,7 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_h_kernel(const AttnArgs p) {
         };
         for (int it = 0; it < tail; ++it) key_tile(it, std::false_type{});
         if (tail < nkt) key_tile(tail, std::true_type{});
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        l = col4_sum(l);
         if (jl) {
             const float inv = oinv / l;
             float* dst = p.out + ((long long)b * p.Lq + j) * p.ldout + h * p.hs + 4 * g;
@@ -295,7 +324,7 @@ __global__ __launch_bounds__(256) void dts_attn_dq_h_kernel(const AttnArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
     const float c0 = p.scale * LOG2E / sc[0];
     const float kinv = 1.0f / sc[0];
-    for (int jt = wave; jt < ((p.Lq + 15) >> 4); jt += 4) {
+    for (int jt = (wave + blockIdx.x) & 3; jt < ((p.Lq + 15) >> 4); jt += 4) {      // (rotated: see the forward kernel)
         const int j = 16 * jt + r16;
         const bool jl = j < p.Lq;
         ah4 qh, ql, dh, dl;
@@ -305,8 +334,7 @@ __global__ __launch_bounds__(256) void dts_attn_dq_h_kernel(const AttnArgs p) {
         const f32x4 dov = *reinterpret_cast<const f32x4*>(Db + (long long)(jl ? j : 0) * p.ldo + 4 * g);
         const f32x4 ov = *reinterpret_cast<const f32x4*>(p.O + ((long long)b * p.Lq + (jl ? j : 0)) * p.ldo + h * p.hs + 4 * g);
         float del = (dov[0] * ov[0] + dov[1] * ov[1]) + (dov[2] * ov[2] + dov[3] * ov[3]);
-        del += __shfl_xor(del, 16);
-        del += __shfl_xor(del, 32);
+        del = col4_sum(del);
         if (jl && g == 0) const_cast<float*>(p.delta)[((long long)b * p.H + h) * p.Lq + j] = del;
         const float dpinv = 1.0f / (sc[1] * split_col(dov, dh, dl));      // V . dO comes out times sV sdO(query)
         const float lse = p.lse[((long long)b * p.H + h) * p.Lq + (jl ? j : 0)];
@@ -376,7 +404,7 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_h_kernel(const AttnArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
     const float c0 = p.scale * LOG2E / sc[0];
     const float dvinv = 1.0f / (sc[1] * AH_PSCALE), qinv = 1.0f / sc[0], pscale = p.scale / AH_PSCALE;
-    for (int jt = wave; jt < ((p.Lk + 15) >> 4); jt += 4) {
+    for (int jt = (wave + blockIdx.x) & 3; jt < ((p.Lk + 15) >> 4); jt += 4) {      // (rotated: see the forward kernel)
         const int j = 16 * jt + r16;                                  // key
         const bool jl = j < p.Lk;
         ah4 kh, kl, vh, vl;
@@ -416,6 +444,217 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_h_kernel(const AttnArgs p) {
         if (jl) {
             *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lk + j) * p.ldout + h * p.hs + 4 * g) = dk;
             *reinterpret_cast<f32x4*>(p.out2 + ((long long)b * p.Lk + j) * p.ldout2 + h * p.hs + 4 * g) = dv * dvinv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: dQ, dK and dV in ONE pass.  The two-pass backward (dts_attn_dq_h_kernel + dts_attn_dkv_h_kernel) forms S, P, dP and dS of every
+// (query tile, key tile) pair twice -- 101 + 127 vector instructions per pair, and reads Q / K / V / dO / O twice.  This kernel is the dK-dV pass
+// (a wave owns key tiles, loops over the query tiles; S, dS in layout [query 4 g + r][key r16]) that ALSO forms the pair's contribution to dQ:
+// dQ^T[d][q] += sum_key K^T[d][key] dS[q][key] contracts over the key, which sits on the lanes of the dS tile, so the fp32 tile goes through a
+// 16 x 16 per-wave LDS scratch (four ds_write_b32 + one ds_read_b128 per lane: lane (q r16, g) gets dS[q][keys 4 g ..] = the B operand) and is split
+// there with ONE power of two per tile (the smallest of the tile's per-key column scales of the dK product: a 16-lane DPP row reduction on the
+// exponent bits); A = K^T of the wave's key tile [d = r16][keys 4 g ..], loaded once per key tile with its own per-tile power of two.  The
+// partial dQ^T tiles of a wave's key tiles wait in registers (AH_MAXT x 4: the query-tile loop is unrolled) and are added over the four key-tile
+// residue classes in class order through LDS at the end -- a fixed order, so the result is bitwise repeatable and independent of the batch a
+// sequence runs in.  delta = dO . O is formed while dO is staged.  About 160 instructions per pair instead of 228; one pass over the operands.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int AH_MAXT = 16;          // query tiles of a head tile (<= 256 tokens: attn()'s bound for the split-f16 kernels)
+constexpr int AH_SCR = 20;           // floats per row of the transposition scratch: 80-byte rows, conflict-free b32 writes and b128 reads
+constexpr int AH_XT = 4;             // query tiles per round of the final dQ exchange ([AH_XT][3][4][64] floats of LDS)
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+// min / max over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1) of POSITIVE floats, on their bit patterns (no NaN canonicalisation)
+__device__ __forceinline__ float row16_min_pos(float v) {
+    int x = __float_as_int(v);
+    x = min(x, dpp_i<0x128>(x)); x = min(x, dpp_i<0x124>(x)); x = min(x, dpp_i<0x122>(x)); x = min(x, dpp_i<0x121>(x));
+    return __int_as_float(x);
+}
+__device__ __forceinline__ float row16_max_pos(float v) {
+    int x = __float_as_int(v);
+    x = max(x, dpp_i<0x128>(x)); x = max(x, dpp_i<0x124>(x)); x = max(x, dpp_i<0x122>(x)); x = max(x, dpp_i<0x121>(x));
+    return __int_as_float(x);
+}
+
+inline size_t attn_bwd_h_lds(int Lq) {
+    const size_t Lqp = (size_t)((Lq + 15) & ~15);
+    const size_t main_bytes = sizeof(_Float16) * 4 * Lqp * AH_RS + sizeof(float) * (2 * Lqp + 8 + 4 * 2 * 16 * AH_SCR);
+    const size_t xchg_bytes = sizeof(float) * AH_XT * 3 * 4 * 64;
+    return (main_bytes > xchg_bytes ? main_bytes : xchg_bytes) + 64;
+}
+
+#ifndef DTS_BWD_WAVES
+#define DTS_BWD_WAVES 2              // waves per SIMD the register allocator is held to (2: <= 256 VGPRs, no spills; 3: <= 168 VGPRs, 61 spilled at NT = 13)
+#endif
+// NT: compile-time bound on the query tiles (the dQ partials dq[NT] must be statically indexed: the query-tile loop is unrolled)
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DTS_BWD_WAVES))) void dts_attn_bwd_h_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+    const int Lqp = (p.Lq + 15) & ~15;
+    _Float16* Qh = reinterpret_cast<_Float16*>(ldsb);      // [Lqp][AH_RS]
+    _Float16* Ql = Qh + Lqp * AH_RS;
+    _Float16* Dh = Ql + Lqp * AH_RS;                       // dO
+    _Float16* Dl = Dh + Lqp * AH_RS;
+    float* lsel = reinterpret_cast<float*>(Dl + Lqp * AH_RS);    // [Lqp]
+    float* dell = lsel + Lqp;                              // [Lqp]
+    float* red = dell + Lqp;                               // [4][2]
+    float* scr = red + 8;                                  // [4 waves][2][16][AH_SCR]
+    const float* Kb = p.K + (long long)b * p.Lk * p.ldk + h * p.hs;
+    const float* Vb = p.V + (long long)b * p.Lk * p.ldv + h * p.hs;
+    float mx[2], sc[2];
+    {
+        HeadRegs qr, dr;
+        mx[0] = head_load(p.Q + (long long)b * p.Lq * p.ldq + h * p.hs, p.ldq, p.Lq, Lqp, qr);
+        mx[1] = head_load(p.dO + (long long)b * p.Lq * p.ldo + h * p.hs, p.ldo, p.Lq, Lqp, dr);
+        // delta[q] = dO[q] . O[q]: the four threads of a row hold its four column quads (the association of the two-pass kernels: bitwise equal)
+#pragma unroll
+        for (int u = 0; u < AH_MAXQ; ++u) {
+            const int i = threadIdx.x + 256 * u, r = i >> 2, d = 4 * (i & 3);
+            float part = 0.0f;
+            if (i < Lqp * 4 && r < p.Lq) {
+                const f32x4 ov = *reinterpret_cast<const f32x4*>(p.O + ((long long)b * p.Lq + r) * p.ldo + h * p.hs + d);
+                part = (dr.v[u][0] * ov[0] + dr.v[u][1] * ov[1]) + (dr.v[u][2] * ov[2] + dr.v[u][3] * ov[3]);
+            }
+            part += __shfl_xor(part, 1);
+            part += __shfl_xor(part, 2);
+            if (i < Lqp * 4 && (i & 3) == 0) dell[r] = part;
+        }
+        wg_scales<2>(mx, red, sc);
+        head_store(qr, sc[0], Lqp, Qh, Ql, nullptr, nullptr);
+        head_store(dr, sc[1], Lqp, Dh, Dl, nullptr, nullptr);
+    }
+    for (int i = threadIdx.x; i < Lqp; i += 256) lsel[i] = i < p.Lq ? p.lse[((long long)b * p.H + h) * p.Lq + i] : INFINITY;     // padded queries: P = 0
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    // key tiles by residue class: class vw = jt & 3 belongs to wave (vw - blockIdx) & 3 -- the class with the extra tile rotates over the SIMDs from
+    // workgroup to workgroup, while sums are formed per CLASS, so the arithmetic does not depend on the rotation
+    const int vw = (wave + blockIdx.x) & 3;
+    const float c0 = p.scale * LOG2E / sc[0];
+    const float dvinv = 1.0f / (sc[1] * AH_PSCALE), qinv = 1.0f / sc[0], pscale = p.scale / AH_PSCALE;
+    const int nqt = Lqp >> 4, nkt = (p.Lk + 15) >> 4;
+    float* myscr = scr + wave * 2 * 16 * AH_SCR;
+    float* scr_w = myscr + (4 * g) * AH_SCR + r16;                     // this lane's first write slot: dS[query 4 g + r][key r16]
+    const float* scr_r = myscr + r16 * AH_SCR + 4 * g;                 // ... and its read: dS[query r16][keys 4 g ..]
+    f32x4 dq[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dq[t] = f32x4{0, 0, 0, 0};
+    for (int jt = vw; jt < nkt; jt += 4) {
+        const int j = 16 * jt + r16;                                  // key
+        const bool jl = j < p.Lk;
+        ah4 kh, kl, vh, vl;
+        const float c = c0 / load_split_col(Kb + (long long)(jl ? j : 0) * p.ldk + 4 * g, kh, kl);
+        const float dpinv = 1.0f / (sc[1] * load_split_col(Vb + (long long)(jl ? j : 0) * p.ldv + 4 * g, vh, vl));
+        // K^T of the tile, [d = r16][keys 16 jt + 4 g ..], one power of two for the tile
+        float kt[4], km = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = 16 * jt + 4 * g + e;
+            kt[e] = key < p.Lk ? Kb[(long long)key * p.ldk + r16] : 0.0f;
+            km = fmaxf(km, fabsf(kt[e]));
+        }
+        float ktinv;
+        const float ksc = pow2_scale(wave_max(km), ktinv);
+        ah4 kth, ktl;
+        attn_split4(kt[0] * ksc, kt[1] * ksc, kt[2] * ksc, kt[3] * ksc, kth, ktl);
+        f32x4 dk = {0, 0, 0, 0}, dv = {0, 0, 0, 0};
+        const int plane = Lqp * AH_RS;                                 // Qh -> Ql -> Dh -> Dl are consecutive planes
+        const _Float16* qp = Qh + r16 * AH_RS + 4 * g;                 // row reads: query 16 it + r16, head columns 4 g ..
+        const _Float16* qc = Qh + (4 * g + (r16 >> 2)) * AH_RS + 4 * (r16 & 3);      // transposed reads of the query block 16 it + 4 g ..: this lane's address
+        // The dQ product of a pair runs ONE query tile behind the rest: the transposed tile is read back from the scratch at the top of the next step,
+        // with that step's other LDS reads, so the write -> read round trip is off the dependency chain (two scratch tiles per wave, alternating).
+        float tsc_prev = 1.0f, tinv_prev = 1.0f;
+        auto dq_step = [&](const f32x4& dst, f32x4& acc) {
+            ah4 th, tl;
+            attn_split4(dst[0] * tsc_prev, dst[1] * tsc_prev, dst[2] * tsc_prev, dst[3] * tsc_prev, th, tl);
+            f32x4 pq = {0, 0, 0, 0};
+            DTS_MMH3(pq, kth, ktl, th, tl);                             // sKt sT dQ^T[d 4 g + r][query r16]
+            acc += pq * (ktinv * tinv_prev);
+        };
+#pragma unroll
+        for (int it = 0; it <= NT; ++it) {
+            if (it < NT && it < nqt) {
+                const _Float16* qrow = qp + 16 * AH_RS * it;
+                const ah4 qh = *reinterpret_cast<const ah4*>(qrow), ql = *reinterpret_cast<const ah4*>(qrow + plane);
+                const ah4 dh = *reinterpret_cast<const ah4*>(qrow + 2 * plane), dl = *reinterpret_cast<const ah4*>(qrow + 3 * plane);
+                f32x4 dprev = {0, 0, 0, 0};
+                if (it > 0) dprev = *reinterpret_cast<const f32x4*>(scr_r + ((it - 1) & 1) * 16 * AH_SCR);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsel + 16 * it + 4 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dell + 16 * it + 4 * g);
+                const _Float16* qq = qc + 16 * AH_RS * it;
+                const ah4 qth = column4_tr(qq), qtl = column4_tr(qq + plane);
+                const ah4 dth = column4_tr(qq + 2 * plane), dtl = column4_tr(qq + 3 * plane);                  // sdO dO^T[d = r16][queries 4 g ..]
+                f32x4 s = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
+                DTS_MMH3(s, qh, ql, kh, kl);                                // sQ sK S[query 4 g + r][key r16]
+                DTS_MMH3(t2, dh, dl, vh, vl);
+                f32x4 pr, ds;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pr[r] = __builtin_amdgcn_exp2f(s[r] * c - (l4[r] - AH_PLOG));        // 2^13 P
+                    ds[r] = pr[r] * (t2[r] * dpinv - d4[r]) * pscale;
+                }
+                if (!jl) ds = f32x4{0, 0, 0, 0};                            // a padded key column (its dK / dV are never stored) must not reach dQ
+                float* sw = scr_w + (it & 1) * 16 * AH_SCR;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sw[r * AH_SCR] = ds[r];
+                ah4 ph, pl, sh, sl;
+                attn_split4(pr[0], pr[1], pr[2], pr[3], ph, pl);
+                float issc;
+                const float csc = tile_split(ds, sh, sl, issc);
+                DTS_MMH3(dv, dth, dtl, ph, pl);
+                f32x4 part = {0, 0, 0, 0};
+                DTS_MMH3(part, qth, qtl, sh, sl);
+                dk += part * (qinv * issc);
+                if (it > 0) dq_step(dprev, dq[it > 0 ? it - 1 : 0]);
+                tsc_prev = row16_min_pos(csc);                              // one power of two for the transposed tile: the smallest column scale
+                tinv_prev = row16_max_pos(issc);
+            } else if (it > 0 && it == nqt) {                               // the last tile's dQ product
+                const f32x4 dprev = *reinterpret_cast<const f32x4*>(scr_r + ((it - 1) & 1) * 16 * AH_SCR);
+                dq_step(dprev, dq[it > 0 ? it - 1 : 0]);
+            }
+        }
+        if (jl) {
+            *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lk + j) * p.ldout + h * p.hs + 4 * g) = dk;
+            *reinterpret_cast<f32x4*>(p.out2 + ((long long)b * p.Lk + j) * p.ldout2 + h * p.hs + 4 * g) = dv * dvinv;
+        }
+    }
+    // dQ tile t = sum over the key-tile classes 0..3 in that order; class t & 3 collects it
+    __syncthreads();
+    float* xb = reinterpret_cast<float*>(ldsb);                            // [AH_XT][3][4][64]
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += AH_XT) {
+        if (t0 < nqt) {
+#pragma unroll
+            for (int tt = 0; tt < AH_XT; ++tt) {
+                const int t = t0 + tt, owner = t & 3;
+                if (t < NT && t < nqt && vw != owner) {
+                    float* dst = xb + ((tt * 3 + ((vw - owner - 1) & 3)) * 4) * 64 + lane;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[r * 64] = dq[t < NT ? t : 0][r];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tt = 0; tt < AH_XT; ++tt) {
+                const int t = t0 + tt, owner = t & 3;
+                if (t < NT && t < nqt && vw == owner) {
+                    f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        if (w == owner) {
+                            acc += dq[t < NT ? t : 0];
+                        } else {
+                            const float* src = xb + ((tt * 3 + ((w - owner - 1) & 3)) * 4) * 64 + lane;
+                            acc += f32x4{src[0], src[64], src[128], src[192]};
+                        }
+                    }
+                    const int q = 16 * t + r16;
+                    if (q < p.Lq) *reinterpret_cast<f32x4*>(p.out3 + ((long long)b * p.Lq + q) * p.ldout3 + h * p.hs + 4 * g) = acc;
+                }
+            }
+            __syncthreads();
         }
     }
 }

@@ -435,7 +435,9 @@ struct AttnArgs {
     int H, Lq, Lk, hd;
     float scale;
     long long hs;                                   // offset of head h's columns: h * hs floats.  Row-major token rows [rows][H hd]: hs = hd, ld = the row
-};                                                  // width; 16-column BLOCKED buffers [block][rows][16] (dts.hip): hs = rows * 16, every ld = 16
+                                                    // width; 16-column BLOCKED buffers [block][rows][16] (dts.hip): hs = rows * 16, every ld = 16
+    float* out3 = nullptr; int ldout3 = 0;          // merged backward (dts_attn_bwd_h_kernel): dQ (out = dK, out2 = dV)
+};
 
 template <int E>
 __device__ __forceinline__ void load_frag(const float* p, float (&f)[E]) {
