@@ -431,8 +431,22 @@ typedef struct mpv_nst_desc {
     int32_t p_hidden[4];              /* p_hidden_dims */
     int32_t latent;                   /* 1: TMDM prior (encoder output -> z_mean -> z_out -> decoder) */
     int32_t pe_rows;                  /* rows of the two position tables passed */
+    int32_t fT_h;                     /* ABI v3.  > 0 (even): Model_spatial -- the encoder output goes through Conv2d(D, D, (1, seq_len + 1),
+                                         pad fT_h / 2) to fT_h steps, `spatial_layers` x relu(ResGatedGraphConv(fT_h D -> fT_h D)) over the graph of
+                                         mpv_nst_set_graph, and ConvTranspose2d back to seq_len steps before the decoder cross-attends to it
+                                         (NsDiff/mu_backbone.py:186-340, called at NsDiff_model.py:744).  0: the plain Model.               */
+    int32_t spatial_layers;
 } mpv_nst_desc;
+/* With fT_h > 0 the tensor list continues: downsampling.{weight [D][D][1][seq_len+1], bias [D]}; per spatial layer spatial_encoder.N.gnn.
+ * {lin_key,lin_query,lin_value}.{weight [C][C], bias [C]}, lin_skip.weight [C][C], bias [C] (C = fT_h D; torch_geometric's ResGatedGraphConv
+ * parameter names: the package is absent, the layer is restated -- unpinned like the rest of f(x)); upsampling.{weight [D][D][1][seq_len+1]
+ * (ConvTranspose2d: [in][out]), bias [D]}. */
 int mpv_nst_load(mpv_ctx* ctx, const mpv_nst_desc* desc, const float* const* tensors, int32_t n_tensors);
+
+/* Model_spatial only: the graph its convolutions run over -- replaces the `edge_index` argument of Model_spatial.forward (mu_backbone.py:296).
+ * edge_src / edge_dst: host [n_edges] (edge_index[0] = source j, edge_index[1] = target i).  Every window of an mpv_nst_forward call is one
+ * copy of this graph: `nodes` there must equal n_nodes. */
+int mpv_nst_set_graph(mpv_ctx* ctx, int32_t n_nodes, int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst);
 
 /* series: dev [nodes][series_len][F]; window w covers [first + w*step, +seq_len) of every node; mean/std: dev [F] scaler fused into
  * the load or both NULL.  y0hat: dev [n_windows*nodes][pred_len][F] (full = 0: the reference's first return value) or
@@ -444,7 +458,8 @@ int mpv_nst_forward(mpv_ctx* ctx, const float* series, int32_t nodes, int64_t se
                     const float* mean, const float* std, int32_t full, int32_t gemm, int64_t rows_per_pass, float* y0hat);
 
 /* Validation helper: intermediate of the LAST pass of the last mpv_nst_forward call.  which: 0 normalised window [B][S][F],
- * 1 statistics [B][2][F] (mean, std), 2 tau [B], 3 delta [B][S], 4 encoder output [B][S][D]. */
+ * 1 statistics [B][2][F] (mean, std), 2 tau [B], 3 delta [B][S], 4 what the decoder cross-attends to [B][S][D] (the encoder output; after the
+ * latent bottleneck / the spatial stage when present), 5 (Model_spatial) the features after the last graph convolution [B][fT_h][D]. */
 int mpv_nst_debug_tensor(mpv_ctx* ctx, int32_t which, float* out_dev, int64_t capacity);
 
 /* The single-series generator of the SLBP sensitivity data sets (shallow-lake bream X / pike Y; dataset/SLBP_dynamic_gene.py:26-58, parameter

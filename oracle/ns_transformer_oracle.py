@@ -148,6 +148,62 @@ def forward(sd: Tensors, cfg, x_enc: torch.Tensor, latent: bool = False) -> Tupl
     return dec[:, -cfg.pred_len:, :], dec
 
 
+def spatial_stage(sd: Tensors, cfg, enc: torch.Tensor, edge_index: torch.Tensor, return_features: bool = False):
+    """Model_spatial.forward between encoder and decoder (NsDiff/mu_backbone.py:312-325, the reference's own lines): Conv2d(D, D, (1, T + 1),
+    padding (0, fT_h // 2)) along time, reshape to [rows, fT_h * D], `spatial_layers` x relu(gnn(x, edge_index)), ConvTranspose2d back.
+    The graph convolution is torch_geometric's ResGatedGraphConv (models/layer/gnn_conv.py:18-19; package absent): the restatement of
+    oracle/diffstg_oracle.py, unpinned.  enc [rows, S, D], rows = whole graphs (edge_index addresses rows)."""
+    from oracle.diffstg_oracle import res_gated_graph_conv
+    p = cfg.fT_h // 2
+    h = enc.unsqueeze(2).transpose(1, 3)                                                       # [rows, D, 1, S]
+    h = F.conv2d(h, sd["downsampling.weight"], sd["downsampling.bias"], padding=(0, p)).transpose(1, 3).squeeze(2)      # [rows, fT_h, D]
+    s = h.reshape(h.shape[0], -1)
+    for i in range(cfg.spatial_layers):
+        s = torch.relu(res_gated_graph_conv(sd, "spatial_encoder.{}.gnn.".format(i), s, edge_index))
+    feat = s.reshape(h.shape[0], cfg.fT_h, -1)
+    u = feat.unsqueeze(2).transpose(1, 3)                                                      # [rows, D, 1, fT_h]
+    out = F.conv_transpose2d(u, sd["upsampling.weight"], sd["upsampling.bias"], padding=(0, p)).transpose(1, 3).squeeze(2)   # [rows, S, D]
+    return (out, feat) if return_features else out
+
+
+def forward_spatial(sd: Tensors, cfg, x_enc: torch.Tensor, edge_index: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Model_spatial.forward (NsDiff/mu_backbone.py:296-340): `forward` with the spatial stage between encoder and decoder.  x_enc [V, seq_len, F]
+    = the nodes of ONE graph, edge_index [2, E] (row 0 source, row 1 target).  PARITY UNPINNED like `forward`, plus the graph convolution."""
+    x_raw = x_enc
+    mean = x_enc.mean(1, keepdim=True)
+    x = x_enc - mean
+    std = torch.sqrt(torch.var(x, dim=1, keepdim=True, unbiased=False) + 1e-5)
+    x = x / std
+    x_dec = torch.cat([x[:, -cfg.label_len:, :], torch.zeros(x.shape[0], cfg.pred_len, x.shape[2], dtype=x.dtype)], dim=1)
+    tau = projector(sd, "tau_learner.", cfg.p_hidden_layers, x_raw, std).exp()
+    delta = projector(sd, "delta_learner.", cfg.p_hidden_layers, x_raw, mean)
+    enc = encoder(sd, "encoder.", cfg, data_embedding(sd, "enc_embedding.", x), tau, delta)
+    enc = spatial_stage(sd, cfg, enc, edge_index)
+    dec = decoder(sd, "decoder.", cfg, data_embedding(sd, "dec_embedding.", x_dec), enc, tau, delta)
+    dec = dec * std + mean
+    return dec[:, -cfg.pred_len:, :], dec
+
+
+def random_spatial_state(cfg, seed: int, max_len: int = 5000) -> Dict[str, torch.Tensor]:
+    """`random_state` + the spatial stage's tensors under the reference's names (downsampling / upsampling: mu_backbone.py:268-275;
+    spatial_encoder.N.gnn.*: torch_geometric's ResGatedGraphConv parameter names)."""
+    sd = random_state(cfg, seed, max_len=max_len)
+    g = torch.Generator().manual_seed(seed + 7919)
+    D, C, K = cfg.d_model, cfg.fT_h * cfg.d_model, cfg.seq_len + 1
+    sd["downsampling.weight"] = torch.randn(D, D, 1, K, generator=g) / math.sqrt(D * K)
+    sd["downsampling.bias"] = 0.05 * torch.randn(D, generator=g)
+    for i in range(cfg.spatial_layers):
+        p = "spatial_encoder.{}.gnn.".format(i)
+        for nm in ("lin_key", "lin_query", "lin_value"):
+            sd[p + nm + ".weight"] = torch.randn(C, C, generator=g) / math.sqrt(C)
+            sd[p + nm + ".bias"] = 0.05 * torch.randn(C, generator=g)
+        sd[p + "lin_skip.weight"] = torch.randn(C, C, generator=g) / math.sqrt(C)
+        sd[p + "bias"] = 0.05 * torch.randn(C, generator=g)
+    sd["upsampling.weight"] = torch.randn(D, D, 1, K, generator=g) / math.sqrt(D * cfg.fT_h)
+    sd["upsampling.bias"] = 0.05 * torch.randn(D, generator=g)
+    return sd
+
+
 def intermediates(sd: Tensors, cfg, x_enc: torch.Tensor) -> Dict[str, torch.Tensor]:
     """Stage outputs for kernel-by-kernel checks."""
     mean = x_enc.mean(1, keepdim=True)
@@ -229,8 +285,9 @@ def random_state(cfg, seed: int, latent: bool = False, max_len: int = 5000) -> D
 
 
 def config(dataset_nf=1, windows=100, pred_len=100, d_model=512, n_heads=8, d_ff=256, e_layers=4, d_layers=2,
-           activation="gelu", p_hidden_dims=(64, 64), p_hidden_layers=2) -> SimpleNamespace:
-    """The shipped `task_model: NsDiff` YAMLs' f(x) hyper-parameters (ews_results/NsDiff_dataset/*/model_trained.yaml)."""
-    return SimpleNamespace(dataset_nf=dataset_nf, seq_len=windows, label_len=windows // 2, pred_len=pred_len, d_model=d_model,
+           activation="gelu", p_hidden_dims=(64, 64), p_hidden_layers=2, fT_h=0, spatial_layers=0) -> SimpleNamespace:
+    """The shipped `task_model: NsDiff` YAMLs' f(x) hyper-parameters (ews_results/NsDiff_dataset/*/model_trained.yaml); fT_h / spatial_layers:
+    Model_spatial's (no shipped YAML names them)."""
+    return SimpleNamespace(dataset_nf=dataset_nf, seq_len=windows, windows=windows, label_len=windows // 2, pred_len=pred_len, d_model=d_model,
                            n_heads=n_heads, d_ff=d_ff, e_layers=e_layers, d_layers=d_layers, activation=activation,
-                           p_hidden_dims=list(p_hidden_dims), p_hidden_layers=p_hidden_layers)
+                           p_hidden_dims=list(p_hidden_dims), p_hidden_layers=p_hidden_layers, fT_h=fT_h, spatial_layers=spatial_layers)

@@ -28,7 +28,7 @@ EXPORTS = (
     "mpv_stg_load", "mpv_stg_set_graph", "mpv_stg_forward", "mpv_stg_sample",
     "mpv_nss_load", "mpv_nss_set_graph", "mpv_nss_forward", "mpv_nss_sample",
     "mpv_biomass_simulate", "mpv_network_sde_simulate", "mpv_dts_load", "mpv_dts_forward", "mpv_dts_vjp", "mpv_dts_debug_tensor", "mpv_dts_sample",
-    "mpv_nst_load", "mpv_nst_forward", "mpv_nst_debug_tensor", "mpv_slbp_simulate",
+    "mpv_nst_load", "mpv_nst_set_graph", "mpv_nst_forward", "mpv_nst_debug_tensor", "mpv_slbp_simulate",
 )
 
 
@@ -96,7 +96,8 @@ class NssSampleShape(C.Structure):
 
 class NstDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("enc_in", "c_out", "seq_len", "label_len", "pred_len", "d_model", "n_heads", "d_ff", "e_layers", "d_layers",
-                                          "activation", "p_layers")] + [("p_hidden", C.c_int32 * 4), ("latent", C.c_int32), ("pe_rows", C.c_int32)]
+                                          "activation", "p_layers")] + [("p_hidden", C.c_int32 * 4), ("latent", C.c_int32), ("pe_rows", C.c_int32),
+                                                                   ("fT_h", C.c_int32), ("spatial_layers", C.c_int32)]
 
 
 class SigmaDesc(C.Structure):
@@ -177,6 +178,7 @@ def load_library():
         "mpv_dts_debug_tensor": (C.c_int, [vp, C.c_char_p, i32, vp, i64]),
         "mpv_dts_sample": (C.c_int, [vp, C.POINTER(DtsSampleShape), vp, _F, vp, vp]),
         "mpv_nst_load": (C.c_int, [vp, C.POINTER(NstDesc), C.POINTER(_F), i32]),
+        "mpv_nst_set_graph": (C.c_int, [vp, i32, i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
         "mpv_nst_forward": (C.c_int, [vp, vp, i32, i64, i32, i64, i64, vp, vp, i32, i32, i64, vp]),
         "mpv_nst_debug_tensor": (C.c_int, [vp, i32, vp, i64]),
         "mpv_chain_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i64)]),
@@ -484,6 +486,21 @@ class Context:
         arr = (_F * len(keep))(*[_fptr(t) for t in keep])
         self._check(self.lib.mpv_nst_load(self._h, C.byref(d), arr, len(keep)), "mpv_nst_load")
         self.nst = d
+        self._nst_graph = None
+
+    def nst_set_graph(self, edge_index: torch.Tensor, num_nodes: int):
+        """Model_spatial: the graph of the spatial stage (edge_index [2, E]: row 0 = source, row 1 = target); kept until the next load."""
+        if self.nst is None:
+            raise MpvError("f(x) weights not loaded")
+        e = torch.as_tensor(edge_index).detach().to("cpu", torch.int64).reshape(2, -1).contiguous()
+        key = (int(num_nodes), e.shape[1], hash(e.numpy().tobytes()))
+        if getattr(self, "_nst_graph", None) == key:
+            return
+        src, dst = e[0].contiguous(), e[1].contiguous()
+        P64 = C.POINTER(C.c_int64)
+        self._check(self.lib.mpv_nst_set_graph(self._h, int(num_nodes), e.shape[1], C.cast(src.data_ptr(), P64), C.cast(dst.data_ptr(), P64)),
+                    "mpv_nst_set_graph")
+        self._nst_graph = key
 
     def nst_forward(self, series: torch.Tensor, n_windows: int, first: int = 0, step: int = 1, mean: Optional[torch.Tensor] = None,
                     std: Optional[torch.Tensor] = None, full: bool = False, rows_per_pass: int = 0, gemm: str = "f16x3") -> torch.Tensor:
@@ -509,7 +526,7 @@ class Context:
         """Intermediate of the last pass (validation): 'x_norm', 'stats', 'tau', 'delta', 'enc_out'; rows = window rows of that pass."""
         d = self.nst
         ids = {"x_norm": (0, (rows, d.seq_len, d.enc_in)), "stats": (1, (rows, 2, d.enc_in)), "tau": (2, (rows,)), "delta": (3, (rows, d.seq_len)),
-               "enc_out": (4, (rows, d.seq_len, d.d_model))}
+               "enc_out": (4, (rows, d.seq_len, d.d_model)), "spatial": (5, (rows, max(1, d.fT_h), d.d_model))}
         idx, shape = ids[which]
         out = torch.empty(shape, device=self.device, dtype=torch.float32)
         self._bind_stream()

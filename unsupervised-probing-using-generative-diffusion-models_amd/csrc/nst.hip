@@ -453,6 +453,32 @@ __global__ __launch_bounds__(256) void nst_head_kernel(const HeadArgs p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // engine
 // ---------------------------------------------------------------------------------------------------------------------
+// ResGatedGraphConv aggregation + ReLU (SpatialBlock.forward, mu_backbone.py:43-51; torch_geometric's published definition, restated:
+// out_i = W_skip x_i + sum_{j -> i} sigmoid(W_k x_i + W_q x_j) * W_v x_j + bias).  kqvs [rows][4C] = key | query | value | skip; rows = consecutive
+// blocks of V nodes (one block per window); incoming edges of a node in edge order = the index_add_ order of the reference.
+__global__ __launch_bounds__(256) void nst_gate_kernel(const float* __restrict__ kqvs, const float* __restrict__ bias, const int* __restrict__ row_ptr,
+                                                        const int* __restrict__ col_idx, int V, int C4, long long n4, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // row * C/4 + channel quad
+    if (i >= n4) return;
+    const int cq = (int)(i % C4), C = 4 * C4;
+    const long long row = i / C4;
+    const int v = (int)(row % V);
+    const long long base = row - v;                                             // first row of this window's graph
+    const v4f k = *reinterpret_cast<const v4f*>(kqvs + row * 4 * C + 4 * cq);
+    v4f a = {0, 0, 0, 0};
+    for (int e = row_ptr[v]; e < row_ptr[v + 1]; ++e) {
+        const float* src = kqvs + (base + col_idx[e]) * 4 * C + 4 * cq;
+        const v4f q = *reinterpret_cast<const v4f*>(src + C), val = *reinterpret_cast<const v4f*>(src + 2 * C);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] += val[c] / (1.0f + __expf(-(k[c] + q[c])));
+    }
+    const v4f skip = *reinterpret_cast<const v4f*>(kqvs + row * 4 * C + 3 * C + 4 * cq), b = *reinterpret_cast<const v4f*>(bias + 4 * cq);
+    v4f o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = fmaxf((a[c] + skip[c]) + b[c], 0.0f);
+    *reinterpret_cast<v4f*>(out + row * C + 4 * cq) = o;
+}
+
 struct Mat {                                                 // one Linear weight [N][K]: fp32, and its scaled two-term f16 split
     const float* w = nullptr;
     const _Float16* h = nullptr;
@@ -465,6 +491,9 @@ struct FfnW { Mat w1; const float* b1; Mat w2; const float* b2; };
 struct NormW { const float *w, *b; };
 struct EncLayer { AttnW att; FfnW ffn; NormW n1, n2; };
 struct DecLayer { AttnW self, cross; FfnW ffn; NormW n1, n2, n3; };
+// Model_spatial (NsDiff/mu_backbone.py:186-340): one gated graph convolution over the fT_h x d_model features of a (window, node) row --
+// the four Linear maps as ONE [4C][C] product (key | query | value | skip; the skip map has no bias), then the gather over incoming edges
+struct SpatialLayer { Mat w4; const float* b4; const float* bias; };
 
 struct NstEngine {
     mpv_nst_desc d{};
@@ -477,6 +506,15 @@ struct NstEngine {
     ProjW tau{}, delta{};
     Mat zw[4];
     const float* zb[4] = {};
+    // spatial stage between encoder and decoder (spatial mode: d.fT_h > 0): k = S + 1 convolution along time as a dense [fT_h D] x [S D]
+    // product (its fT_h output steps are shifted copies of the kernel, laid out at load time), graph convolutions, transposed convolution back
+    Mat wdown, wup;
+    const float *bdown = nullptr, *bup = nullptr;             // biases repeated per output step: [fT_h][D], [S][D]
+    std::vector<SpatialLayer> sp;
+    int gV = 0;                                               // the graph (CSR by target node, incoming edges in edge order), mpv_nst_set_graph
+    long long gE = 0;
+    int *row_ptr = nullptr, *col_idx = nullptr;
+    float *sp_a = nullptr, *sp_b = nullptr, *sp_kqvs = nullptr;
     _Float16* blob16 = nullptr;
     int gemm_mode = MPV_GEMM_F16X3;
     float* ws = nullptr;
@@ -493,6 +531,8 @@ void nst_engine_destroy(NstEngine* e) {
     if (e->blob) (void)hipFree(e->blob);
     if (e->blob16) (void)hipFree(e->blob16);
     if (e->ws) (void)hipFree(e->ws);
+    if (e->row_ptr) (void)hipFree(e->row_ptr);
+    if (e->col_idx) (void)hipFree(e->col_idx);
     delete e;
 }
 
@@ -509,7 +549,8 @@ size_t per_row_floats(const mpv_nst_desc& d) {
     return S * F + 2 * F + 1 + S          // xn, stats, tau, delta
            + 2 * S * D + 2 * Ld * D       // ex, ey, dx, dy
            + Lm * 3 * D + S * 2 * D       // qkv (self) ; cross kv shares the tail of the same buffer
-           + Lm * D + Lm * std::max<size_t>(d.d_ff, D) + 64;
+           + Lm * D + Lm * std::max<size_t>(d.d_ff, D) + 64
+           + 6 * (size_t)d.fT_h * D;     // spatial stage: two feature buffers + key | query | value | skip
 }
 
 int carve(mpv_ctx* ctx, NstEngine& e, long long B) {
@@ -521,6 +562,7 @@ int carve(mpv_ctx* ctx, NstEngine& e, long long B) {
     const size_t o_xn = take(B * S * F), o_st = take(B * 2 * F), o_tau = take(B), o_del = take(B * S), o_ex = take(B * S * D), o_ey = take(B * S * D),
                  o_dx = take(B * Ld * D), o_dy = take(B * Ld * D), o_qkv = take(B * (Lm * 3 * D + S * 2 * D)), o_att = take(B * Lm * D),
                  o_hid = take(B * Lm * std::max<size_t>(d.d_ff, D));
+    const size_t C = (size_t)d.fT_h * D, o_spa = take(B * C), o_spb = take(B * C), o_spk = take(B * 4 * C);
     if (total > e.ws_floats) {
         MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (e.ws) (void)hipFree(e.ws);
@@ -532,6 +574,7 @@ int carve(mpv_ctx* ctx, NstEngine& e, long long B) {
     }
     e.xn = e.ws + o_xn; e.stats = e.ws + o_st; e.tau_v = e.ws + o_tau; e.delta_v = e.ws + o_del; e.ex = e.ws + o_ex; e.ey = e.ws + o_ey;
     e.dx = e.ws + o_dx; e.dy = e.ws + o_dy; e.qkv = e.ws + o_qkv; e.att = e.ws + o_att; e.hid = e.ws + o_hid;
+    e.sp_a = e.ws + o_spa; e.sp_b = e.ws + o_spb; e.sp_kqvs = e.ws + o_spk;
     e.cap_b = B;
     return MPV_OK;
 }
@@ -620,6 +663,20 @@ int forward_pass(mpv_ctx* ctx, NstEngine& e, const float* series, int V, long lo
         NST_TRY(gemm(ctx, e, e.ey, D, e.zw[2], 0, e.zb[2], nullptr, 0, e.ex, D, Me, D, 1));
         NST_TRY(gemm(ctx, e, e.ex, D, e.zw[3], 0, e.zb[3], nullptr, 0, e.ey, D, Me, D, 0));
     }
+    if (d.fT_h > 0) {                     // Model_spatial.forward, mu_backbone.py:312-325 (B is a whole number of V-node windows here)
+        const int C = d.fT_h * D;
+        NST_TRY(gemm(ctx, e, enc_out, (long long)S * D, e.wdown, 0, e.bdown, nullptr, 0, e.sp_a, C, B, C, 0));         // downsampling: [B][S D] -> [B][fT_h D]
+        float *cur = e.sp_a, *nxt = e.sp_b;
+        for (const SpatialLayer& l : e.sp) {
+            NST_TRY(gemm(ctx, e, cur, C, l.w4, 0, l.b4, nullptr, 0, e.sp_kqvs, 4 * C, B, 4 * C, 0));
+            const long long n4 = B * (C / 4);
+            hipLaunchKernelGGL(nst_gate_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ctx->stream, e.sp_kqvs, l.bias, e.row_ptr, e.col_idx, e.gV, C / 4, n4, nxt);
+            MPV_HIP_TRY(ctx, hipGetLastError());
+            std::swap(cur, nxt);
+        }
+        NST_TRY(gemm(ctx, e, cur, C, e.wup, 0, e.bup, nullptr, 0, e.ex, (long long)S * D, B, S * D, 0));               // upsampling: -> [B][S D]
+        enc_out = e.ex;
+    }
     // decoder
     {
         EmbedArgs ea{e.xn, e.dec_tok, e.dec_pe, e.dx, S, F, D, Ld, d.label_len, B * Ld};
@@ -666,8 +723,12 @@ int mpv_nst_load(mpv_ctx* ctx, const mpv_nst_desc* d, const float* const* t, int
         if (d->p_hidden[i] < 1 || d->p_hidden[i] > 256) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: projector hidden widths must be in [1, 256]");
     if (2 * F > 256) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: too many features");
     if (d->pe_rows < std::max(S, Ld)) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: position table shorter than the sequences");
+    if (d->fT_h < 0 || d->spatial_layers < 0 || (d->fT_h == 0 && d->spatial_layers > 0) || (d->fT_h % 2) != 0 || d->fT_h > S || (d->fT_h > 0 && d->latent))
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: spatial mode needs an even 0 < fT_h <= seq_len, spatial_layers >= 0 and no latent bottleneck");
+    if (d->fT_h > 0 && (double)d->fT_h * D * (double)S * D > 1.0e9)
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: the dense [fT_h d_model] x [seq_len d_model] image of the k = seq_len + 1 convolution exceeds 1e9 entries");
     const int n_proj = 2 + 2 * d->p_layers;
-    const int expect = 4 + 16 * d->e_layers + 2 + 26 * d->d_layers + 4 + 2 * n_proj + (d->latent ? 8 : 0);
+    const int expect = 4 + 16 * d->e_layers + 2 + 26 * d->d_layers + 4 + 2 * n_proj + (d->latent ? 8 : 0) + (d->fT_h > 0 ? 4 + 8 * d->spatial_layers : 0);
     if (n_tensors != expect) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: expected " + std::to_string(expect) + " tensors, got " + std::to_string(n_tensors));
     for (int i = 0; i < n_tensors; ++i)
         if (!t[i]) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: tensor " + std::to_string(i) + " is NULL");
@@ -773,6 +834,62 @@ int mpv_nst_load(mpv_ctx* ctx, const mpv_nst_desc* d, const float* const* t, int
     size_t o_zb[4] = {};
     if (d->latent)
         for (int i = 0; i < 4; ++i) { o_zw[i] = put_mat(t[k + 2 * i], D, D); o_zb[i] = put(t[k + 2 * i + 1], D); }
+    if (d->latent) k += 8;
+    // spatial stage: downsampling.{weight [D][D][1][S+1], bias}, per layer gnn.{lin_key, lin_query, lin_value}.{weight [C][C], bias}, gnn.lin_skip.weight,
+    // gnn.bias; upsampling.{weight [D][D][1][S+1] (ConvTranspose2d: [in][out]), bias}
+    MatO o_wdown{}, o_wup{};
+    size_t o_bdown = 0, o_bup = 0;
+    struct SpO { MatO w4; size_t b4, bias; };
+    std::vector<SpO> spo(d->fT_h > 0 ? d->spatial_layers : 0);
+    if (d->fT_h > 0) {
+        const int Tn = d->fT_h, pd = Tn / 2, KW = S + 1, C = Tn * D;
+        {
+            const float* w = t[k];                            // Conv2d cross-correlation: out[to] = sum_k w[k] x[to + k - pd]  =>  k = ti - to + pd
+            std::vector<float> m((size_t)C * S * D, 0.0f), b((size_t)C);
+            for (int to = 0; to < Tn; ++to)
+                for (int co = 0; co < D; ++co) {
+                    float* row = &m[((size_t)to * D + co) * S * D];
+                    for (int ti = 0; ti < S; ++ti) {
+                        const int kk = ti - to + pd;
+                        if (kk < 0 || kk >= KW) continue;
+                        for (int ci = 0; ci < D; ++ci) row[(size_t)ti * D + ci] = w[((size_t)co * D + ci) * KW + kk];
+                    }
+                    b[(size_t)to * D + co] = t[k + 1][co];
+                }
+            o_wdown = put_mat(m.data(), (size_t)C, S * D);
+            o_bdown = put(b.data(), b.size());
+            k += 2;
+        }
+        for (SpO& o : spo) {
+            std::vector<float> w((size_t)4 * C * C), b((size_t)4 * C, 0.0f);
+            for (int part = 0; part < 3; ++part) {
+                std::memcpy(&w[(size_t)part * C * C], t[k + 2 * part], sizeof(float) * C * C);
+                std::memcpy(&b[(size_t)part * C], t[k + 2 * part + 1], sizeof(float) * C);
+            }
+            std::memcpy(&w[(size_t)3 * C * C], t[k + 6], sizeof(float) * C * C);
+            o.w4 = put_mat(w.data(), (size_t)4 * C, C);
+            o.b4 = put(b.data(), b.size());
+            o.bias = put(t[k + 7], C);
+            k += 8;
+        }
+        {
+            const float* w = t[k];                            // ConvTranspose2d (stride 1): out[t] = sum_{to, k: t = to + k - pd} x[to] w[k]  =>  k = t - to + pd
+            std::vector<float> m((size_t)S * D * C, 0.0f), b((size_t)S * D);
+            for (int tt = 0; tt < S; ++tt)
+                for (int co = 0; co < D; ++co) {
+                    float* row = &m[((size_t)tt * D + co) * C];
+                    for (int to = 0; to < Tn; ++to) {
+                        const int kk = tt - to + pd;
+                        if (kk < 0 || kk >= KW) continue;
+                        for (int ci = 0; ci < D; ++ci) row[(size_t)to * D + ci] = w[((size_t)ci * D + co) * KW + kk];
+                    }
+                    b[(size_t)tt * D + co] = t[k + 1][co];
+                }
+            o_wup = put_mat(m.data(), (size_t)S * D, C);
+            o_bup = put(b.data(), b.size());
+            k += 2;
+        }
+    }
     if (hipMalloc(&e->blob, host.size() * sizeof(float)) != hipSuccess) { delete e; return mpv_fail(ctx, MPV_ENOMEM, "mpv_nst_load: weight blob"); }
     if (hipMalloc(&e->blob16, host16.size() * sizeof(_Float16)) != hipSuccess) { nst_engine_destroy(e); return mpv_fail(ctx, MPV_ENOMEM, "mpv_nst_load: f16 weight blob"); }
     if (hipMemcpy(e->blob, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
@@ -800,7 +917,43 @@ int mpv_nst_load(mpv_ctx* ctx, const mpv_nst_desc* d, const float* const* t, int
     e->tau = PW(o_tau); e->delta = PW(o_delta);
     if (d->latent)
         for (int i = 0; i < 4; ++i) { e->zw[i] = M_(o_zw[i]); e->zb[i] = P(o_zb[i]); }
+    if (d->fT_h > 0) {
+        e->wdown = M_(o_wdown); e->bdown = P(o_bdown); e->wup = M_(o_wup); e->bup = P(o_bup);
+        for (const SpO& o : spo) e->sp.push_back(SpatialLayer{M_(o.w4), P(o.b4), P(o.bias)});
+    }
     ctx->nst = e;
+    return MPV_OK;
+}
+
+/* The ONE graph of Model_spatial's graph convolutions (reference: the `edge_index` argument of Model_spatial.forward, mu_backbone.py:296): stored as
+ * CSR by target node with every node's incoming edges in edge order; every window of a call is one copy of it. */
+int mpv_nst_set_graph(mpv_ctx* ctx, int32_t n_nodes, int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst) {
+    if (!ctx) return mpv_fail(nullptr, MPV_EINVAL, "mpv_nst_set_graph: ctx is NULL");
+    if (!ctx->nst) return mpv_fail(ctx, MPV_ESTATE, "mpv_nst_set_graph: call mpv_nst_load first");
+    NstEngine& e = *ctx->nst;
+    if (e.d.fT_h <= 0) return mpv_fail(ctx, MPV_ESTATE, "mpv_nst_set_graph: the loaded backbone has no spatial stage (fT_h = 0)");
+    if (n_nodes < 1 || n_edges < 0 || (n_edges > 0 && (!edge_src || !edge_dst))) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_set_graph: bad argument");
+    std::vector<int> rp((size_t)n_nodes + 1, 0), ci((size_t)n_edges);
+    for (int64_t i = 0; i < n_edges; ++i) {
+        if (edge_src[i] < 0 || edge_src[i] >= n_nodes || edge_dst[i] < 0 || edge_dst[i] >= n_nodes)
+            return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_set_graph: edge " + std::to_string(i) + " names a node outside [0, n_nodes)");
+        ++rp[(size_t)edge_dst[i] + 1];
+    }
+    for (int v = 0; v < n_nodes; ++v) rp[v + 1] += rp[v];
+    std::vector<int> fill(rp.begin(), rp.end() - 1);
+    for (int64_t i = 0; i < n_edges; ++i) ci[(size_t)fill[(size_t)edge_dst[i]]++] = (int)edge_src[i];       // stable: edge order within a target
+    DeviceGuard dg(ctx->device);
+    MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (e.row_ptr) (void)hipFree(e.row_ptr);
+    if (e.col_idx) (void)hipFree(e.col_idx);
+    e.row_ptr = e.col_idx = nullptr;
+    e.gV = 0;
+    if (hipMalloc(&e.row_ptr, sizeof(int) * rp.size()) != hipSuccess || hipMalloc(&e.col_idx, sizeof(int) * std::max<size_t>(1, ci.size())) != hipSuccess)
+        return mpv_fail(ctx, MPV_ENOMEM, "mpv_nst_set_graph: graph buffers");
+    MPV_HIP_TRY(ctx, hipMemcpy(e.row_ptr, rp.data(), sizeof(int) * rp.size(), hipMemcpyHostToDevice));
+    if (!ci.empty()) MPV_HIP_TRY(ctx, hipMemcpy(e.col_idx, ci.data(), sizeof(int) * ci.size(), hipMemcpyHostToDevice));
+    e.gV = n_nodes;
+    e.gE = n_edges;
     return MPV_OK;
 }
 
@@ -815,9 +968,12 @@ int mpv_nst_forward(mpv_ctx* ctx, const float* series, int32_t nodes, int64_t se
     e.gemm_mode = gemm;
     if (first + (int64_t)(n_windows - 1) * step + e.d.seq_len > series_len)
         return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_forward: the last window runs past the end of the series");
+    if (e.d.fT_h > 0 && (e.gV < 1 || e.gV != nodes))
+        return mpv_fail(ctx, MPV_ESTATE, "mpv_nst_forward: spatial backbone: call mpv_nst_set_graph with a graph of `nodes` nodes first");
     DeviceGuard dg(ctx->device);
     const long long B = (long long)n_windows * nodes;
     long long pass = rows_per_pass > 0 ? rows_per_pass : std::max<long long>(1, (long long)((6.0 * (1ull << 30) / sizeof(float)) / (double)per_row_floats(e.d)));
+    if (e.d.fT_h > 0) pass = std::max<long long>(nodes, pass / nodes * nodes);       // the graph convolution couples the nodes of a window: whole windows per pass
     pass = std::min(pass, B);
     NST_TRY(carve(ctx, e, pass));
     const int n_keep = full ? e.d.label_len + e.d.pred_len : e.d.pred_len;
@@ -840,7 +996,9 @@ int mpv_nst_debug_tensor(mpv_ctx* ctx, int32_t which, float* out, int64_t capaci
         case 1: src = e.stats; n = B * 2 * F; break;
         case 2: src = e.tau_v; n = B; break;
         case 3: src = e.delta_v; n = B * S; break;
-        case 4: src = e.ey; n = B * S * D; break;          // encoder output (after the latent bottleneck when present)
+        case 4: src = e.d.fT_h > 0 ? e.ex : e.ey; n = B * S * D; break;     // what the decoder cross-attends to: the encoder output (after the latent
+                                                                            // bottleneck / the spatial stage when present)
+        case 5: src = e.sp.size() % 2 ? e.sp_b : e.sp_a; n = B * e.d.fT_h * D; break;      // spatial features after the last graph convolution
         default: return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_debug_tensor: unknown tensor id");
     }
     if (!out || capacity < n) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_debug_tensor: output too small (need " + std::to_string(n) + " floats)");

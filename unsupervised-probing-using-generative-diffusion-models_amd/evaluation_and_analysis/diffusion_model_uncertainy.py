@@ -332,9 +332,13 @@ def _native_shard_batched(model, windows, pred_len, scale, graph=None):
     ctx = model.native_context()
     inv_std = model.scaler_std.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
     inv_mean = model.scaler_mean.to(ctx.device).float().contiguous() if _uses_scaler(model) else None
-    is_stg = graph is not None
+    is_nss = graph is not None and _is_spatial(model)           # NsDiff_spatial: windows of one graph, f(x) = the native Model_spatial
+    is_stg = graph is not None and not is_nss
     hist_len = model.T_h if is_stg else model.windows
-    per_window = V * (int(model.parallel_sampling) if is_stg else min(int(model.parallel_sample), int(model.n_z_samples)))
+    if is_nss:
+        per_window = V * int(model.configs.parallel_sample)
+    else:
+        per_window = V * (int(model.parallel_sampling) if is_stg else min(int(model.parallel_sample), int(model.n_z_samples)))
     chunk = max(1, MAX_BATCH_ROWS // max(per_window, 1))
     preds, mpv_parts, mean_parts = [], [], []
     for start in range(0, len(windows), chunk):
@@ -342,13 +346,18 @@ def _native_shard_batched(model, windows, pred_len, scale, graph=None):
         hist = torch.stack([torch.as_tensor(w).float()[:, :hist_len, :] for w in part]).to(ctx.device)         # [w, V, hist, F]
         if scale:
             hist = (hist - model.scaler_mean.to(ctx.device)) / model.scaler_std.to(ctx.device)
-        samples = model.sample_windows(hist, graph.edge_index) if is_stg else model.sample_windows(hist)
+        samples = model.sample_windows(hist, graph.edge_index) if graph is not None else model.sample_windows(hist)
         samples = samples[:, :, -pred_len:].contiguous()                                                       # [w, V, pred_len, F, S]
         mpv, pm, _ = ctx.reduce(samples, inv_std, inv_mean)
         mpv_parts.append(mpv)
         mean_parts.append(pm)
         preds.append(samples if dist_utils.active() else samples.cpu())
     return torch.cat(preds, dim=0), torch.cat(mpv_parts), torch.cat(mean_parts)
+
+
+def _is_spatial(model) -> bool:
+    """NsDiff_model_spatial: samples over a graph with the NsDiff posterior (its `sample_windows(history, edge_index)` runs f(x), g(x) and the sampler)."""
+    return hasattr(model, "spatial_mean_windows")
 
 
 def _native_shard(model, windows, pred_len, scale, keep_samples=True, graph=None):
@@ -445,6 +454,8 @@ def _sample_axis(model, graph=None):
     """(n_samples, chunk, whole_chunks_only) of a model family's sample axis: NsDiff and TMDM sample pointwise in chunks of
     `parallel_sample` (a chunk may be cut); a DiffusionTS chunk is one batch with shared normalisers and a DiffSTG chunk one sequential pass
     of `parallel_sampling` graph copies (whole chunks only)."""
+    if graph is not None and _is_spatial(model):
+        return None                      # NsDiff_spatial shards by window only
     if graph is not None:
         return int(model.parallel_sampling) * int(model.sequential_sampling), int(model.parallel_sampling), True
     if hasattr(model, "_prior_variance") and hasattr(model, "configs"):
@@ -595,7 +606,7 @@ def _sample_stacked(model, window_list, pred_len, scale: bool, keep_samples: boo
     else:                                   # more ranks than windows: an empty block still joins the collectives
         cfg = getattr(model, "configs", model)
         S = int(getattr(cfg, "n_z_samples", getattr(model, "n_z_samples", 1)))
-        if graph is not None:
+        if graph is not None and not _is_spatial(model):
             S = int(model.parallel_sampling) * int(model.sequential_sampling)
         nccl = dist_utils.active() and torch.distributed.get_backend() == "nccl"
         dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
@@ -709,6 +720,22 @@ def run_diffstg_evaluation_cache(model, timeseries_datas, pred_len, graph_data, 
     cache_path = Path(cache_path)
     if cache_path.exists() and not force_recompute:
         return normalize_diffstg_pred_future_list(_load_tensor_list(cache_path))
+    windows = list(timeseries_datas[:max_windows] if max_windows is not None else timeseries_datas)
+    with torch.no_grad():
+        preds, mpv, pm = _sample_stacked(model, windows, pred_len, scale=_uses_scaler(model), graph=graph_data)
+    out = _DeviceCurve(preds)
+    out.ews, out.pred_mean = mpv, pm
+    _save_on_primary(list(out), cache_path)
+    return out
+
+
+def run_spatial_evaluation_cache(model, timeseries_datas, pred_len, graph_data, cache_path, device, force_recompute=False, max_windows=None):
+    """NsDiff_spatial (extension: the reference's harness has no branch for it -- it would hand `evaluation_step` a tensor where
+    NsDiff_model.py:695-699 reads a graph batch): windows -> list of CPU tensors [V, pred_len, F, n_z_samples], cached like run_evaluation_cache;
+    every window is one copy of `graph_data`, f(x) = Model_spatial, g(x) and the sampler run for all windows in as few library calls as memory allows."""
+    cache_path = Path(cache_path)
+    if cache_path.exists() and not force_recompute:
+        return _load_tensor_list(cache_path)
     windows = list(timeseries_datas[:max_windows] if max_windows is not None else timeseries_datas)
     with torch.no_grad():
         preds, mpv, pm = _sample_stacked(model, windows, pred_len, scale=_uses_scaler(model), graph=graph_data)
@@ -1262,6 +1289,19 @@ def uncertainty_ews(model_save_file=None, data_file=None, torch_time_series=None
             if infer_params is None:
                 infer_params = {"parallel_sampling": 10, "sequential_sampling": 1, "n_z_samples": 10, "diffusion_steps": 20}
             preds = run_diffstg_evaluation_cache(need_model(), window_views, pred_len, load_diffstg_graph(graph_file), cache_path, device,
+                                                 force_recompute=force_recompute, max_windows=max_windows)
+        pred_mean_list, ews_list = summarize_pred_future_list(preds, model=model)
+    elif want_sampling and task_model == "NsDiff_spatial":             # extension (run_spatial_evaluation_cache)
+        if dynamic_type not in NETWORK_DYNAMICS:
+            raise ValueError("NsDiff_spatial only supports network dynamics: SIS, neuronal, biomass.")
+        if graph_file is None:
+            raise ValueError("graph_file is required for NsDiff_spatial.")
+        if cached_preds is not None:
+            preds = cached_preds
+            if model_save_file is not None and load_model_when_cached:
+                need_model()
+        else:
+            preds = run_spatial_evaluation_cache(need_model(), window_views, pred_len, load_diffstg_graph(graph_file), cache_path, device,
                                                  force_recompute=force_recompute, max_windows=max_windows)
         pred_mean_list, ews_list = summarize_pred_future_list(preds, model=model)
     elif want_sampling:

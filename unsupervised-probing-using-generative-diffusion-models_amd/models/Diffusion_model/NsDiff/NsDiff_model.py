@@ -313,21 +313,27 @@ class NsDiff_model(_NsDiffBase):
         return self._evaluation_step(batch, y0hat, noise)
 
 
+SPATIAL_CONFIG_KEYS = ns_Transformer.CONFIG_KEYS + ("fT_h", "spatial_layers")
+
 _F_SPATIAL_MSG = (
-    "NsDiff_spatial's mean backbone f(x) is the reference's `Model_spatial` (NsDiff/mu_backbone.py:186-340: torch-timeseries encoder / decoder "
-    "layers interleaved with graph convolutions), which has no native implementation here.  Pass a precomputed y_0_hat [V, pred_len, F] "
-    "(`y0hat=`), or attach your own module with the reference's call signature `(batch_x, dec_inp, edge_index) -> (y_0_hat, _)` via "
-    "`attach_backbone(module)`.")
+    "NsDiff_spatial's mean backbone f(x) is the reference's `Model_spatial` (NsDiff/mu_backbone.py:186-340: the ns-Transformer with graph "
+    "convolutions between encoder and decoder), and net_param lacks its hyper-parameters (" + ", ".join(SPATIAL_CONFIG_KEYS) + "), so none was "
+    "built.  Add them, pass a precomputed y_0_hat [V, pred_len, F] (`y0hat=`), or attach your own module with the reference's call signature "
+    "`(batch_x, dec_inp, edge_index) -> (y_0_hat, _)` via `attach_backbone(module)`.")
 
 
 class NsDiff_model_spatial(_NsDiffBase):
     """NsDiff over a graph (reference NsDiff_model.py:497-790): g(x) by the sigma-head kernel, the graph U-Net eps / sigma network and the
-    NsDiff reverse loop by csrc/stg.hip (engine mode 1) behind mpv_nss_*; f(x) (`Model_spatial`) is an input (`y0hat=` / attach_backbone).
+    NsDiff reverse loop by csrc/stg.hip (engine mode 1) behind mpv_nss_*; f(x) = `Model_spatial` by csrc/nst.hip's spatial mode when net_param
+    carries its hyper-parameters (d_model, n_heads, d_ff, e_layers, d_layers, activation, p_hidden_dims, p_hidden_layers, fT_h, spatial_layers),
+    else an input (`y0hat=` / attach_backbone).
 
     `evaluation_step(gdata)` takes the reference's graph batch (`.x` [V, >= windows, F], `.edge_index` [2, E], `.num_nodes`) and returns
     (outs [V, pred_len, F, n_z_samples] on the CPU, batch_y | None).  Two reference behaviours are kept as they are: rows are tiled
     node-major (row v*P + p, :756-763) while the duplicated edge index is copy-major (copy r // V, :783-790), and with parallel_sample = 1
     the reference never defines the edge index it passes on (UnboundLocalError, :751-753) -- here that case uses the plain edge index."""
+
+    batched_history = True          # the harness hands `sample_windows` all windows of a launch as [W, V, history, F] (+ the graph)
 
     def __init__(self, net_param, train_model_select, pretrain_f_path="results/pre_model_F", pretrain_g_path="results/pre_model_G"):
         super().__init__()
@@ -339,11 +345,15 @@ class NsDiff_model_spatial(_NsDiffBase):
         if train_model_select == "NsDiff_model":
             self.needs_backbone = True
             self.model = NsDiff_net_spatial(self.configs, self.device)
+            self.cond_pred_model = self._build_spatial_backbone(net_param)                  # reference :539-548
             self.cond_pred_model_g = G.SigmaEstimation(self.windows, self.pred_len, self.dataset_nf, 512, self.rolling_length, native=self._native)
         elif train_model_select == "pretrain_g":
             self.cond_pred_model_g = G.SigmaEstimation(self.windows, self.pred_len, self.dataset_nf, 512, self.rolling_length, native=self._native)
-        elif train_model_select == "pretrain_f":
-            raise NotImplementedError(_F_SPATIAL_MSG)
+        elif train_model_select == "pretrain_f":                                            # reference :561: f(x) alone
+            self.needs_backbone = True
+            self.cond_pred_model = self._build_spatial_backbone(net_param)
+            if self.cond_pred_model is None:
+                raise NotImplementedError(_F_SPATIAL_MSG)
         else:
             raise ValueError("train_model_select should be in ['NsDiff_model', 'pretrain_f', 'pretrain_g']")
 
@@ -353,12 +363,22 @@ class NsDiff_model_spatial(_NsDiffBase):
         self.scaler_mean = data.mean(axis=(0, 1))
         self.scaler_std = std
 
+    def _build_spatial_backbone(self, net_param):
+        if all(k in net_param for k in SPATIAL_CONFIG_KEYS):
+            return ns_Transformer.Model_spatial(self.configs, native=self._native)
+        return None
+
+    def _native_backbone(self) -> bool:
+        return isinstance(getattr(self, "cond_pred_model", None), ns_Transformer.Model_spatial)
+
     def _upload_native(self, ctx):
         if getattr(self, "model", None) is not None:
             ctx.load_nss(self.model.diffussion_model, self.model.coef_rows, self.diffusion_steps, gemm=self.gemm_mode if self.gemm_mode in ("f16x3", "f32") else "f16x3")
         g = getattr(self, "cond_pred_model_g", None)
         if g is not None:
             ctx.load_sigma(g.seq_len, g.kernel_size, g.pred_len, g.enc_in, g.hidden_size, g.native_weights())
+        if self._native_backbone():
+            ctx.load_nst(self.cond_pred_model)
 
     @staticmethod
     def duplicate_edge_index(parallel_sampling, edge_index, num_nodes, device):
@@ -368,18 +388,35 @@ class NsDiff_model_spatial(_NsDiffBase):
         return (edge_index + indent).reshape((2, -1))
 
     def _spatial_mean(self, batch_x, edge_index):
+        """y_0_hat [V, pred_len, F] of one graph's scaled windows [V, windows, F] (reference :744)."""
         if self.cond_pred_model is None:
             raise NotImplementedError(_F_SPATIAL_MSG)
+        if self._native_backbone():
+            return self.cond_pred_model(batch_x, None, edge_index)[0]
         dev = next(self.cond_pred_model.parameters(), torch.zeros(0, device=self.scaler_mean.device)).device
         with torch.no_grad():
             y0hat, _ = self.cond_pred_model(batch_x.to(dev), self._decoder_input(batch_x.to(dev)), edge_index.to(dev))
         return y0hat
 
-    def sample_windows(self, history: torch.Tensor, edge_index: torch.Tensor, y0hat: torch.Tensor, *, noise: Optional[torch.Tensor] = None,
+    def spatial_mean_windows(self, history: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+        """f(x) of W windows of one graph in ONE call: history [W, V, windows, F] (scaled) -> y_0_hat [W, V, pred_len, F] on device.  The native
+        backbone gathers windows out of a series, so the windows are laid end to end per node (step = windows); an attached module is called
+        window by window with the reference's signature."""
+        if self.cond_pred_model is None:
+            raise NotImplementedError(_F_SPATIAL_MSG)
+        W, V = history.shape[0], history.shape[1]
+        if not self._native_backbone():
+            return torch.stack([self._spatial_mean(history[w], edge_index).to(history.device) for w in range(W)])
+        ctx = self._native.context()
+        ctx.nst_set_graph(edge_index, V)
+        series = history.to(device=ctx.device, dtype=torch.float32).permute(1, 0, 2, 3).reshape(V, W * self.windows, self.dataset_nf).contiguous()
+        return ctx.nst_forward(series, W, 0, self.windows, gemm=self.cond_pred_model.gemm_mode)
+
+    def sample_windows(self, history: torch.Tensor, edge_index: torch.Tensor, y0hat: Optional[torch.Tensor] = None, *, noise: Optional[torch.Tensor] = None,
                        seed: Optional[int] = None) -> torch.Tensor:
-        """history [W, V, windows, F] (scaled), the ONE graph's edge_index [2, E], y0hat [W, V, pred_len, F] -> samples
-        [W, V, pred_len, F, n_z_samples] on device: one sigma-head launch over all W*V rows, then every window's parallel_sample graph
-        copies side by side through the T-step loop, n_z_samples / parallel_sample passes."""
+        """history [W, V, windows, F] (scaled), the ONE graph's edge_index [2, E], y0hat [W, V, pred_len, F] (None: f(x) = the native Model_spatial
+        or the attached module) -> samples [W, V, pred_len, F, n_z_samples] on device: one sigma-head launch over all W*V rows, then every
+        window's parallel_sample graph copies side by side through the T-step loop, n_z_samples / parallel_sample passes."""
         if getattr(self, "model", None) is None:
             raise RuntimeError("train_model_select={!r} has no diffusion network to sample from".format(self.train_model_select))
         S, P = self._check_sampling_config()
@@ -389,6 +426,8 @@ class NsDiff_model_spatial(_NsDiffBase):
             raise ValueError("history must be [W, V, {}, {}], got {}".format(self.windows, self.dataset_nf, tuple(hist.shape)))
         W, V = hist.shape[0], hist.shape[1]
         gx = ctx.sigma_head(hist.reshape(W * V, self.windows, self.dataset_nf), 1, 0, 1)[0].reshape(W, V, self.pred_len, self.dataset_nf).contiguous()   # no EPS (:748)
+        if y0hat is None:
+            y0hat = self.spatial_mean_windows(hist, edge_index)
         y0 = y0hat.to(device=ctx.device, dtype=torch.float32).reshape(W, V, self.pred_len, self.dataset_nf).contiguous()
         if noise is None and self.noise_source == "torch_cpu":
             noise = self.host_noise(W, V)

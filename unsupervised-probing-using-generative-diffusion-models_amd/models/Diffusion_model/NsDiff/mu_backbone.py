@@ -155,7 +155,10 @@ class Model(nn.Module):
                       d_model=self.d_model, n_heads=self.n_heads, d_ff=self.d_ff, e_layers=len(self.encoder.attn_layers),
                       d_layers=len(self.decoder.layers), activation=int(self.activation == "gelu"), p_layers=self.p_hidden_layers,
                       p_hidden=self.p_hidden_dims[: self.p_hidden_layers], latent=int(self.latent), pe_rows=rows)
-        return fields, t
+        return self._extend_native(fields, t)
+
+    def _extend_native(self, fields, tensors):
+        return fields, tensors
 
     def _run(self, x_enc):
         if x_enc.dim() != 3 or x_enc.shape[1] != self.seq_len or x_enc.shape[2] != self.enc_in:
@@ -171,4 +174,70 @@ class Model(nn.Module):
         if enc_self_mask is not None or dec_self_mask is not None or dec_enc_mask is not None:
             raise NotImplementedError("attention masks other than the decoder's causal mask are not part of this path")
         dec_out = self._run(x_enc)
+        return dec_out[:, -self.pred_len:, :], dec_out
+
+
+class SpatialBlock(nn.Module):
+    """Holder of one graph convolution of Model_spatial (reference :43-51): `gnn` carries torch_geometric's ResGatedGraphConv parameter names
+    (lin_key / lin_query / lin_value with bias, bias-free lin_skip, bias)."""
+
+    def __init__(self, c_in, c_out, gnn_name="ResGatedGraphConv", gnn_param=None):
+        super().__init__()
+        if gnn_name != "ResGatedGraphConv":
+            raise NotImplementedError("Model_spatial's graph convolution is built for gnn_name='ResGatedGraphConv' (got {!r})".format(gnn_name))
+        if c_in != c_out:
+            raise ValueError("SpatialBlock keeps the feature width")
+        self.gnn = _Named(lin_key=nn.Linear(c_in, c_out), lin_query=nn.Linear(c_in, c_out), lin_value=nn.Linear(c_in, c_out),
+                          lin_skip=nn.Linear(c_in, c_out, bias=False))
+        self.gnn.bias = nn.Parameter(torch.zeros(c_out))
+
+    def tensors(self):
+        g = self.gnn
+        return [g.lin_key.weight, g.lin_key.bias, g.lin_query.weight, g.lin_query.bias, g.lin_value.weight, g.lin_value.bias, g.lin_skip.weight, g.bias]
+
+
+class Model_spatial(Model):
+    """Non-stationary Transformer with a graph stage between encoder and decoder: f(x) of NsDiff_spatial (reference :186-340).  Adds the
+    reference's `downsampling` (Conv2d(D, D, (1, windows + 1), padding (0, fT_h // 2))), `spatial_encoder` (spatial_layers x SpatialBlock over
+    fT_h * d_model features) and `upsampling` (ConvTranspose2d) under their names; configs additionally carries fT_h (even), spatial_layers,
+    f_gnn_name, f_gnn_param.  `forward(batch_x, dec_inp, edge_index)` runs csrc/nst.hip's spatial mode: batch_x = the nodes of ONE graph."""
+
+    def __init__(self, configs, native=None, enc_in=None):
+        super().__init__(configs, native=native, enc_in=enc_in)
+        self.T = getattr(configs, "windows", configs.seq_len)
+        if self.T != self.seq_len:
+            raise ValueError("Model_spatial: windows must equal seq_len (the k = windows + 1 convolution maps seq_len steps to fT_h)")
+        self.fT_h, self.spatial_layers = int(configs.fT_h), int(configs.spatial_layers)
+        if self.fT_h < 2 or self.fT_h % 2 or self.fT_h > self.seq_len:
+            raise ValueError("fT_h must be even and in [2, seq_len]")
+        D, C = self.d_model, self.fT_h * self.d_model
+        gnn_name = getattr(configs, "f_gnn_name", "ResGatedGraphConv")
+        self.spatial_encoder = nn.ModuleList([SpatialBlock(C, C, gnn_name, getattr(configs, "f_gnn_param", None)) for _ in range(self.spatial_layers)])
+        self.downsampling = nn.Conv2d(D, D, (1, self.T + 1), (1, 1), (0, self.fT_h // 2))
+        self.upsampling = nn.ConvTranspose2d(D, D, (1, self.T + 1), (1, 1), (0, self.fT_h // 2))
+
+    def _extend_native(self, fields, tensors):
+        t = list(tensors) + [self.downsampling.weight, self.downsampling.bias]
+        for blk in self.spatial_encoder:
+            t += blk.tensors()
+        t += [self.upsampling.weight, self.upsampling.bias]
+        return dict(fields, fT_h=self.fT_h, spatial_layers=self.spatial_layers), t
+
+    def _run_graph(self, x_enc, edge_index):
+        if x_enc.dim() != 3 or x_enc.shape[1] != self.seq_len or x_enc.shape[2] != self.enc_in:
+            raise ValueError("f(x) was built for windows [V, {}, {}], got {}".format(self.seq_len, self.enc_in, tuple(x_enc.shape)))
+        if self._native is None:
+            raise RuntimeError("the backbone is not attached to a native handle")
+        ctx = self._native.context(self)
+        ctx.nst_set_graph(edge_index, x_enc.shape[0])
+        series = x_enc.to(device=ctx.device, dtype=torch.float32).contiguous()
+        return ctx.nst_forward(series, 1, 0, 1, full=True, gemm=self.gemm_mode)[0]          # [V, label_len + pred_len, F]
+
+    def forward(self, x_enc, x_dec=None, edge_index=None, enc_self_mask=None, dec_self_mask=None, dec_enc_mask=None):
+        """(batch_x [V, seq_len, F], dec_inp, edge_index [2, E]) -> (dec_out[:, -pred_len:], dec_out)   (reference :296-340)."""
+        if enc_self_mask is not None or dec_self_mask is not None or dec_enc_mask is not None:
+            raise NotImplementedError("attention masks other than the decoder's causal mask are not part of this path")
+        if edge_index is None:
+            raise ValueError("Model_spatial.forward needs the graph's edge_index")
+        dec_out = self._run_graph(x_enc, edge_index)
         return dec_out[:, -self.pred_len:, :], dec_out
