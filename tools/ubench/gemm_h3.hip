@@ -24,6 +24,22 @@ float run(const NstGemmHArgs& a, int reps) {
     return ms / reps;
 }
 
+template <int PROBE>
+float run256(const NstGemmHArgs& a, int reps) {
+    const long long tiles = ((a.M + 255) / 256) * ((a.N + G_BN - 1) / G_BN);
+    const dim3 grid((unsigned)(8 * ((tiles + 7) / 8)));
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((nst_gemm_h3_kernel<PROBE, 256>), grid, dim3(256), 0, 0, a);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((nst_gemm_h3_kernel<PROBE, 256>), grid, dim3(256), 0, 0, a);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+
 float run64(const NstGemmHArgs& a, int reps) {
     const long long tiles = ((a.M + 63) / 64) * ((a.N + G_BN - 1) / G_BN);
     const dim3 grid((unsigned)(8 * ((tiles + 7) / 8)));
@@ -72,6 +88,8 @@ int main() {
         const float full = run<0>(a, 5), nostore = run<1>(a, 5), onek = run<2>(a, 5), noload = run<4>(a, 5), loop_only = run<5>(a, 5);
         printf("%-10s N=%4d K=%3d: full %.3f ms (%.0f TF/s) | no stores %.3f | one k-tile %.3f | no loads in loop %.3f | no loads, no stores %.3f\n", s.name, s.N, s.K,
                full, gf / full, nostore, onek, noload, loop_only);
+        const float f256 = run256<0>(a, 5), l256 = run256<5>(a, 5), o256 = run256<2>(a, 5);
+        printf("           256-row tiles: full %.3f ms (%.0f TF/s) | one k-tile %.3f | no loads, no stores %.3f\n", f256, gf / f256, o256, l256);
     }
     return 0;
 }

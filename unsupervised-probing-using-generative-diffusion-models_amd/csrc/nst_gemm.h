@@ -51,53 +51,63 @@ template <bool PROBE_NO_STORE = false, int MT = 2>      // MT: 32-row accumulato
 __device__ __forceinline__ void gemm_store_tile(float* Cs, const v16f (&acc)[MT][2], float scale, long long m0, int n0, long long M, int N, const float* bias,
                                                 int act, const float* R, long long ldr, float* Y, long long ldy) {
     constexpr int BM = 64 * MT;
+    // MT = 4 (256-row workgroup tiles, round 4): the staging buffer holds 128 rows, so the two wave rows (wm = 0, 1: 128 output rows each) go through
+    // it one after the other
+    constexpr int HALVES = MT == 4 ? 2 : 1, HR = BM / HALVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-    // the residual tile is requested first, all 16 row pieces of this thread at once: the loads fly while the accumulators go through LDS (a
-    // product with a short K -- DiffSTG's up-sampling maps, K = 80..160 against N = 3200 -- is all epilogue: 237 us per launch with the loads
-    // issued four at a time inside the store loop)
     const int c4e = (tid & 31) * 4;
     const bool add_r = R && act != 3 && n0 + c4e < N;
-    v4f rr[BM / 8];
-    if (add_r) {
-#pragma unroll
-        for (int it = 0; it < BM / 8; ++it) {
-            const long long m = m0 + it * 8 + (tid >> 5);
-            rr[it] = m < M ? *reinterpret_cast<const v4f*>(R + (size_t)m * ldr + n0 + c4e) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-    }
-    __syncthreads();                              // every wave is done with the operand tiles
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Cs[(wm * 32 * MT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * C_LD + wn * 64 + j * 32 + li] = acc[i][j][r] * scale;
-    __syncthreads();
     const int c4 = (tid & 31) * 4, n = n0 + c4;
-    if (n >= N) return;
     v4f b4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (bias) b4 = *reinterpret_cast<const v4f*>(bias + n);
+    if (bias && n < N) b4 = *reinterpret_cast<const v4f*>(bias + n);
 #pragma unroll
-    for (int it = 0; it < BM / 8; ++it) {
-        const int row = it * 8 + (tid >> 5);
-        const long long m = m0 + row;
-        if (m >= M) break;
-        v4f y = *reinterpret_cast<const v4f*>(Cs + row * C_LD + c4) + b4;
-        if (act == 1) {
+    for (int half = 0; half < HALVES; ++half) {
+        const long long mh = m0 + (long long)half * HR;
+        // the residual tile is requested first, all row pieces of this thread at once: the loads fly while the accumulators go through LDS (a
+        // product with a short K -- DiffSTG's up-sampling maps, K = 80..160 against N = 3200 -- is all epilogue: 237 us per launch with the loads
+        // issued four at a time inside the store loop)
+        v4f rr[HR / 8];
+        if (add_r) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) y[c] = fmaxf(y[c], 0.0f);
-        } else if (act == 2) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) y[c] = nst_gelu(y[c]);
+            for (int it = 0; it < HR / 8; ++it) {
+                const long long m = mh + it * 8 + (tid >> 5);
+                rr[it] = m < M ? *reinterpret_cast<const v4f*>(R + (size_t)m * ldr + n0 + c4e) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+            }
         }
-        if (act == 3) {                           // y *= gelu'(R[m][n]): the GELU backward of an MLP, R = the saved pre-activation
-            const v4f u = *reinterpret_cast<const v4f*>(R + (size_t)m * ldr + n);
+        __syncthreads();                              // every wave is done with the operand tiles (resp. with the previous half's rows)
+        if (HALVES == 1 || wm == half) {
+            const int wrow = HALVES == 1 ? wm * 32 * MT : 0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                y[c] *= 0.5f * (1.0f + erff(u[c] * 0.70710678118654752f)) + u[c] * 0.39894228040143268f * __expf(-0.5f * u[c] * u[c]);
-        } else if (add_r) y += rr[it];
-        if (!PROBE_NO_STORE || y[0] == 1.2345e30f) *reinterpret_cast<v4f*>(Y + (size_t)m * ldy + n) = y;
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        Cs[(wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * C_LD + wn * 64 + j * 32 + li] = acc[i][j][r] * scale;
+        }
+        __syncthreads();
+        if (n >= N) continue;
+#pragma unroll
+        for (int it = 0; it < HR / 8; ++it) {
+            const int row = it * 8 + (tid >> 5);
+            const long long m = mh + row;
+            if (m >= M) break;
+            v4f y = *reinterpret_cast<const v4f*>(Cs + row * C_LD + c4) + b4;
+            if (act == 1) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) y[c] = fmaxf(y[c], 0.0f);
+            } else if (act == 2) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) y[c] = nst_gelu(y[c]);
+            }
+            if (act == 3) {                           // y *= gelu'(R[m][n]): the GELU backward of an MLP, R = the saved pre-activation
+                const v4f u = *reinterpret_cast<const v4f*>(R + (size_t)m * ldr + n);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    y[c] *= 0.5f * (1.0f + erff(u[c] * 0.70710678118654752f)) + u[c] * 0.39894228040143268f * __expf(-0.5f * u[c] * u[c]);
+            } else if (add_r) y += rr[it];
+            if (!PROBE_NO_STORE || y[0] == 1.2345e30f) *reinterpret_cast<v4f*>(Y + (size_t)m * ldy + n) = y;
+        }
     }
 }
 
@@ -203,17 +213,38 @@ struct NstGemmHArgs {
     int ldw;
 };
 
-constexpr int H_LD = G_BK + 8;                  // halves per LDS row
+// Operand tiles in LDS: rows of G_BK = 32 halves = four 16-byte chunks.  Round 3 padded a row to 80 bytes, which makes the operand reads (16 lanes x
+// 16 bytes, consecutive rows) conflict-free but not the tile writes (8 or 16 bytes per lane, 64 contiguous bytes per row, next row 80 bytes on: rows 0
+// and 3 of a 256-byte pass share banks) -- PMC on the QKV product: SQ_LDS_BANK_CONFLICT = 31 % of SQ_LDS_IDX_ACTIVE (profiles/r04/gemm_h3_ubench.txt).
+// Round 4: unpadded 64-byte rows with the chunk index XOR-ed by (row >> 2) & 3 -- writes cover whole 64-byte rows (any chunk order), and the 16 rows
+// of a read pass hit bank group 16 (row & 3) + 4 (chunk ^ (row >> 2)): all distinct.  H_SWZ 0 restores the padded layout.
+#ifndef H_SWZ
+#define H_SWZ 1
+#endif
+constexpr int H_LD = H_SWZ ? G_BK : G_BK + 8;   // halves per LDS row
+__device__ __forceinline__ int h_off(int row, int half) {        // offset (halves) of element `half` (a multiple of 4) of row `row`
+#if H_SWZ
+    return row * H_LD + ((((half >> 3) ^ (row >> 2)) & 3) << 3) + (half & 7);
+#else
+    return row * H_LD + half;
+#endif
+}
 
 // PROBE (tools/ubench/gemm_h3.hip only): 1 no epilogue stores, 2 one k-tile, 4 no global loads inside the loop
 // BM = 128 (four waves of 64 x 64; the shipped shape) or 64 (four waves of 32 x 64: half the registers and LDS, three workgroups per CU; see
 // nst_gemm_h3_launch).
+// BM = 256 (round 4: four waves of 128 x 64): the k loop of the 128-row shape runs at half the matrix pipe's pace because the CU's ONE LDS port is as
+// busy as its four matrix pipes -- per 32-wide k-tile a workgroup reads 4 waves x 16 ds_read_b128 (64 KB) and writes 32 KB of split operands for
+// 96 MFMAs, and two resident workgroups make that 1536 LDS cycles per 1536 MFMA cycles per SIMD.  A 128 x 64 wave tile needs 24 reads per 48 MFMAs
+// instead of 32, and the 256 x 128 workgroup tile stages 384 operand rows per 2x the products instead of 512: 0.75x the LDS traffic per MFMA.  One
+// register set of staged tiles (the k-tile's compute phase is twice as long); the output goes through the 128-row staging buffer in two halves.
 template <int PROBE = 0, int BM = G_BM>
 __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(const NstGemmHArgs p) {
     constexpr int MT = BM / 64;
-    static_assert(BM == 64 || BM == 128, "workgroup tile rows");
-    static_assert((2 * BM + 2 * G_BN) * H_LD * 2 <= BM * C_LD * 4, "the operand tiles fit the output tile's LDS");
-    __shared__ __attribute__((aligned(16))) float smem[BM * C_LD];             // operand tiles, then the output tile
+    constexpr int SR = BM == 256 ? 128 : BM;                                   // rows of the output staging buffer
+    static_assert(BM == 64 || BM == 128 || BM == 256, "workgroup tile rows");
+    static_assert((2 * BM + 2 * G_BN) * H_LD * 2 <= SR * C_LD * 4, "the operand tiles fit the output tile's LDS");
+    __shared__ __attribute__((aligned(16))) float smem[SR * C_LD];             // operand tiles, then the output tile
     _Float16* Ah = reinterpret_cast<_Float16*>(smem);
     _Float16* Al = Ah + BM * H_LD;
     _Float16* Bh = Al + BM * H_LD;
@@ -243,7 +274,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(cons
     }
     // Two register sets of staged tiles, so that a global load has two compute phases to land before it is written to LDS.
     struct Stage { v4f x[2 * MT]; h8 h[2], l[2]; };
-    Stage sa, sb;
+    Stage sa, sb;                                          // (BM = 256 never touches sb: dead, no registers)
     auto fetch = [&](Stage& st, int kt) {
 #pragma unroll
         for (int j = 0; j < 2 * MT; ++j)
@@ -269,13 +300,13 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(cons
             ph[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hi[2], hi[3]));
             pl[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo[0], lo[1]));
             pl[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo[2], lo[3]));
-            *reinterpret_cast<u2*>(Ah + (lr + 32 * j) * H_LD + lk) = ph;
-            *reinterpret_cast<u2*>(Al + (lr + 32 * j) * H_LD + lk) = pl;
+            *reinterpret_cast<u2*>(Ah + h_off(lr + 32 * j, lk)) = ph;
+            *reinterpret_cast<u2*>(Al + h_off(lr + 32 * j, lk)) = pl;
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<h8*>(Bh + (wr + 64 * j) * H_LD + wk) = st.h[j];
-            *reinterpret_cast<h8*>(Bl + (wr + 64 * j) * H_LD + wk) = st.l[j];
+            *reinterpret_cast<h8*>(Bh + h_off(wr + 64 * j, wk)) = st.h[j];
+            *reinterpret_cast<h8*>(Bl + h_off(wr + 64 * j, wk)) = st.l[j];
         }
     };
     v16f acc[MT][2];
@@ -287,21 +318,27 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(cons
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const int nk = (PROBE & 2) ? 1 : p.ldw / G_BK;
     const int li = lane & 31, lh = lane >> 5;
-    const int a_off = (wm * 32 * MT + li) * H_LD + 8 * lh;
-    const int b_off = (wn * 64 + li) * H_LD + 8 * lh;
+    // (row bases are multiples of 32, so the swizzle of a lane's rows depends on li alone: one pair of offsets per k-step, fixed for the kernel)
+    const int a_row = wm * 32 * MT + li, b_row = wn * 64 + li;
+    int a_off[G_BK / 16], b_off[G_BK / 16];
+#pragma unroll
+    for (int ks = 0; ks < G_BK / 16; ++ks) {
+        a_off[ks] = h_off(a_row, 16 * ks + 8 * lh);
+        b_off[ks] = h_off(b_row, 16 * ks + 8 * lh);
+    }
     auto compute = [&]() {
 #pragma unroll
         for (int ks = 0; ks < G_BK / 16; ++ks) {
             h8 ah[MT], al[MT], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                ah[i] = *reinterpret_cast<const h8*>(Ah + a_off + i * 32 * H_LD + 16 * ks);
-                al[i] = *reinterpret_cast<const h8*>(Al + a_off + i * 32 * H_LD + 16 * ks);
+                ah[i] = *reinterpret_cast<const h8*>(Ah + a_off[ks] + i * 32 * H_LD);
+                al[i] = *reinterpret_cast<const h8*>(Al + a_off[ks] + i * 32 * H_LD);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                bh[i] = *reinterpret_cast<const h8*>(Bh + b_off + i * 32 * H_LD + 16 * ks);
-                bl[i] = *reinterpret_cast<const h8*>(Bl + b_off + i * 32 * H_LD + 16 * ks);
+                bh[i] = *reinterpret_cast<const h8*>(Bh + b_off[ks] + i * 32 * H_LD);
+                bl[i] = *reinterpret_cast<const h8*>(Bl + b_off[ks] + i * 32 * H_LD);
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -316,6 +353,19 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(cons
     fetch(sa, 0);
     stash(sa);
     if (nk > 1) fetch(sa, 1);
+    if constexpr (BM == 256) {                             // one register set: tile kt + 2 is requested once tile kt + 1 has left the registers
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            compute();                                     // tile kt
+            if (kt + 1 >= nk) break;
+            __syncthreads();
+            stash(sa);                                     // tile kt + 1
+            __syncthreads();
+            if (!(PROBE & 4) && kt + 2 < nk) fetch(sa, kt + 2);
+        }
+        gemm_store_tile<(PROBE & 1) != 0, MT>(smem, acc, p.inv_scale, m0, n0, p.M, p.N, p.bias, p.act, p.R, p.ldr, p.Y, p.ldy);
+        return;
+    }
     if (nk > 2) fetch(sb, 2);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
@@ -339,7 +389,20 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(cons
 // 5 % faster on the N = 80 products and 40 % slower on N = 160, K = 3200; the whole step 8.7 against 9.1 windows/s with 128 rows).
 inline void nst_gemm_h3_launch(const NstGemmHArgs& a, hipStream_t stream) {
     const long long n_n = (a.N + G_BN - 1) / G_BN;
-    static const bool rows64 = getenv("MPV_GEMM_BM") && atoi(getenv("MPV_GEMM_BM")) == 64;
+    static const int bm_env = getenv("MPV_GEMM_BM") ? atoi(getenv("MPV_GEMM_BM")) : 0;
+    // 64-row tiles (MPV_GEMM_BM=64, a tuning aid): alone on the device they win on DiffSTG's single-N-tile "downsampling" products (N = 80: 56.9 -> 46.7 us
+    // at K = 1600 with the swizzled operand tiles), inside the sampler step they lose -- c5 8.68 windows/s with them on those products against 9.22
+    // with 128 rows everywhere (profiles/r04/gemm_h3_ubench.txt) -- so they are not chosen automatically.
+    const bool rows64 = bm_env == 64;
+    // 256-row tiles for the wide products (f(x)'s fused QKV: N = 3 d_model) when they still fill the chip several times over.  Measured on one
+    // 216 800-row pass (tools/ubench/gemm_h3, profiles/r04/gemm_h3_ubench.txt): N = 1536, K = 512: 1.179 -> 1.053 ms (289 -> 324 TFLOP/s);
+    // N = 512: 0.428 -> 0.417; N = 256: 0.230 -> 0.237; N = 512, K = 256: 0.278 -> 0.306 (the longer prologue / epilogue of a 256-row tile outweighs
+    // the leaner k-loop once a row block has few N tiles) -- so only N >= 1024.  MPV_GEMM_BM=128 keeps the round-3 shape for A/B runs.
+    const long long tiles256 = ((a.M + 255) / 256) * n_n;
+    if (bm_env == 256 || (bm_env == 0 && a.N >= 1024 && tiles256 >= 2048)) {
+        hipLaunchKernelGGL((nst_gemm_h3_kernel<0, 256>), dim3((unsigned)(8 * ((tiles256 + 7) / 8))), dim3(256), 0, stream, a);
+        return;
+    }
     if (rows64) {
         const long long tiles = ((a.M + 63) / 64) * n_n;
         hipLaunchKernelGGL((nst_gemm_h3_kernel<0, 64>), dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(256), 0, stream, a);
