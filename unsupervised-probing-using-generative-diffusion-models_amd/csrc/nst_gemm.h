@@ -32,9 +32,10 @@ constexpr int G_BM = 128, G_BN = 128, G_BK = 32, G_LD = G_BK + 4;
 // on the same XCD, so the X block is fetched from HBM once and served to the others by that L2 (the weights, a few MB, stay
 // resident in every L2).  Returns false for the padding workgroups of the last chunk.
 template <int BM = G_BM>
-__device__ __forceinline__ bool gemm_tile(long long M, int N, long long& m0, int& n0) {
+__device__ __forceinline__ bool gemm_tile(long long M, int N, long long& m0, int& n0, long long id = -1) {
     const long long n_n = (N + G_BN - 1) / G_BN, total = ((M + BM - 1) / BM) * n_n;
-    const long long per = (total + 7) / 8, id = blockIdx.x;
+    const long long per = (total + 7) / 8;
+    if (id < 0) id = blockIdx.x;
     const long long t = (id & 7) * per + (id >> 3);
     if ((id >> 3) >= per || t >= total) return false;
     m0 = (t / n_n) * BM;
@@ -211,6 +212,16 @@ struct NstGemmHArgs {
     int N, K;                                   // K a multiple of 4; the k loop runs over ldw (K rounded up to 32), X columns >= K read as 0
     int act;
     int ldw;
+    // Round 4, split-K with a fixed summation order (DiffSTG's long-K, narrow-N "downsampling" products: 25 600 rows x N = 80..160 are 200-400 tiles
+    // on 256 CUs, each streaming K = 800..3200 with 32 KB in flight -- concurrency-bound at 1.6-2.4 TB/s).  ksplit > 1: the k-tiles of an output tile
+    // are dealt to ksplit workgroups in contiguous chunks; workgroup s writes its partial sums (x inv_scale; NO bias / activation / residual) to
+    // Y + s * ypart.  The consumer reads them back through xparts / xpart / xbias: its A operand is ((X_0 + X_1) + ...) + xbias[k], always in that
+    // order, so the result is bitwise repeatable.
+    int ksplit = 1;
+    long long ypart = 0;
+    int xparts = 1;
+    long long xpart = 0;
+    const float* xbias = nullptr;
 };
 
 // Operand tiles in LDS: rows of G_BK = 32 halves = four 16-byte chunks.  Round 3 padded a row to 80 bytes, which makes the operand reads (16 lanes x
@@ -238,7 +249,9 @@ __device__ __forceinline__ int h_off(int row, int half) {        // offset (halv
 // 96 MFMAs, and two resident workgroups make that 1536 LDS cycles per 1536 MFMA cycles per SIMD.  A 128 x 64 wave tile needs 24 reads per 48 MFMAs
 // instead of 32, and the 256 x 128 workgroup tile stages 384 operand rows per 2x the products instead of 512: 0.75x the LDS traffic per MFMA.  One
 // register set of staged tiles (the k-tile's compute phase is twice as long); the output goes through the 128-row staging buffer in two halves.
-template <int PROBE = 0, int BM = G_BM>
+// SK: the split-K producer / consumer paths (ksplit, xparts, xbias) exist only in this instantiation -- in the plain one they cost 6 VGPRs the 128-row
+// shape does not have (250 -> 256 + 9 spilled: DiffSTG's step 9.2 -> 7.2 windows/s when they were runtime branches of the one kernel).
+template <int PROBE = 0, int BM = G_BM, bool SK = false>
 __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(const NstGemmHArgs p) {
     constexpr int MT = BM / 64;
     constexpr int SR = BM == 256 ? 128 : BM;                                   // rows of the output staging buffer
@@ -253,7 +266,10 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(cons
     const int wm = wave >> 1, wn = wave & 1;
     long long m0;
     int n0;
-    if (!gemm_tile<BM>(p.M, p.N, m0, n0)) return;
+    const int ksplit = (SK && p.ksplit > 1) ? p.ksplit : 1, split = ksplit > 1 ? (int)(blockIdx.x % ksplit) : 0;
+    if (!gemm_tile<BM>(p.M, p.N, m0, n0, ksplit > 1 ? (long long)(blockIdx.x / ksplit) : -1)) return;
+    const int nk_all = (PROBE & 2) ? 1 : p.ldw / G_BK, kchunk = (nk_all + ksplit - 1) / ksplit;
+    const int kt0 = split * kchunk, k0 = kt0 * G_BK;       // this workgroup's k-tiles: [kt0, kt0 + nk)
     const int lr = tid >> 3, lk = (tid & 7) * 4;           // X: rows lr + 32 j, 4 floats at lk
     const int wr = tid >> 2, wk = (tid & 3) * 8;           // W: rows wr + 64 j, 8 halves at wk
     const float* xa[2 * MT];
@@ -263,22 +279,32 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(cons
     for (int j = 0; j < 2 * MT; ++j) {
         long long r = m0 + lr + 32 * j;
         if (r >= p.M) r = p.M - 1;
-        xa[j] = p.X + (size_t)r * p.ldx + lk;
+        xa[j] = p.X + (size_t)r * p.ldx + lk + k0;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         int n = n0 + wr + 64 * j;
         if (n >= p.N) n = p.N - 1;
-        wh[j] = p.Wh + (size_t)n * p.ldw + wk;
-        wl[j] = p.Wl + (size_t)n * p.ldw + wk;
+        wh[j] = p.Wh + (size_t)n * p.ldw + wk + k0;
+        wl[j] = p.Wl + (size_t)n * p.ldw + wk + k0;
     }
     // Two register sets of staged tiles, so that a global load has two compute phases to land before it is written to LDS.
     struct Stage { v4f x[2 * MT]; h8 h[2], l[2]; };
-    Stage sa, sb;                                          // (BM = 256 never touches sb: dead, no registers)
+    Stage sa, sb;                                          // (BM = 256 and the split-K instance never touch sb: dead, no registers)
     auto fetch = [&](Stage& st, int kt) {
 #pragma unroll
-        for (int j = 0; j < 2 * MT; ++j)
-            st.x[j] = (kt * G_BK + lk < p.K) ? *reinterpret_cast<const v4f*>(xa[j] + (size_t)kt * G_BK) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < 2 * MT; ++j) {
+            if (k0 + kt * G_BK + lk < p.K) {
+                v4f v = *reinterpret_cast<const v4f*>(xa[j] + (size_t)kt * G_BK);
+                if constexpr (SK) {
+                    for (int s = 1; s < p.xparts; ++s) v += *reinterpret_cast<const v4f*>(xa[j] + (size_t)s * p.xpart + (size_t)kt * G_BK);   // partial sums of a split-K producer
+                    if (p.xbias) v += *reinterpret_cast<const v4f*>(p.xbias + k0 + kt * G_BK + lk);
+                }
+                st.x[j] = v;
+            } else {
+                st.x[j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             st.h[j] = *reinterpret_cast<const h8*>(wh[j] + (size_t)kt * G_BK);
@@ -316,7 +342,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(cons
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const int nk = (PROBE & 2) ? 1 : p.ldw / G_BK;
+    const int nk = kt0 >= nk_all ? 0 : (kt0 + kchunk <= nk_all ? kchunk : nk_all - kt0);      // (0: an empty split still writes its zero partial)
     const int li = lane & 31, lh = lane >> 5;
     // (row bases are multiples of 32, so the swizzle of a lane's rows depends on li alone: one pair of offsets per k-step, fixed for the kernel)
     const int a_row = wm * 32 * MT + li, b_row = wn * 64 + li;
@@ -350,10 +376,19 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(cons
                 }
         }
     };
+    const bool partial = ksplit > 1;
+    const float* e_bias = partial ? nullptr : p.bias;
+    const float* e_R = partial ? nullptr : p.R;
+    const int e_act = partial ? 0 : p.act;
+    float* e_Y = partial ? p.Y + (size_t)split * p.ypart : p.Y;
+    if (nk == 0) {
+        gemm_store_tile<(PROBE & 1) != 0, MT>(smem, acc, p.inv_scale, m0, n0, p.M, p.N, e_bias, e_act, e_R, p.ldr, e_Y, p.ldy);
+        return;
+    }
     fetch(sa, 0);
     stash(sa);
     if (nk > 1) fetch(sa, 1);
-    if constexpr (BM == 256) {                             // one register set: tile kt + 2 is requested once tile kt + 1 has left the registers
+    if constexpr (BM == 256 || SK) {                       // one register set: tile kt + 2 is requested once tile kt + 1 has left the registers
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             compute();                                     // tile kt
@@ -363,7 +398,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(cons
             __syncthreads();
             if (!(PROBE & 4) && kt + 2 < nk) fetch(sa, kt + 2);
         }
-        gemm_store_tile<(PROBE & 1) != 0, MT>(smem, acc, p.inv_scale, m0, n0, p.M, p.N, p.bias, p.act, p.R, p.ldr, p.Y, p.ldy);
+        gemm_store_tile<(PROBE & 1) != 0, MT>(smem, acc, p.inv_scale, m0, n0, p.M, p.N, e_bias, e_act, e_R, p.ldr, e_Y, p.ldy);
         return;
     }
     if (nk > 2) fetch(sb, 2);
@@ -382,7 +417,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(cons
         __syncthreads();
         if (!(PROBE & 4) && kt + 4 < nk) fetch(sb, kt + 4);
     }
-    gemm_store_tile<(PROBE & 1) != 0, MT>(smem, acc, p.inv_scale, m0, n0, p.M, p.N, p.bias, p.act, p.R, p.ldr, p.Y, p.ldy);
+    gemm_store_tile<(PROBE & 1) != 0, MT>(smem, acc, p.inv_scale, m0, n0, p.M, p.N, e_bias, e_act, e_R, p.ldr, e_Y, p.ldy);
 }
 
 // Launch on `stream`.  MPV_GEMM_BM=64 selects the 64-row workgroup tiles for every product (a tuning aid: at DiffSTG's BASELINE shapes they are
@@ -399,7 +434,13 @@ inline void nst_gemm_h3_launch(const NstGemmHArgs& a, hipStream_t stream) {
     // N = 512: 0.428 -> 0.417; N = 256: 0.230 -> 0.237; N = 512, K = 256: 0.278 -> 0.306 (the longer prologue / epilogue of a 256-row tile outweighs
     // the leaner k-loop once a row block has few N tiles) -- so only N >= 1024.  MPV_GEMM_BM=128 keeps the round-3 shape for A/B runs.
     const long long tiles256 = ((a.M + 255) / 256) * n_n;
-    if (bm_env == 256 || (bm_env == 0 && a.N >= 1024 && tiles256 >= 2048)) {
+    if (a.ksplit > 1 || a.xparts > 1 || a.xbias) {        // split-K producer / consumer: 128-row tiles, ksplit workgroups per tile (consecutive block ids)
+        const long long tiles = ((a.M + G_BM - 1) / G_BM) * n_n;
+        hipLaunchKernelGGL((nst_gemm_h3_kernel<0, 128, true>), dim3((unsigned)(8 * ((tiles + 7) / 8) * (a.ksplit > 1 ? a.ksplit : 1))), dim3(256), 0, stream, a);
+        return;
+    }
+    // (and K >= 256: DiffSTG's up-sampling products, N = 3200 at K = 80..160, are all epilogue -- 206 us per launch with 256-row tiles against 165)
+    if (bm_env == 256 || (bm_env == 0 && a.N >= 1024 && a.K >= 256 && tiles256 >= 2048)) {
         hipLaunchKernelGGL((nst_gemm_h3_kernel<0, 256>), dim3((unsigned)(8 * ((tiles256 + 7) / 8))), dim3(256), 0, stream, a);
         return;
     }

@@ -648,16 +648,35 @@ namespace {
         if (int rc_ = (expr)) return rc_; \
     } while (0)
 
+constexpr int STG_KSPLIT_MAX = 4;                       // partial buffers carved per row of the down-sampled features (e.z)
+
+// How many ways the k loop of a "downsampling" product [rows][K] x [N][K]^T is split (1 = not at all).  Round 4 measured negative: on the c5 step the
+// split products (MPV_STG_KSPLIT=0: as many ways as it takes to give the chip 3 workgroups per CU, at most 4; the graph-conv product sums the partial
+// tensors as it loads them, fixed order) average 84.9 us per launch against 75.8 us unsplit on the same box (8.64 against 8.83 windows/s) -- alone on the
+// device the long-K products are concurrency-bound (1.6-2.4 TB/s from 200-400 workgroups), inside the step the neighbouring launches' tails fill the
+// chip anyway.  Off unless MPV_STG_KSPLIT is set (n >= 2: that many ways; 0: the automatic rule).
+int down_ksplit(mpv_ctx* ctx, const StgEngine& e, const float* W, int K, int N, long long rows) {
+    static const int forced = getenv("MPV_STG_KSPLIT") ? atoi(getenv("MPV_STG_KSPLIT")) : 1;
+    if (e.d.gemm == MPV_GEMM_F32 || e.split.find(W) == e.split.end() || K % 4 != 0 || N % 4 != 0) return 1;
+    if (forced >= 1) return std::min(forced, STG_KSPLIT_MAX);
+    const long long tiles = ((rows + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
+    int ks = 1;
+    while (ks < STG_KSPLIT_MAX && tiles * ks < 3LL * ctx->cu_count && K / (2 * ks) >= 256) ks *= 2;
+    return ks;
+}
+
 int gemm(mpv_ctx* ctx, const StgEngine& e, const float* X, long long ldx, const float* W, const float* bias, int K, int N, long long rows, float* Y, long long ldy,
-         int relu = 0, const float* r1 = nullptr) {
+         int relu = 0, const float* r1 = nullptr, int ksplit = 1, long long ypart = 0, int xparts = 1, long long xpart = 0, const float* xbias = nullptr) {
     const auto sp = e.split.find(W);
     if (e.d.gemm != MPV_GEMM_F32 && sp != e.split.end() && K % 4 == 0 && N % 4 == 0) {
         // two-term f16 split on the f16 matrix pipe, fp32-equivalent: the k = T+1 convolutions and the graph-conv Linear maps
         NstGemmHArgs a{X, ldx, sp->second.h, sp->second.l, sp->second.inv_scale, bias, r1, ldy, Y, ldy, rows, N, K, relu, sp->second.ldw};
+        a.ksplit = ksplit; a.ypart = ypart; a.xparts = xparts; a.xpart = xpart; a.xbias = xbias;
         nst_gemm_h3_launch(a, ctx->stream);
         MPV_HIP_TRY(ctx, hipGetLastError());
         return MPV_OK;
     }
+    if (ksplit > 1 || xparts > 1) return mpv_fail(ctx, MPV_ESTATE, "DiffSTG: split-K products need the split-f16 GEMM");
     int KC = 64;
     if (K < 64) KC = (K + 15) & ~15;
     GemmArgs a{X, ldx, W, bias, Y, ldy, rows, K, N, KC, relu, r1};
@@ -685,7 +704,7 @@ int carve(mpv_ctx* ctx, StgEngine& e, long long N) {
         max_c = std::max(max_c, (size_t)s.c_out);
     }
     const size_t C = (size_t)e.d.Td_h * max_c;
-    const size_t o_hn = take((size_t)N * max_ct), o_z = take((size_t)N * C), o_kqvs = take((size_t)N * 4 * C), o_sp = take((size_t)N * C),
+    const size_t o_hn = take((size_t)N * max_ct), o_z = take((size_t)N * C * STG_KSPLIT_MAX), o_kqvs = take((size_t)N * 4 * C), o_sp = take((size_t)N * C),
                  o_up = take((size_t)N * max_ct), o_e1 = take((size_t)N * Fo * T2), o_eps = take((size_t)N * F * Ts),
                  o_xt = take((size_t)N * Ts * F), o_xm = take((size_t)N * Ts * F), o_nz = take((size_t)N * Ts * F),
                  o_sig = take(e.mode ? (size_t)N * Ts * F : 0), o_e2 = take(e.mode ? (size_t)N * Fo * T2 : 0), o_gg = take(e.mode ? (size_t)N * Ts * F : 0);
@@ -831,8 +850,15 @@ int unet(mpv_ctx* ctx, StgEngine& e, long long N, int t, const float** out_cur) 
 #undef STG_TCN
                 MPV_HIP_TRY(ctx, hipGetLastError());
             }
-            STG_TRY(gemm(ctx, e, e.hn, (long long)co * s.T, s.r.wdown, s.r.bdown, co * s.T, C, N, e.z, C));
-            STG_TRY(gemm(ctx, e, e.z, C, s.r.wg, s.r.bg4, C, 4 * C, N, e.kqvs, 4 * C));
+            // long-K, narrow-N: split the k loop over up to four workgroups per tile; the graph-conv product sums the partials (+ the bias) as it loads them
+            const int ks = down_ksplit(ctx, e, s.r.wdown, co * s.T, C, N);
+            if (ks > 1) {
+                STG_TRY(gemm(ctx, e, e.hn, (long long)co * s.T, s.r.wdown, nullptr, co * s.T, C, N, e.z, C, 0, nullptr, ks, (long long)N * C));
+                STG_TRY(gemm(ctx, e, e.z, C, s.r.wg, s.r.bg4, C, 4 * C, N, e.kqvs, 4 * C, 0, nullptr, 1, 0, ks, (long long)N * C, s.r.bdown));
+            } else {
+                STG_TRY(gemm(ctx, e, e.hn, (long long)co * s.T, s.r.wdown, s.r.bdown, co * s.T, C, N, e.z, C));
+                STG_TRY(gemm(ctx, e, e.z, C, s.r.wg, s.r.bg4, C, 4 * C, N, e.kqvs, 4 * C));
+            }
             hipLaunchKernelGGL(stg_gate_kernel, g1d(N * C), dim3(256), 0, st, e.kqvs, s.r.gbias, e.graph, e.graph + e.V + 1, e.V, C, N * C, e.sp);
             MPV_HIP_TRY(ctx, hipGetLastError());
             // up-sampling product with the block's shortcut added in its epilogue: the block input itself (identity) or the 1x1
