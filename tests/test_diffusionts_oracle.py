@@ -102,3 +102,32 @@ def test_eta_sampler_matches_reference_and_host_plan_carries_sigma():
             assert row[10] == float(sigma) and row[5] == float((1 - an - sigma ** 2).sqrt())
     m0 = diffusion_models("DiffusionTS", dict(par, device="cpu", scaler_type="StandardScaler"))
     assert float(m0._plan()[:, 10].abs().max()) == 0.0
+
+
+def test_full_plan_fixture_small_model_and_c3full_header():
+    """tests/golden/diffusionts_c3full.npz (make_golden_diffusionts_c3full.py, round 4): the REAL 100 / 100-step plan -- 100 model_predictions + 128
+    Langevin forward / backward passes per chain with the K in {0, 1, 2, 3} thresholds of DiffusionTS.py:359-407 -- run by the reference itself.
+    `t100`: a small model with every draw recorded; the oracle replays it.  `c3full`: 25 nodes x 32 samples = 800 sequences of the BASELINE
+    configs[2] model in one chunk (85 minutes of 6 CPU threads); only its header is checked here, the -m gpu test compares the device run."""
+    from conftest import GOLDEN
+    z = np.load(GOLDEN / "diffusionts_c3full.npz")
+    w, o, nf, d, le, ld, nh, ts, steps, nz, par = (int(v) for v in z["cfg_t100"])
+    assert ts == 100 and steps == 100
+    sd = {k[len("sd_t100_"):]: T(z[k]) for k in z.files if k.startswith("sd_t100_")}
+    cfg = D.DTSConfig(windows=w, pred_len=o, nf=nf, d_model=d, n_layer_enc=le, n_layer_dec=ld, n_heads=nh, timesteps=ts, sampling_timesteps=steps,
+                      n_z_samples=nz, parallel_sample=par)
+    L, rows = w + o, par * 2
+    draws = T(z["eval_t100_noise"]).reshape(-1, rows, L, nf)
+    assert draws.shape[0] == (nz // par) * 327                               # 1 + sum over the 99 pairs of (2 + K): 1 + 198 + 128 per chunk
+    it = iter(draws.unbind(0))
+    used = []
+    out = D.evaluation_step(sd, cfg, T(z["batch_t100"]), lambda shape: next(it).reshape(shape), record=used)
+    want = z["eval_t100_out"]
+    err = float(np.abs(out.detach().numpy() - want).max() / np.abs(want).max())
+    print("DiffusionTS oracle on the 100 / 100-step plan (small model): max rel err %.3e over %d draws" % (err, len(used)))
+    assert len(used) == draws.shape[0] and err < 2e-4
+    nodes, n_z, n_steps = (int(v) for v in z["c3full_cfg"][:3])
+    assert (nodes, n_z, n_steps) == (25, 32, 100) and tuple(z["c3full_out"].shape) == (25, 100, 1, 32) and tuple(z["c3full_hist"].shape) == (25, 100, 1)
+    x = z["c3full_out"].astype(np.float64)
+    assert abs(float(x.var(axis=-1).mean()) - float(z["c3full_mpv"])) < 1e-12 and abs(float(x.mean()) - float(z["c3full_pred_mean"])) < 1e-12
+    assert np.isfinite(x).all() and np.abs(x).max() <= 1.0 + 1e-6              # the last step returns the clamped x0 estimate

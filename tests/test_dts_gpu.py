@@ -163,6 +163,27 @@ def test_evaluation_step_matches_reference(tag, gemm):
     assert err < 1e-2 and abs(mpv_g - mpv_w) <= RTOL * abs(mpv_w)
 
 
+@pytest.mark.parametrize("gemm", ["f16x3", "f32"])
+def test_evaluation_step_on_the_full_100_step_plan_small_model(gemm):
+    """The reference's evaluation_step of a small model on the REAL plan (timesteps = diffusion_steps = 100: K = 3 / 2 / 1 / 0 Langevin iterations by t,
+    654 recorded draws; tests/golden/make_golden_diffusionts_c3full.py, case t100) with its draws injected."""
+    from conftest import GOLDEN
+    from mpv_amd.models.models import diffusion_models
+    z = np.load(GOLDEN / "diffusionts_c3full.npz")
+    par = dict(zip(KEYS, [int(v) for v in z["cfg_t100"]]))
+    m = diffusion_models("DiffusionTS", dict(par, device="cpu", scaler_type="StandardScaler", gemm_mode=gemm))
+    m.load_state_dict({k[len("sd_t100_"):]: T(z[k]) for k in z.files if k.startswith("sd_t100_")}, strict=True)
+    m = m.to(dev()).eval()
+    plan = m._plan()
+    assert plan.shape[0] == 100 and int(plan[:, 6].sum()) == 128 and sorted(set(int(k) for k in plan[:, 6].tolist())) == [0, 1, 2, 3]
+    outs, _ = m.evaluation_step(T(z["batch_t100"]), noise=T(z["eval_t100_noise"]))
+    want = z["eval_t100_out"]
+    err = rel_err(outs, want)
+    mpv_g, mpv_w = outs.var(dim=-1, unbiased=False).mean().item(), T(want).var(dim=-1, unbiased=False).mean().item()
+    print("DiffusionTS evaluation_step, 100 / 100-step plan, small model (%s): samples vs reference %.3e; MPV %.6g vs %.6g" % (gemm, err, mpv_g, mpv_w))
+    assert err < 1e-2 and abs(mpv_g - mpv_w) <= RTOL * abs(mpv_w)
+
+
 def test_evaluation_step_torch_cpu_stream_and_philox_mode():
     """noise_source='torch_cpu' under the reference's seed == the reference run; the default Philox mode is repeatable under
     torch.manual_seed, changes with the seed, and several windows in one call equal the windows one by one."""

@@ -134,6 +134,50 @@ def test_c3_full_window_subset_against_oracle_statistically(c3):
     assert abs(mpv_g - mpv_w) <= 0.10 * abs(mpv_w)
 
 
+def test_c3_real_plan_window_against_the_reference_run():
+    """A BASELINE configs[2] window on the REAL sampling plan held by the REFERENCE: tests/golden/diffusionts_c3full.npz is the
+    reference's own DiffusionTS_model.evaluation_step (DiffusionTS_model.py:72-109 -> DiffusionTS.py:277-310, 359-407) on the C3 model with
+    diffusion_steps = 100 -- 228 forward + 128 backward passes -- for 25 nodes x N = 32 = 800 sequences in one chunk under torch.manual_seed (85 minutes
+    of 6 CPU threads in the build container; the batch size enters through the Langevin loss normalisers, so 800 is part of the case).  The device run
+    replays the same torch CPU stream (noise_source = 'torch_cpu': 327 draws x 800 x 200).  The sampler is sign descent around a top-k frequency
+    selection, chaotic at the sample level (the reference's own float64 re-run leaves its float32 trajectory), so sequences either
+    stay on the reference's trajectory or leave it; what must agree is the STATISTIC the path exists for -- MPV and pred_mean over the 80 000 (node,
+    horizon) rows -- and the test reports the fraction of sequences still within 1e-2 of the reference's."""
+    from conftest import GOLDEN
+    from mpv_amd.bench_dts import C3
+    from mpv_amd.models.models import diffusion_models
+    z = np.load(GOLDEN / "diffusionts_c3full.npz")
+    nodes, n_z, steps, seed_w, _seed_h, seed_run = (int(v) for v in z["c3full_cfg"])
+    net = dict(device=dev(), scaler_type="StandardScaler", task_model="DiffusionTS", dataset_nf=C3["nf"], windows=C3["windows"], pred_len=C3["pred_len"],
+               d_model=C3["d_model"], n_heads=C3["n_heads"], n_layer_enc=C3["n_layer_enc"], n_layer_dec=C3["n_layer_dec"], timesteps=C3["timesteps"],
+               diffusion_steps=steps, n_z_samples=n_z, parallel_sample=n_z, noise_source="torch_cpu")
+    torch.manual_seed(seed_w)
+    model = diffusion_models("DiffusionTS", net).to(dev()).eval()
+    check = np.array([float(v.double().abs().sum()) for _, v in sorted(model.state_dict().items()) if v.dtype.is_floating_point])
+    np.testing.assert_allclose(check, z["c3full_state_checksum"], rtol=1e-12, err_msg="the seeded weights differ from the ones the reference ran")
+    hist = torch.from_numpy(z["c3full_hist"])
+    torch.manual_seed(seed_run)
+    outs, _ = model.evaluation_step(hist)                                         # [25, 100, 1, 32] on the host
+    want = torch.from_numpy(z["c3full_out"])
+    assert tuple(outs.shape) == tuple(want.shape) and bool(torch.isfinite(outs).all())
+    mpv_g, pm_g = mpv64(outs)
+    mpv_w, pm_w = float(z["c3full_mpv"]), float(z["c3full_pred_mean"])
+    g_seq, w_seq = outs.permute(0, 3, 1, 2).reshape(nodes * n_z, -1), want.permute(0, 3, 1, 2).reshape(nodes * n_z, -1)
+    per_seq = np.array([rel_err(g_seq[i], w_seq[i]) for i in range(g_seq.shape[0])])
+    frac = float((per_seq < 1e-2).mean())
+    row_var_g, row_var_w = outs.double().var(dim=-1, unbiased=False).flatten(), want.double().var(dim=-1, unbiased=False).flatten()
+    corr = float(torch.corrcoef(torch.stack([row_var_g, row_var_w]))[0, 1])
+    print("C3 real plan (228 + 128 passes), 800 sequences vs the REFERENCE's run: MPV %.6g vs %.6g (rel %.2e), pred_mean %.5g vs %.5g; %.1f %% of the sequences within 1e-2 "
+          "(median per-sequence err %.2e); correlation of the per-row variances %.3f" % (mpv_g, mpv_w, abs(mpv_g - mpv_w) / mpv_w, pm_g, pm_w, 100 * frac,
+                                                                                      float(np.median(per_seq)), corr))
+    # Measured (round 4): MPV 0.829606 vs the reference's 0.826119 (0.42 %), pred_mean 0.0239 vs 0.0214, 28 % of the 800 sequences still within 1e-2 of
+    # the reference's after 128 sign-descent iterations, per-row variances correlated at 0.80.  Tolerance: the sequences that left the trajectory are
+    # fresh draws of the same distribution, so the two MPVs are two estimates of one population value -- the reference's own float32-vs-float64 runs
+    # of the small fixtures differ by 1.6-7 % in MPV (DESIGN section 4).  2 % bounds a systematic error (a wrong normaliser, row index or plan row moves the
+    # MPV by tens of percent) and, with >= 15 % of the sequences required on the trajectory, the case cannot pass on statistics alone.
+    assert abs(mpv_g - mpv_w) <= 0.02 * mpv_w and abs(pm_g - pm_w) <= 0.01 and frac >= 0.15 and corr >= 0.6
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # C5: DiffSTG, 200-node small-world graph x 32 copies = 6400 node rows, 50 inference steps
 # ---------------------------------------------------------------------------------------------------------------------------------
