@@ -55,6 +55,11 @@ struct DtsEngine {
           *delta = nullptr, *gseason = nullptr, *gmeans = nullptr, *gout = nullptr, *gx = nullptr;
     // sampler state [B][L][F]
     float *img = nullptr, *target = nullptr, *xstart = nullptr, *pmean = nullptr, *noise = nullptr;
+    // Round 4: the three consumers of a decoder block's x2 -- trend block, Fourier layer (token mixing, selection, synthesis), MLP -- are independent
+    // until the mean removal; the first two are short latency-bound kernels (1.2-3 TB/s alone on the device), so they run on two auxiliary streams
+    // beside the MLP (fork / join with events; every buffer is written by one branch only, so the arithmetic is unchanged).  MPV_DTS_STREAMS=0: one stream.
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     bool snapshots = false;                          // mpv_dts_vjp: keep the gradient at the encoder output for mpv_dts_debug_tensor
     // Attention operands (Q | K | V, attention output, and their gradients) in 16-column BLOCKED layout [block][tokens][16] when a head is 16
     // wide: a (sequence, head) tile is then 12.8 KB of contiguous memory instead of 64-byte pieces of 768-byte rows (half of every 128-byte
@@ -424,6 +429,26 @@ int mlp_block(mpv_ctx* ctx, DtsEngine& e, const float* x, const float* lnw, cons
     return lin(ctx, u, e.M, w2, b2, e.M, e.D, T, out, e.D, PRO_GELU, nullptr, nullptr, 0, x, e.D);
 }
 
+// the auxiliary streams of the decoder's fork (created on first use); false: everything on ctx->stream
+bool aux_streams(mpv_ctx* ctx, DtsEngine& e) {
+    static const bool off = getenv("MPV_DTS_STREAMS") && atoi(getenv("MPV_DTS_STREAMS")) == 0;
+    if (off) return false;
+    if (e.aux[0]) return true;
+    for (int i = 0; i < 2; ++i) {
+        if (hipStreamCreateWithFlags(&e.aux[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e.ev_join[i], hipEventDisableTiming) != hipSuccess) {
+            e.aux[0] = e.aux[1] = nullptr;
+            return false;
+        }
+    }
+    if (hipEventCreateWithFlags(&e.ev_fork, hipEventDisableTiming) != hipSuccess) { e.aux[0] = e.aux[1] = nullptr; return false; }
+    return true;
+}
+struct StreamSwap {                                   // ctx->stream = s for the scope (the launch helpers read it)
+    mpv_ctx* ctx; hipStream_t keep;
+    StreamSwap(mpv_ctx* c, hipStream_t s) : ctx(c), keep(c->stream) { c->stream = s; }
+    ~StreamSwap() { ctx->stream = keep; }
+};
+
 // ---- forward: Transformer.forward (transformer.py:422-438); save = the input-gradient pass follows ----------------------------
 int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t, bool save) {
     const int L = e.L, F = e.F, D = e.D, H = e.H, M = e.M;
@@ -468,11 +493,22 @@ int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t, bool save)
         DTS_TRY(lin(ctx, s.att2, l1, w.wp2, w.bp2, D, D, T, s.x2, D, PRO_NONE, nullptr, nullptr, 0, s.x1, D, 0, blk));
         // proj (Conv1d(L -> 2L, k=1) over the token axis) folded into its two consumers: trend block on x2 with composite taps, and
         // the selected spectrum as ONE token mix with (DFT basis x proj[L:])
-        hipLaunchKernelGGL(dts_trend_fwd_kernel, dim3(B), dim3(256), sizeof(float) * (15 * D + 3 * F), st, s.x2, (long long)L * D, w.tw0, w.tb0, w.tw3, w.tb3,
+        const bool fork = aux_streams(ctx, e);
+        hipStream_t s_trend = st, s_four = st;
+        if (fork) {
+            MPV_HIP_TRY(ctx, hipEventRecord(e.ev_fork, st));
+            MPV_HIP_TRY(ctx, hipStreamWaitEvent(e.aux[0], e.ev_fork, 0));
+            MPV_HIP_TRY(ctx, hipStreamWaitEvent(e.aux[1], e.ev_fork, 0));
+            s_trend = e.aux[0];
+            s_four = e.aux[1];
+        }
+        hipLaunchKernelGGL(dts_trend_fwd_kernel, dim3(B), dim3(256), sizeof(float) * (15 * D + 3 * F), s_trend, s.x2, (long long)L * D, w.tw0, w.tb0, w.tw3, w.tb3,
                            e.poly, L, F, D, s.t3, e.trend_sum);
         MPV_HIP_TRY(ctx, hipGetLastError());
+        if (fork) MPV_HIP_TRY(ctx, hipEventRecord(e.ev_join[0], s_trend));
         {
             static const bool mix_exact = getenv("MPV_DTS_MIX_F32") != nullptr;          // A/B aid: the token mixing on the fp32 matrix pipe
+            StreamSwap on_branch(ctx, s_four);                                            // the launch helpers enqueue on ctx->stream
             int rc = -100;
             if (e.d.gemm != MPV_GEMM_F32 && !mix_exact)
                 rc = seqmix_h(ctx, D, w.wdft_h, w.wdft_l, w.wdft_isw, 2 * e.NFp, (L + 31) & ~31, w.bdft, s.x2, (long long)L * D, D, L, e.spec, 2LL * e.NFp * D, D,
@@ -480,11 +516,16 @@ int forward(mpv_ctx* ctx, DtsEngine& e, const float* x, int B, int t, bool save)
             if (rc == -100) rc = seqmix(ctx, D, w.wdft, 2 * e.NFp, e.Lp, w.bdft, s.x2, (long long)L * D, D, L, e.spec, 2LL * e.NFp * D, D, 2 * e.NFp, B);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(dts_fourier_select_kernel, g1d((long long)B * D), dim3(256), 0, st, e.spec, e.NF, e.NFp, D, e.topk, (long long)B * D, s.fidx,
+        hipLaunchKernelGGL(dts_fourier_select_kernel, g1d((long long)B * D), dim3(256), 0, s_four, e.spec, e.NF, e.NFp, D, e.topk, (long long)B * D, s.fidx,
                            e.famp, e.fph);
-        hipLaunchKernelGGL(dts_fourier_synth_kernel, dim3(B), dim3(256), 0, st, s.fidx, e.famp, e.fph, e.freq + 1, L, D, e.topk, e.season_sum);
+        hipLaunchKernelGGL(dts_fourier_synth_kernel, dim3(B), dim3(256), 0, s_four, s.fidx, e.famp, e.fph, e.freq + 1, L, D, e.topk, e.season_sum);
         MPV_HIP_TRY(ctx, hipGetLastError());
+        if (fork) MPV_HIP_TRY(ctx, hipEventRecord(e.ev_join[1], s_four));
         DTS_TRY(mlp_block(ctx, e, s.x2, w.ln2w, w.ln2b, w.w0, w.b0, w.w2, w.b2, s.u, e.x3, T, save));
+        if (fork) {
+            MPV_HIP_TRY(ctx, hipStreamWaitEvent(st, e.ev_join[0], 0));
+            MPV_HIP_TRY(ctx, hipStreamWaitEvent(st, e.ev_join[1], 0));
+        }
         hipLaunchKernelGGL(dts_meansub_fwd_kernel, dim3(B), dim3(256), sizeof(float) * (256 + D), st, e.x3, w.wlin, w.blin, L, F, D, e.xd[i + 1],
                            e.means + (size_t)i * F, e.d.n_dec * F);
         MPV_HIP_TRY(ctx, hipGetLastError());
@@ -640,6 +681,11 @@ void dts_engine_destroy(DtsEngine* e) {
     if (!e) return;
     if (e->blob) (void)hipFree(e->blob);
     if (e->ws) (void)hipFree(e->ws);
+    for (int i = 0; i < 2; ++i) {
+        if (e->aux[i]) { (void)hipStreamSynchronize(e->aux[i]); (void)hipStreamDestroy(e->aux[i]); }
+        if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
+    }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     delete e;
 }
 

@@ -48,13 +48,13 @@ constexpr int C_LD = G_BN + 4;                  // floats per row of the output 
 // Output tile: accumulators -> LDS [128][C_LD] -> rows of 512 contiguous bytes (a wave writes two whole rows per instruction; the
 // accumulator layout itself would give 128-byte pieces of 64 different rows).  Bias, activation and residual are applied on the way out.
 // N must be a multiple of 4.
-template <bool PROBE_NO_STORE = false, int MT = 2>      // MT: 32-row accumulator tiles per wave (the workgroup tile has BM = 64 MT rows)
+template <bool PROBE_NO_STORE = false, int MT = 2, bool HALF_STAGE = false>      // MT: 32-row accumulator tiles per wave (the workgroup tile has BM = 64 MT rows)
 __device__ __forceinline__ void gemm_store_tile(float* Cs, const v16f (&acc)[MT][2], float scale, long long m0, int n0, long long M, int N, const float* bias,
                                                 int act, const float* R, long long ldr, float* Y, long long ldy) {
     constexpr int BM = 64 * MT;
-    // MT = 4 (256-row workgroup tiles, round 4): the staging buffer holds 128 rows, so the two wave rows (wm = 0, 1: 128 output rows each) go through
-    // it one after the other
-    constexpr int HALVES = MT == 4 ? 2 : 1, HR = BM / HALVES;
+    // MT = 4 (256-row workgroup tiles, round 4) and HALF_STAGE: the staging buffer holds half the tile's rows, so the two wave rows (wm = 0, 1) go
+    // through it one after the other
+    constexpr int HALVES = (MT == 4 || HALF_STAGE) ? 2 : 1, HR = BM / HALVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
     const int c4e = (tid & 31) * 4;
     const bool add_r = R && act != 3 && n0 + c4e < N;
@@ -251,10 +251,16 @@ __device__ __forceinline__ int h_off(int row, int half) {        // offset (halv
 // register set of staged tiles (the k-tile's compute phase is twice as long); the output goes through the 128-row staging buffer in two halves.
 // SK: the split-K producer / consumer paths (ksplit, xparts, xbias) exist only in this instantiation -- in the plain one they cost 6 VGPRs the 128-row
 // shape does not have (250 -> 256 + 9 spilled: DiffSTG's step 9.2 -> 7.2 windows/s when they were runtime branches of the one kernel).
-template <int PROBE = 0, int BM = G_BM, bool SK = false>
-__global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(const NstGemmHArgs p) {
+// LITE (BM = 128 only): one register set of staged tiles and a 64-row output staging buffer -- <= 168 VGPRs and 34 KB of LDS, so THREE workgroups share
+// a CU (three waves per SIMD) where the full shape has two.
+template <int PROBE = 0, int BM = G_BM, bool SK = false, bool LITE = false>
+#ifndef NST_LITE_WGS
+#define NST_LITE_WGS 3
+#endif
+__global__ __launch_bounds__(256, LITE ? NST_LITE_WGS : (BM == 64 ? 3 : 2)) void nst_gemm_h3_kernel(const NstGemmHArgs p) {
     constexpr int MT = BM / 64;
-    constexpr int SR = BM == 256 ? 128 : BM;                                   // rows of the output staging buffer
+    constexpr int SR = BM == 256 ? 128 : (LITE ? BM / 2 : BM);                  // rows of the output staging buffer
+    static_assert(!LITE || BM == 128, "LITE is a variant of the 128-row shape");
     static_assert(BM == 64 || BM == 128 || BM == 256, "workgroup tile rows");
     static_assert((2 * BM + 2 * G_BN) * H_LD * 2 <= SR * C_LD * 4, "the operand tiles fit the output tile's LDS");
     __shared__ __attribute__((aligned(16))) float smem[SR * C_LD];             // operand tiles, then the output tile
@@ -382,13 +388,13 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(cons
     const int e_act = partial ? 0 : p.act;
     float* e_Y = partial ? p.Y + (size_t)split * p.ypart : p.Y;
     if (nk == 0) {
-        gemm_store_tile<(PROBE & 1) != 0, MT>(smem, acc, p.inv_scale, m0, n0, p.M, p.N, e_bias, e_act, e_R, p.ldr, e_Y, p.ldy);
+        gemm_store_tile<(PROBE & 1) != 0, MT, LITE>(smem, acc, p.inv_scale, m0, n0, p.M, p.N, e_bias, e_act, e_R, p.ldr, e_Y, p.ldy);
         return;
     }
     fetch(sa, 0);
     stash(sa);
     if (nk > 1) fetch(sa, 1);
-    if constexpr (BM == 256 || SK) {                       // one register set: tile kt + 2 is requested once tile kt + 1 has left the registers
+    if constexpr (BM == 256 || SK || LITE) {               // one register set: tile kt + 2 is requested once tile kt + 1 has left the registers
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             compute();                                     // tile kt
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void nst_gemm_h3_kernel(cons
             __syncthreads();
             if (!(PROBE & 4) && kt + 2 < nk) fetch(sa, kt + 2);
         }
-        gemm_store_tile<(PROBE & 1) != 0, MT>(smem, acc, p.inv_scale, m0, n0, p.M, p.N, e_bias, e_act, e_R, p.ldr, e_Y, p.ldy);
+        gemm_store_tile<(PROBE & 1) != 0, MT, LITE>(smem, acc, p.inv_scale, m0, n0, p.M, p.N, e_bias, e_act, e_R, p.ldr, e_Y, p.ldy);
         return;
     }
     if (nk > 2) fetch(sb, 2);
@@ -440,16 +446,22 @@ inline void nst_gemm_h3_launch(const NstGemmHArgs& a, hipStream_t stream) {
         return;
     }
     // (and K >= 256: DiffSTG's up-sampling products, N = 3200 at K = 80..160, are all epilogue -- 206 us per launch with 256-row tiles against 165)
-    if (bm_env == 256 || (bm_env == 0 && a.N >= 1024 && a.K >= 256 && tiles256 >= 2048)) {
+    if (bm_env == 256) {                                  // (superseded as a default by the three-workgroup shape below: QKV 1.077 ms against 0.984)
         hipLaunchKernelGGL((nst_gemm_h3_kernel<0, 256>), dim3((unsigned)(8 * ((tiles256 + 7) / 8))), dim3(256), 0, stream, a);
         return;
     }
     if (rows64) {
         const long long tiles = ((a.M + 63) / 64) * n_n;
         hipLaunchKernelGGL((nst_gemm_h3_kernel<0, 64>), dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(256), 0, stream, a);
-    } else {
+    } else if (bm_env == 128) {                           // the round-3 shape: two register sets of staged tiles, whole-tile output staging, 2 workgroups per CU
         const long long tiles = ((a.M + G_BM - 1) / G_BM) * n_n;
         hipLaunchKernelGGL((nst_gemm_h3_kernel<0, 128>), dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(256), 0, stream, a);
+    } else {
+        // Default (round 4): the same 128 x 128 tile with ONE register set and a half-tile output staging buffer -- 164 VGPRs, 34 KB of LDS, three
+        // workgroups per CU.  tools/ubench/gemm_h3 on a 216 800-row pass: QKV 1.165 -> 0.984 ms (347 TFLOP/s), out + residual 0.418 -> 0.376,
+        // FFN 0.222 -> 0.199 and 0.278 -> 0.243; the k loop alone 0.765 -> 0.636 ms.  (Four per CU would need <= 128 VGPRs: 65 spilled, 3.9 ms.)
+        const long long tiles = ((a.M + G_BM - 1) / G_BM) * n_n;
+        hipLaunchKernelGGL((nst_gemm_h3_kernel<0, 128, false, true>), dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(256), 0, stream, a);
     }
 }
 
