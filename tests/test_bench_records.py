@@ -103,10 +103,15 @@ def test_pmc_traffic_is_bound_to_the_binary(tmp_path):
     roof = BC.multi_kernel_roofline(tr, 0.25, 120.0, "f16x3", "kernels")
     assert roof["bound"] == "hbm" and roof["traffic"] == 8.0e12 and abs(roof["achieved"] - 2000.0) < 1e-9 and abs(roof["frac"] - 0.25) < 1e-12
     lib.write_bytes(b"binary two")
-    tr = BC.measured_traffic("c3", root=str(tmp_path), lib_hash=BC.lib_sha256(str(lib)))
+    tr = BC.measured_traffic("c3", root=str(tmp_path), lib_hash=BC.lib_sha256(str(lib)), src_hash="unrelated")
     assert tr["stale"] is True
     roof = BC.multi_kernel_roofline(tr, 0.25, 120.0, "f16x3", "kernels")
     assert roof["traffic"] is None and roof["traffic_stale"] is True and roof["bound"] == "mfma"
+    # a rebuild of UNCHANGED sources (another box, another hash of the .so) keeps the measurement; changed sources do not
+    (d / "pmc_traffic_c3.json").write_text(json.dumps({"_lib_sha256": sha, "_csrc_sha256": "s1", "bytes_per_window": 8.0e12}))
+    other = BC.lib_sha256(str(lib))
+    assert BC.measured_traffic("c3", root=str(tmp_path), lib_hash=other, src_hash="s1")["stale"] is False
+    assert BC.measured_traffic("c3", root=str(tmp_path), lib_hash=other, src_hash="s2")["stale"] is True
     (d / "pmc_traffic_c3.json").write_text(json.dumps({"bytes_per_window": 8.0e12}))       # a file from before the binding: never quoted
     assert BC.measured_traffic("c3", root=str(tmp_path), lib_hash=sha)["stale"] is True
     assert BC.measured_traffic("nope", root=str(tmp_path)) is None

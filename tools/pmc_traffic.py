@@ -29,7 +29,7 @@ def binary_identity():
         info = json.load(open(os.path.join(ROOT, "unsupervised-probing-using-generative-diffusion-models_amd", "build_info.json")))
     except (OSError, ValueError):
         pass
-    return bc.lib_sha256(), info.get("commit"), info.get("dirty")
+    return bc.lib_sha256(), info.get("commit"), info.get("dirty"), bc.csrc_sha256(ROOT)
 
 
 def short(name):
@@ -78,8 +78,8 @@ def main():
         kernels[k] = rec
         total += rec["hbm_bytes"]
     top = sorted(kernels.items(), key=lambda kv: -kv[1].get("share_pct", 0.0))
-    sha, commit, dirty = binary_identity()
-    res = {"_how": how, "_lib_sha256": sha, "_commit": commit, "_commit_dirty": dirty, "_correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KB) x 1024 x 2 (gfx950 reports half of wide coalesced reads), "
+    sha, commit, dirty, src = binary_identity()
+    res = {"_how": how, "_lib_sha256": sha, "_csrc_sha256": src, "_commit": commit, "_commit_dirty": dirty, "_correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KB) x 1024 x 2 (gfx950 reports half of wide coalesced reads), "
                                        "WRITE_SIZE (KB) x 1024 exact; separate --pmc passes, durations from a third --kernel-trace --stats pass",
            "windows_in_step": windows, "hbm_bytes_total": total, "bytes_per_window": total / max(windows, 1),
            "dominant_kernel": top[0][0] if top else None, "kernels": dict(top)}

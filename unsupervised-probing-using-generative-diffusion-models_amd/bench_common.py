@@ -54,15 +54,37 @@ def lib_sha256(path=None):
         return None
 
 
-def measured_traffic(key, root=None, lib_hash=None):
+def csrc_sha256(root=None):
+    """sha256 over the kernel sources the library is built from (csrc/*.hip, csrc/*.h, include/mpv_hip.h, build.py's flags), in sorted order: the
+    identity of the BINARY'S SOURCE, unchanged by a rebuild.  None when the sources are not there."""
+    import glob
+    import hashlib
+    pkg = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.h")))
+    files += [os.path.join(root or repo_root(), "include", "mpv_hip.h"), os.path.join(pkg, "build.py")]
+    h = hashlib.sha256()
+    try:
+        for f in files:
+            h.update(os.path.basename(f).encode())
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    except OSError:
+        return None
+    return h.hexdigest()
+
+
+def measured_traffic(key, root=None, lib_hash=None, src_hash=None):
     """Per-kernel HBM traffic of one bench step from the committed PMC passes (profiles/*/pmc_traffic_<key>.json, written by
     tools/pmc_traffic.py: separate FETCH_SIZE and WRITE_SIZE passes, FETCH doubled as the guide prescribes for gfx950); newest round
-    first, None when there is none.  A file measured on ANOTHER binary than the one loaded now (its `_lib_sha256` differs from this
-    library's, or it carries none) is returned with `stale = True`: the caller must not quote its bytes as this run's traffic."""
+    first, None when there is none.  A file measured on ANOTHER binary than the one loaded now is returned with `stale = True` and the caller
+    must not quote its bytes as this run's traffic: the file's `_lib_sha256` must equal this library's, or -- a rebuild of unchanged sources on
+    another box -- its `_csrc_sha256` the hash of the sources in the tree; a file that carries neither is always stale."""
     import glob
     import json
     root = root or repo_root()
     lib_hash = lib_hash or lib_sha256()
+    if src_hash is None and os.environ.get("MPV_LIB") is None:          # (an explicitly chosen library is identified by its own hash only)
+        src_hash = csrc_sha256()
     for f in sorted(glob.glob(os.path.join(root, "profiles", "*", "pmc_traffic_%s.json" % key)), reverse=True):
         try:
             with open(f) as fh:
@@ -70,7 +92,9 @@ def measured_traffic(key, root=None, lib_hash=None):
         except (OSError, ValueError):
             continue
         rec["source"] = os.path.relpath(f, root)
-        rec["stale"] = not (rec.get("_lib_sha256") and rec.get("_lib_sha256") == lib_hash)
+        same_lib = bool(rec.get("_lib_sha256")) and rec.get("_lib_sha256") == lib_hash
+        same_src = bool(rec.get("_csrc_sha256")) and src_hash is not None and rec.get("_csrc_sha256") == src_hash
+        rec["stale"] = not (same_lib or same_src)
         return rec
     return None
 
