@@ -62,6 +62,9 @@ __device__ __forceinline__ void tcn_split4(const float (&v)[4], th4& hi, th4& lo
 #define TCN_BATCH 4                 // staging items (4 channels x 1 step) whose global loads a thread issues back to back
 #endif
 
+#ifndef TCN_PROBE
+#define TCN_PROBE 0                 // timing probes (tools/r4_tcn_probe.sh only; results are wrong): 1 no global stores, 2 no global loads
+#endif
 #define TCN_MMA(acc, a, b) (acc) = __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (acc), 0, 0, 0)
 
 // NC1 / NC2: 32-wide k chunks of conv1 / conv2 (ceil(3 cip / 32)); SB: the block shortcut is a 1x1 convolution
@@ -140,7 +143,8 @@ __global__ __launch_bounds__(256) void stg_tcn_mfma_kernel(const TcnMArgs p) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int c = 4 * q + j;
-                            if (c < p.c1) v[u][j] = p.src1[(n * p.c1 + c) * T + t];
+                            if (TCN_PROBE & 2) v[u][j] = 0.25f * (float)(c + t);
+                            else if (c < p.c1) v[u][j] = p.src1[(n * p.c1 + c) * T + t];
                             else if (c < ci) v[u][j] = p.src2[(n * p.c2 + (c - p.c1)) * T + t];
                         }
                     }
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256) void stg_tcn_mfma_kernel(const TcnMArgs p) {
                 if (t >= t0 && t < t1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (4 * g + r < co) p.sc[(n * co + 4 * g + r) * T + t] = sb[r] * p.invsb + sbv[r];
+                        if (4 * g + r < co && (!(TCN_PROBE & 1) || sb[r] == 1.2345e30f)) p.sc[(n * co + 4 * g + r) * T + t] = sb[r] * p.invsb + sbv[r];
                 }
             }
         }
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256) void stg_tcn_mfma_kernel(const TcnMArgs p) {
             if (t < t1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (4 * g + r < co) p.out[(n * co + 4 * g + r) * T + t] = v[r] * rstd * lw[r] + lb[r];
+                    if (4 * g + r < co && (!(TCN_PROBE & 1) || v[r] == 1.2345e30f)) p.out[(n * co + 4 * g + r) * T + t] = v[r] * rstd * lw[r] + lb[r];
             }
         }
     }
