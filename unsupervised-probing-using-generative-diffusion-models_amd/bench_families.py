@@ -79,6 +79,31 @@ def record_nsdiff_spatial(device, log, cpu=True):
         tr, rec["value"], achieved, "f16x3",
         "the kernels of c5 at time length 100 (stg_tcn_mfma_kernel, nst_gemm_h3_kernel, stg_gate_kernel) + nss_heads / nss_posterior",
         {"flop_per_window": flop_per_window})
+    # the same step with f(x) = the native Model_spatial in front of it (round 4; no shipped YAML names its sizes: d_model 128, 4 heads,
+    # d_ff 128, 2 + 1 layers, fT_h 10, two graph convolutions over 1280 features)
+    try:
+        fx = dict(d_model=128, n_heads=4, d_ff=128, e_layers=2, d_layers=1, activation="gelu", p_hidden_dims=[64, 64], p_hidden_layers=2, fT_h=10, spatial_layers=2)
+        torch.manual_seed(655)
+        full = diffusion_models("NsDiff_spatial", dict(net, **fx), train_model_select="NsDiff_model").to(device).eval()
+        with torch.no_grad():
+            full.scaler_mean.fill_(0.0)
+            full.scaler_std.fill_(1.0)
+        full.refresh_native()
+        fctx = full.native_context()
+
+        def full_step():
+            smp = full.sample_windows(hist, edge, None, seed=7)                      # f(x), g(x), sampler
+            mpv, pm, _ = fctx.reduce(smp)
+            return torch.stack([mpv, pm]).cpu()
+
+        dtf, fcurve = _events(full_step, 2)
+        dfx, _ = _events(lambda: full.spatial_mean_windows(hist, edge), 3)
+        rec["with_native_fx"] = {"value": W / dtf, "unit": "windows/s", "ms_per_step": dtf * 1e3, "fx_ms_per_step": dfx * 1e3, "finite": bool(torch.isfinite(fcurve).all()),
+                                 "fx": "Model_spatial d_model 128, 4 heads, d_ff 128, 2 enc + 1 dec layers, fT_h 10, 2 x ResGatedGraphConv(1280): parity unpinned"}
+        log("other family nsdiff_spatial with native f(x): %.3g windows/s (f(x) %.1f ms per %d windows)" % (W / dtf, dfx * 1e3, W))
+        del full
+    except Exception as exc:                                                         # noqa: BLE001
+        rec["with_native_fx"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if cpu:
         from oracle import nsdiff_spatial_oracle as O
         from oracle import nsdiff_oracle as NS
