@@ -230,3 +230,34 @@ def test_uncertainty_ews_on_a_nsdiff_spatial_directory(tmp_path, monkeypatch):
     again = H.uncertainty_ews(model_save_file=path, data_file=tmp_path / "biomass_x.pt", dynamic_type="biomass", graph_file=tmp_path / "g.graphml",
                               device=dev(), save_nsdiff_g=False, sample_window_step=step, load_model_when_cached=True)
     np.testing.assert_allclose(np.array(again["ews"], dtype=np.float64), np.array(want), rtol=1e-4)        # served from the cache
+
+
+def test_sample_axis_shards_union_nsdiff_spatial():
+    """Fewer windows than ranks: rank r samples ALL windows (f(x), g(x) everywhere) with the chunks [r C/world, (r+1) C/world) of the reference's stream;
+    side by side = the unsplit run (the device side of distributed._sample_split for this family)."""
+    from conftest import GOLDEN
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+    from mpv_amd.models.models import diffusion_models
+    z = np.load(GOLDEN / "nsdiff_spatial_cases.npz")
+    net, V, sd, sd_f, full, cfg = spatial_net_and_state(z, "tiny", FX)
+    net = dict(net, n_z_samples=8, parallel_sample=2, noise_source="torch_cpu")            # 4 chunks of 2 graph copies
+    m = diffusion_models("NsDiff_spatial", dict(net, device="cpu"), train_model_select="NsDiff_model")
+    m.load_state_dict(full, strict=True)
+    with torch.no_grad():
+        m.scaler_mean.fill_(0.1)
+        m.scaler_std.fill_(1.3)
+    m = m.to(dev()).eval()
+    graph = H._Graph(T(z["edge_tiny"]), V)
+    g = torch.Generator().manual_seed(4)
+    windows = [torch.cumsum(torch.randn(V, net["windows"], 1, generator=g) * 0.3, dim=1) for _ in range(2)]
+    assert H._sample_axis(m, graph) == (8, 2, True)
+    torch.manual_seed(31)
+    whole, _, _ = H._native_shard(m, windows, net["pred_len"], True, graph=graph)           # [2, V, O, 1, 8]
+    for world in (2, 4):
+        parts = []
+        for r in range(world):
+            torch.manual_seed(31)
+            parts.append(H._native_sample_shard_other(m, windows, net["pred_len"], True, r * (8 // world), (r + 1) * (8 // world), seed=0, graph=graph).cpu())
+        got = torch.cat(parts, dim=-1)
+        assert tuple(got.shape) == tuple(whole.shape) and int(m.configs.n_z_samples) == 8
+        assert rel_err(got, whole.cpu()) < 1e-5

@@ -454,8 +454,8 @@ def _sample_axis(model, graph=None):
     """(n_samples, chunk, whole_chunks_only) of a model family's sample axis: NsDiff and TMDM sample pointwise in chunks of
     `parallel_sample` (a chunk may be cut); a DiffusionTS chunk is one batch with shared normalisers and a DiffSTG chunk one sequential pass
     of `parallel_sampling` graph copies (whole chunks only)."""
-    if graph is not None and _is_spatial(model):
-        return None                      # NsDiff_spatial shards by window only
+    if graph is not None and _is_spatial(model):             # NsDiff_spatial: a chunk = one pass of parallel_sample graph copies (whole chunks only)
+        return int(model.configs.n_z_samples), int(model.configs.parallel_sample), True
     if graph is not None:
         return int(model.parallel_sampling) * int(model.sequential_sampling), int(model.parallel_sampling), True
     if hasattr(model, "_prior_variance") and hasattr(model, "configs"):
@@ -475,7 +475,21 @@ def _native_sample_shard_other(model, windows, pred_len, scale, s_lo, s_hi, seed
     V = int(windows[0].shape[0])
     ctx = model.native_context()
     torch_cpu = getattr(model, "noise_source", "philox") == "torch_cpu"
-    is_stg, is_dts = graph is not None, graph is None and getattr(model, "batched_history", False)
+    is_nss = graph is not None and _is_spatial(model)
+    is_stg, is_dts = graph is not None and not is_nss, graph is None and getattr(model, "batched_history", False)
+    if is_nss:
+        # NsDiff_spatial: f(x) and g(x) for all windows on every rank (cheap beside the sampler), this rank's chunks of the chains
+        hist = torch.stack([torch.as_tensor(w).float()[:, :model.windows, :] for w in windows]).to(ctx.device)      # [W, V, windows, F]
+        if scale:
+            hist = (hist - model.scaler_mean.to(ctx.device)) / model.scaler_std.to(ctx.device)
+        noise = model.host_noise(len(windows), V)[:, s_lo // P: s_hi // P].contiguous() if torch_cpu else None     # [W, C, T, V*P, O, F]: chunk axis second
+        keep = model.configs.n_z_samples
+        model.configs.n_z_samples = per
+        try:
+            samples = model.sample_windows(hist, graph.edge_index, None, noise=noise, seed=None if torch_cpu else seed + dist_utils.rank())
+        finally:
+            model.configs.n_z_samples = keep
+        return samples[:, :, -pred_len:].contiguous()
     if is_stg or is_dts:
         hist_len = model.T_h if is_stg else model.windows
         hist = torch.stack([torch.as_tensor(w).float()[:, :hist_len, :] for w in windows]).to(ctx.device)          # [W, V, hist, F]
