@@ -227,6 +227,9 @@ __device__ __forceinline__ float tile_split(const f32x4& t, ah4& hi, ah4& lo, fl
     return sc;
 }
 
+#ifndef AH_FWD_NQ
+#define AH_FWD_NQ 2                  // query tiles a wave of the forward kernel runs side by side (1 = the round-3 loop)
+#endif
 __global__ __launch_bounds__(256) void dts_attn_fwd_h_kernel(const AttnArgs p) {
     constexpr int HD = 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -251,56 +254,102 @@ __global__ __launch_bounds__(256) void dts_attn_fwd_h_kernel(const AttnArgs p) {
     const float oinv = 1.0f / sc[1];                                   // O = (2^13 sV O) / (sV 2^13 l)
     const int nkt = Lkp >> 4, tail = (p.Lk & 15) ? nkt - 1 : nkt;      // key tile with padded keys (only that one is masked)
     // 13 query tiles over 4 waves = 4 + 3 + 3 + 3: the wave with the extra tile rotates from workgroup to workgroup, or SIMD 0 (wave 0 of every
-    // resident workgroup) carries a third more than the others
-    for (int jt = (wave + blockIdx.x) & 3; jt < ((p.Lq + 15) >> 4); jt += 4) {
-        const int j = 16 * jt + r16;
-        const bool jl = j < p.Lq;
-        ah4 qh, ql;
-        const float c = c0 / load_split_col(Qb + (long long)(jl ? j : 0) * p.ldq + 4 * g, qh, ql);      // the scores come out of the MFMA times sK sQ(query)
+    // resident workgroup) carries a third more than the others.
+    // Round 4: a wave runs TWO of its query tiles (jt, jt + 4) through the key tiles together.  A (query tile, key tile) pair is one serial chain --
+    // LDS read -> 3 dependent MFMAs -> maximum across lanes -> exp2 -> split -> 3 dependent MFMAs, ~1600 cycles end to end -- and with the five waves per
+    // SIMD the LDS budget allows the kernel ran at 320 cycles per pair: latency-bound (the issue limit for its 64 instructions is ~130).  Two independent
+    // chains per wave share the K / V fragment reads and fill each other's stalls.
+    const int nqt = (p.Lq + 15) >> 4;
+    const _Float16* kp = Kh + r16 * AH_RS + 4 * g;
+    const _Float16* vp = VTh + r16 * Lkp + 4 * g;
+    const int klo = Lkp * AH_RS, vlo = 16 * Lkp;
+    for (int jt0 = (wave + blockIdx.x) & 3; jt0 < nqt; jt0 += 4 * AH_FWD_NQ) {
+        int j[AH_FWD_NQ];
+        bool jl[AH_FWD_NQ];
+        ah4 qh[AH_FWD_NQ], ql[AH_FWD_NQ];
+        float c[AH_FWD_NQ], mr[AH_FWD_NQ], l[AH_FWD_NQ];
+        f32x4 o[AH_FWD_NQ];
+#pragma unroll
+        for (int u = 0; u < AH_FWD_NQ; ++u) {
+            j[u] = 16 * (jt0 + 4 * u) + r16;
+            jl[u] = j[u] < p.Lq;                                       // (a tile beyond the last one has no valid query at all)
+            c[u] = c0 / load_split_col(Qb + (long long)(jl[u] ? j[u] : 0) * p.ldq + 4 * g, qh[u], ql[u]);      // the scores come out of the MFMA times sK sQ(query)
+            mr[u] = -INFINITY;
+            l[u] = 0.0f;
+            o[u] = f32x4{0, 0, 0, 0};
+        }
         // online softmax on the RAW scores (c > 0): running maximum mr of s, probabilities 2^13 exp2(c (s - mr)) as one fused multiply-add per score
-        float mr = -INFINITY, l = 0.0f;
-        f32x4 o = {0, 0, 0, 0};
-        const _Float16* kp = Kh + r16 * AH_RS + 4 * g;
-        const _Float16* vp = VTh + r16 * Lkp + 4 * g;
-        const int klo = Lkp * AH_RS, vlo = 16 * Lkp;
-        auto key_tile = [&](int it, auto masked) {
+        auto key_tile = [&](int it, auto masked, auto nact) {
+            constexpr int NA = decltype(nact)::value;
             const ah4 kh = *reinterpret_cast<const ah4*>(kp + 16 * AH_RS * it);
             const ah4 kl = *reinterpret_cast<const ah4*>(kp + klo + 16 * AH_RS * it);
-            f32x4 s = {0, 0, 0, 0};
-            DTS_MMH3(s, kh, kl, qh, ql);                                // sK sQ S^T[key 4 g + r][query r16]
-            if constexpr (decltype(masked)::value) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (16 * it + 4 * g + r >= p.Lk) s[r] = -INFINITY;
-            }
-            const float tmax = col4_max(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
-            const float mn = fmaxf(mr, tmax);                      // finite from the first tile on (Lk >= 1)
-            const float alpha = __builtin_amdgcn_exp2f((mr - mn) * c);
-            const float nb = __builtin_fmaf(-mn, c, AH_PLOG);      // probabilities come out times 2^13 (the split's scale); l carries the same factor
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, nb));
-            const float ps = (s[0] + s[1]) + (s[2] + s[3]);
-            l = l * alpha + ps;
-            o *= alpha;
-            mr = mn;
-            ah4 ph, pl;
-            attn_split4(s[0], s[1], s[2], s[3], ph, pl);
             const ah4 vh = *reinterpret_cast<const ah4*>(vp + 16 * it);
             const ah4 vl = *reinterpret_cast<const ah4*>(vp + vlo + 16 * it);
-            DTS_MMH3(o, vh, vl, ph, pl);                                // 2^13 sV O^T[d 4 g + r][query r16]
+            f32x4 s[NA];
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                s[u] = f32x4{0, 0, 0, 0};
+                DTS_MMH3(s[u], kh, kl, qh[u], ql[u]);                   // sK sQ S^T[key 4 g + r][query r16]
+            }
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                if constexpr (decltype(masked)::value) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * it + 4 * g + r >= p.Lk) s[u][r] = -INFINITY;
+                }
+                const float tmax = col4_max(fmaxf(fmaxf(s[u][0], s[u][1]), fmaxf(s[u][2], s[u][3])));
+                const float mn = fmaxf(mr[u], tmax);                   // finite from the first tile on (Lk >= 1)
+                const float alpha = __builtin_amdgcn_exp2f((mr[u] - mn) * c[u]);
+                const float nb = __builtin_fmaf(-mn, c[u], AH_PLOG);   // probabilities come out times 2^13 (the split's scale); l carries the same factor
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[u][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], c[u], nb));
+                const float ps = (s[u][0] + s[u][1]) + (s[u][2] + s[u][3]);
+                l[u] = l[u] * alpha + ps;
+                o[u] *= alpha;
+                mr[u] = mn;
+            }
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                ah4 ph, pl;
+                attn_split4(s[u][0], s[u][1], s[u][2], s[u][3], ph, pl);
+                DTS_MMH3(o[u], vh, vl, ph, pl);                         // 2^13 sV O^T[d 4 g + r][query r16]
+            }
         };
-        for (int it = 0; it < tail; ++it) key_tile(it, std::false_type{});
-        if (tail < nkt) key_tile(tail, std::true_type{});
-        l = col4_sum(l);
-        if (jl) {
-            const float inv = oinv / l;
-            float* dst = p.out + ((long long)b * p.Lq + j) * p.ldout + h * p.hs + 4 * g;
-            *reinterpret_cast<f32x4*>(dst) = o * inv;
-            if (g == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Lq + j] = __builtin_fmaf(mr, c, __builtin_amdgcn_logf(l) - AH_PLOG);
+        auto run = [&](auto nact) {
+            for (int it = 0; it < tail; ++it) key_tile(it, std::false_type{}, nact);
+            if (tail < nkt) key_tile(tail, std::true_type{}, nact);
+        };
+        int nact = 0;
+#pragma unroll
+        for (int u = 0; u < AH_FWD_NQ; ++u) nact += (jt0 + 4 * u < nqt) ? 1 : 0;          // wave-uniform
+        if (AH_FWD_NQ >= 4 && nact == 4) run(std::integral_constant<int, (AH_FWD_NQ >= 4 ? 4 : 1)>{});
+        else if (AH_FWD_NQ >= 3 && nact == 3) run(std::integral_constant<int, (AH_FWD_NQ >= 3 ? 3 : 1)>{});
+        else if (AH_FWD_NQ >= 2 && nact == 2) run(std::integral_constant<int, (AH_FWD_NQ >= 2 ? 2 : 1)>{});
+        else run(std::integral_constant<int, 1>{});
+#pragma unroll
+        for (int u = 0; u < AH_FWD_NQ; ++u) {
+            if (u >= nact) break;
+            const float lt = col4_sum(l[u]);
+            if (jl[u]) {
+                const float inv = oinv / lt;
+                float* dst = p.out + ((long long)b * p.Lq + j[u]) * p.ldout + h * p.hs + 4 * g;
+                *reinterpret_cast<f32x4*>(dst) = o[u] * inv;
+                if (g == 0 && p.lse) p.lse[((long long)b * p.H + h) * p.Lq + j[u]] = __builtin_fmaf(mr[u], c[u], __builtin_amdgcn_logf(lt) - AH_PLOG);
+            }
         }
     }
 }
 
+// tiles a wave runs side by side (1 or 2).  Measured, same box, 10-step c3 plan (profiles/r04/c3_attn_ilp.txt): forward 280.5 -> 265.6 us with two
+// query tiles (three: 263.1, four: 266-269); dK-dV 493.8 -> 476.6 with two key tiles (112 VGPRs: four workgroups per CU instead of five, still ahead);
+// dQ 386.1 -> 397.2 with two (97 VGPRs cost it its fifth workgroup for nothing): one.
+#ifndef AH_DQ_NQ
+#define AH_DQ_NQ 1
+#endif
+#ifndef AH_DKV_NQ
+#define AH_DKV_NQ 2
+#endif
 __global__ __launch_bounds__(256) void dts_attn_dq_h_kernel(const AttnArgs p) {
     constexpr int HD = 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -324,54 +373,79 @@ __global__ __launch_bounds__(256) void dts_attn_dq_h_kernel(const AttnArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
     const float c0 = p.scale * LOG2E / sc[0];
     const float kinv = 1.0f / sc[0];
-    for (int jt = (wave + blockIdx.x) & 3; jt < ((p.Lq + 15) >> 4); jt += 4) {      // (rotated: see the forward kernel)
-        const int j = 16 * jt + r16;
-        const bool jl = j < p.Lq;
-        ah4 qh, ql, dh, dl;
-        const float c = c0 / load_split_col(Qb + (long long)(jl ? j : 0) * p.ldq + 4 * g, qh, ql);
-        // delta[query] = dO[query] . O[query] is formed here, from the dO row the kernel loads anyway and the matching O row (four lanes per query, two
-        // shuffles), and left in p.delta for the dK-dV pass: the separate pass over dO and O (dts_attn_delta_kernel) is gone in this mode
-        const f32x4 dov = *reinterpret_cast<const f32x4*>(Db + (long long)(jl ? j : 0) * p.ldo + 4 * g);
-        const f32x4 ov = *reinterpret_cast<const f32x4*>(p.O + ((long long)b * p.Lq + (jl ? j : 0)) * p.ldo + h * p.hs + 4 * g);
-        float del = (dov[0] * ov[0] + dov[1] * ov[1]) + (dov[2] * ov[2] + dov[3] * ov[3]);
-        del = col4_sum(del);
-        if (jl && g == 0) const_cast<float*>(p.delta)[((long long)b * p.H + h) * p.Lq + j] = del;
-        const float dpinv = 1.0f / (sc[1] * split_col(dov, dh, dl));      // V . dO comes out times sV sdO(query)
-        const float lse = p.lse[((long long)b * p.H + h) * p.Lq + (jl ? j : 0)];
-        f32x4 dq = {0, 0, 0, 0};
-        const int nkt = Lkp >> 4, tail = (p.Lk & 15) ? nkt - 1 : nkt;  // key tile with padded keys (only that one is masked)
-        const int plane = Lkp * AH_RS;                                 // Kh -> Kl -> Vh -> Vl are consecutive planes
-        const _Float16* kp = Kh + r16 * AH_RS + 4 * g;
-        const _Float16* kc = Kh + (4 * g + (r16 >> 2)) * AH_RS + 4 * (r16 & 3);      // transposed reads of the key block 4 g .. 4 g + 3: this lane's address
-        auto key_tile = [&](int it, auto masked) {
+    const int nqt = (p.Lq + 15) >> 4;
+    const int nkt = Lkp >> 4, tail = (p.Lk & 15) ? nkt - 1 : nkt;      // key tile with padded keys (only that one is masked)
+    const int plane = Lkp * AH_RS;                                     // Kh -> Kl -> Vh -> Vl are consecutive planes
+    const _Float16* kp = Kh + r16 * AH_RS + 4 * g;
+    const _Float16* kc = Kh + (4 * g + (r16 >> 2)) * AH_RS + 4 * (r16 & 3);      // transposed reads of the key block 4 g .. 4 g + 3: this lane's address
+    for (int jt0 = (wave + blockIdx.x) & 3; jt0 < nqt; jt0 += 4 * AH_DQ_NQ) {      // (rotated, and AH_DQ_NQ query tiles side by side: see the forward kernel)
+        int j[AH_DQ_NQ];
+        bool jl[AH_DQ_NQ];
+        ah4 qh[AH_DQ_NQ], ql[AH_DQ_NQ], dh[AH_DQ_NQ], dl[AH_DQ_NQ];
+        float c[AH_DQ_NQ], del[AH_DQ_NQ], dpinv[AH_DQ_NQ], lse[AH_DQ_NQ];
+        f32x4 dq[AH_DQ_NQ];
+#pragma unroll
+        for (int u = 0; u < AH_DQ_NQ; ++u) {
+            j[u] = 16 * (jt0 + 4 * u) + r16;
+            jl[u] = j[u] < p.Lq;
+            c[u] = c0 / load_split_col(Qb + (long long)(jl[u] ? j[u] : 0) * p.ldq + 4 * g, qh[u], ql[u]);
+            // delta[query] = dO[query] . O[query] is formed here, from the dO row the kernel loads anyway and the matching O row (four lanes per query, two
+            // shuffles), and left in p.delta for the dK-dV pass: the separate pass over dO and O (dts_attn_delta_kernel) is gone in this mode
+            const f32x4 dov = *reinterpret_cast<const f32x4*>(Db + (long long)(jl[u] ? j[u] : 0) * p.ldo + 4 * g);
+            const f32x4 ov = *reinterpret_cast<const f32x4*>(p.O + ((long long)b * p.Lq + (jl[u] ? j[u] : 0)) * p.ldo + h * p.hs + 4 * g);
+            del[u] = col4_sum((dov[0] * ov[0] + dov[1] * ov[1]) + (dov[2] * ov[2] + dov[3] * ov[3]));
+            if (jl[u] && g == 0) const_cast<float*>(p.delta)[((long long)b * p.H + h) * p.Lq + j[u]] = del[u];
+            dpinv[u] = 1.0f / (sc[1] * split_col(dov, dh[u], dl[u]));      // V . dO comes out times sV sdO(query)
+            lse[u] = p.lse[((long long)b * p.H + h) * p.Lq + (jl[u] ? j[u] : 0)];
+            dq[u] = f32x4{0, 0, 0, 0};
+        }
+        auto key_tile = [&](int it, auto masked, auto nact) {
+            constexpr int NA = decltype(nact)::value;
             const _Float16* kr = kp + 16 * AH_RS * it;
             const ah4 kh = *reinterpret_cast<const ah4*>(kr), kl = *reinterpret_cast<const ah4*>(kr + plane);
             const ah4 vh = *reinterpret_cast<const ah4*>(kr + 2 * plane), vl = *reinterpret_cast<const ah4*>(kr + 3 * plane);
-            f32x4 s = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
-            DTS_MMH3(s, kh, kl, qh, ql);
-            DTS_MMH3(t2, vh, vl, dh, dl);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pr = __builtin_amdgcn_exp2f(s[r] * c - lse);
-                s[r] = pr * (t2[r] * dpinv - del) * p.scale;
-            }
-            if constexpr (decltype(masked)::value) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (16 * it + 4 * g + r >= p.Lk) s[r] = 0.0f;
-            }
-            ah4 sh, sl;
-            float issc;
-            (void)tile_split(s, sh, sl, issc);                          // dS^T of this tile times its own power of two
             const _Float16* kq = kc + 16 * AH_RS * it;
             const ah4 th = column4_tr(kq), tl = column4_tr(kq + plane);                                    // sK K^T[d = r16][keys 4 g ..]
-            f32x4 part = {0, 0, 0, 0};
-            DTS_MMH3(part, th, tl, sh, sl);
-            dq += part * (kinv * issc);
+            f32x4 s[NA], t2[NA];
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                s[u] = f32x4{0, 0, 0, 0};
+                t2[u] = f32x4{0, 0, 0, 0};
+                DTS_MMH3(s[u], kh, kl, qh[u], ql[u]);
+                DTS_MMH3(t2[u], vh, vl, dh[u], dl[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = __builtin_amdgcn_exp2f(s[u][r] * c[u] - lse[u]);
+                    s[u][r] = pr * (t2[u][r] * dpinv[u] - del[u]) * p.scale;
+                }
+                if constexpr (decltype(masked)::value) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * it + 4 * g + r >= p.Lk) s[u][r] = 0.0f;
+                }
+                ah4 sh, sl;
+                float issc;
+                (void)tile_split(s[u], sh, sl, issc);                   // dS^T of this tile times its own power of two
+                f32x4 part = {0, 0, 0, 0};
+                DTS_MMH3(part, th, tl, sh, sl);
+                dq[u] += part * (kinv * issc);
+            }
         };
-        for (int it = 0; it < tail; ++it) key_tile(it, std::false_type{});
-        if (tail < nkt) key_tile(tail, std::true_type{});
-        if (jl) *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lq + j) * p.ldout + h * p.hs + 4 * g) = dq;
+        auto run = [&](auto nact) {
+            for (int it = 0; it < tail; ++it) key_tile(it, std::false_type{}, nact);
+            if (tail < nkt) key_tile(tail, std::true_type{}, nact);
+        };
+        int nact = 0;
+#pragma unroll
+        for (int u = 0; u < AH_DQ_NQ; ++u) nact += (jt0 + 4 * u < nqt) ? 1 : 0;          // wave-uniform
+        if (AH_DQ_NQ >= 2 && nact == 2) run(std::integral_constant<int, (AH_DQ_NQ >= 2 ? 2 : 1)>{});
+        else run(std::integral_constant<int, 1>{});
+#pragma unroll
+        for (int u = 0; u < AH_DQ_NQ; ++u)
+            if (u < nact && jl[u]) *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lq + j[u]) * p.ldout + h * p.hs + 4 * g) = dq[u];
     }
 }
 
@@ -404,46 +478,74 @@ __global__ __launch_bounds__(256) void dts_attn_dkv_h_kernel(const AttnArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
     const float c0 = p.scale * LOG2E / sc[0];
     const float dvinv = 1.0f / (sc[1] * AH_PSCALE), qinv = 1.0f / sc[0], pscale = p.scale / AH_PSCALE;
-    for (int jt = (wave + blockIdx.x) & 3; jt < ((p.Lk + 15) >> 4); jt += 4) {      // (rotated: see the forward kernel)
-        const int j = 16 * jt + r16;                                  // key
-        const bool jl = j < p.Lk;
-        ah4 kh, kl, vh, vl;
-        const float c = c0 / load_split_col(Kb + (long long)(jl ? j : 0) * p.ldk + 4 * g, kh, kl);
-        const float dpinv = 1.0f / (sc[1] * load_split_col(Vb + (long long)(jl ? j : 0) * p.ldv + 4 * g, vh, vl));
-        f32x4 dk = {0, 0, 0, 0}, dv = {0, 0, 0, 0};
-        const int plane = Lqp * AH_RS;                                 // Qh -> Ql -> Dh -> Dl are consecutive planes
-        const _Float16* qp = Qh + r16 * AH_RS + 4 * g;                 // row reads: query 16 it + r16, head columns 4 g ..
-        const _Float16* qc = Qh + (4 * g + (r16 >> 2)) * AH_RS + 4 * (r16 & 3);      // transposed reads of the query block 16 it + 4 g ..: this lane's address
-        for (int it = 0; it < (Lqp >> 4); ++it) {
-            const _Float16* qr = qp + 16 * AH_RS * it;
-            const ah4 qh = *reinterpret_cast<const ah4*>(qr), ql = *reinterpret_cast<const ah4*>(qr + plane);
-            const ah4 dh = *reinterpret_cast<const ah4*>(qr + 2 * plane), dl = *reinterpret_cast<const ah4*>(qr + 3 * plane);
-            f32x4 s = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
-            DTS_MMH3(s, qh, ql, kh, kl);                                // sQ sK S[query 4 g + r][key r16]
-            DTS_MMH3(t2, dh, dl, vh, vl);
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsel + 16 * it + 4 * g);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dell + 16 * it + 4 * g);
-            f32x4 pr, ds;
+    const int nktk = (p.Lk + 15) >> 4;
+    const int plane = Lqp * AH_RS;                                     // Qh -> Ql -> Dh -> Dl are consecutive planes
+    const _Float16* qp = Qh + r16 * AH_RS + 4 * g;                     // row reads: query 16 it + r16, head columns 4 g ..
+    const _Float16* qc = Qh + (4 * g + (r16 >> 2)) * AH_RS + 4 * (r16 & 3);      // transposed reads of the query block 16 it + 4 g ..: this lane's address
+    for (int jt0 = (wave + blockIdx.x) & 3; jt0 < nktk; jt0 += 4 * AH_DKV_NQ) {     // (rotated, AH_DKV_NQ key tiles side by side: see the forward kernel)
+        int j[AH_DKV_NQ];
+        bool jl[AH_DKV_NQ];
+        ah4 kh[AH_DKV_NQ], kl[AH_DKV_NQ], vh[AH_DKV_NQ], vl[AH_DKV_NQ];
+        float c[AH_DKV_NQ], dpinv[AH_DKV_NQ];
+        f32x4 dk[AH_DKV_NQ], dv[AH_DKV_NQ];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pr[r] = __builtin_amdgcn_exp2f(s[r] * c - (l4[r] - AH_PLOG));        // 2^13 P
-                ds[r] = pr[r] * (t2[r] * dpinv - d4[r]) * pscale;
-            }
-            ah4 ph, pl, sh, sl;
-            attn_split4(pr[0], pr[1], pr[2], pr[3], ph, pl);
-            float issc;
-            (void)tile_split(ds, sh, sl, issc);
-            const _Float16* qq = qc + 16 * AH_RS * it;
-            const ah4 qth = column4_tr(qq), qtl = column4_tr(qq + plane);
-            const ah4 dth = column4_tr(qq + 2 * plane), dtl = column4_tr(qq + 3 * plane);                  // sdO dO^T[d = r16][queries 4 g ..]
-            DTS_MMH3(dv, dth, dtl, ph, pl);
-            f32x4 part = {0, 0, 0, 0};
-            DTS_MMH3(part, qth, qtl, sh, sl);
-            dk += part * (qinv * issc);
+        for (int u = 0; u < AH_DKV_NQ; ++u) {
+            j[u] = 16 * (jt0 + 4 * u) + r16;                          // key
+            jl[u] = j[u] < p.Lk;
+            c[u] = c0 / load_split_col(Kb + (long long)(jl[u] ? j[u] : 0) * p.ldk + 4 * g, kh[u], kl[u]);
+            dpinv[u] = 1.0f / (sc[1] * load_split_col(Vb + (long long)(jl[u] ? j[u] : 0) * p.ldv + 4 * g, vh[u], vl[u]));
+            dk[u] = f32x4{0, 0, 0, 0};
+            dv[u] = f32x4{0, 0, 0, 0};
         }
-        if (jl) {
-            *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lk + j) * p.ldout + h * p.hs + 4 * g) = dk;
-            *reinterpret_cast<f32x4*>(p.out2 + ((long long)b * p.Lk + j) * p.ldout2 + h * p.hs + 4 * g) = dv * dvinv;
+        auto run = [&](auto nact) {
+            constexpr int NA = decltype(nact)::value;
+            for (int it = 0; it < (Lqp >> 4); ++it) {
+                const _Float16* qr = qp + 16 * AH_RS * it;
+                const ah4 qh = *reinterpret_cast<const ah4*>(qr), ql = *reinterpret_cast<const ah4*>(qr + plane);
+                const ah4 dh = *reinterpret_cast<const ah4*>(qr + 2 * plane), dl = *reinterpret_cast<const ah4*>(qr + 3 * plane);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsel + 16 * it + 4 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dell + 16 * it + 4 * g);
+                const _Float16* qq = qc + 16 * AH_RS * it;
+                const ah4 qth = column4_tr(qq), qtl = column4_tr(qq + plane);
+                const ah4 dth = column4_tr(qq + 2 * plane), dtl = column4_tr(qq + 3 * plane);                  // sdO dO^T[d = r16][queries 4 g ..]
+                f32x4 s[NA], t2[NA];
+#pragma unroll
+                for (int u = 0; u < NA; ++u) {
+                    s[u] = f32x4{0, 0, 0, 0};
+                    t2[u] = f32x4{0, 0, 0, 0};
+                    DTS_MMH3(s[u], qh, ql, kh[u], kl[u]);               // sQ sK S[query 4 g + r][key r16]
+                    DTS_MMH3(t2[u], dh, dl, vh[u], vl[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < NA; ++u) {
+                    f32x4 pr, ds;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pr[r] = __builtin_amdgcn_exp2f(s[u][r] * c[u] - (l4[r] - AH_PLOG));        // 2^13 P
+                        ds[r] = pr[r] * (t2[u][r] * dpinv[u] - d4[r]) * pscale;
+                    }
+                    ah4 ph, pl, sh, sl;
+                    attn_split4(pr[0], pr[1], pr[2], pr[3], ph, pl);
+                    float issc;
+                    (void)tile_split(ds, sh, sl, issc);
+                    DTS_MMH3(dv[u], dth, dtl, ph, pl);
+                    f32x4 part = {0, 0, 0, 0};
+                    DTS_MMH3(part, qth, qtl, sh, sl);
+                    dk[u] += part * (qinv * issc);
+                }
+            }
+        };
+        int nact = 0;
+#pragma unroll
+        for (int u = 0; u < AH_DKV_NQ; ++u) nact += (jt0 + 4 * u < nktk) ? 1 : 0;         // wave-uniform
+        if (AH_DKV_NQ >= 2 && nact == 2) run(std::integral_constant<int, (AH_DKV_NQ >= 2 ? 2 : 1)>{});
+        else run(std::integral_constant<int, 1>{});
+#pragma unroll
+        for (int u = 0; u < AH_DKV_NQ; ++u) {
+            if (u < nact && jl[u]) {
+                *reinterpret_cast<f32x4*>(p.out + ((long long)b * p.Lk + j[u]) * p.ldout + h * p.hs + 4 * g) = dk[u];
+                *reinterpret_cast<f32x4*>(p.out2 + ((long long)b * p.Lk + j[u]) * p.ldout2 + h * p.hs + 4 * g) = dv[u] * dvinv;
+            }
         }
     }
 }
