@@ -14,6 +14,7 @@ case $CFG in
   nss) ARGS="--config nss --no-cpu-baseline"; WIN=12 ;;      # NsDiff_spatial family record: 1 warm-up + 2 timed steps of 4 windows
 esac
 PMCENV=""
+[ $CFG = nss ] && export MPV_BENCH_NSS_NO_FX=1      # the native-f(x) leg of the record would double the launches counted against its 12 windows
 [ $CFG = c3 ] && PMCENV=10      # c3: the counter passes run a 10-step plan (same launches, 10x fewer: a counter pass of the 36 k launches of the full plan takes > 7 min)
 if [ -z "$SKIP_STATS" ]; then
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/stats.json 2> $OUT/stats.err || exit 1

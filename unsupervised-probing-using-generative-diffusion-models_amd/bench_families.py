@@ -3,6 +3,7 @@ C5- / C2-shaped synthetic workloads, each with a roofline object and a bounded C
 default `python bench.py` line; never the headline."""
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -82,6 +83,8 @@ def record_nsdiff_spatial(device, log, cpu=True):
     # the same step with f(x) = the native Model_spatial in front of it (round 4; no shipped YAML names its sizes: d_model 128, 4 heads,
     # d_ff 128, 2 + 1 layers, fT_h 10, two graph convolutions over 1280 features)
     try:
+        if os.environ.get("MPV_BENCH_NSS_NO_FX"):                      # tools/pmc_pass.sh nss: the counter passes measure the record's own step only
+            raise RuntimeError("skipped (MPV_BENCH_NSS_NO_FX)")
         fx = dict(d_model=128, n_heads=4, d_ff=128, e_layers=2, d_layers=1, activation="gelu", p_hidden_dims=[64, 64], p_hidden_layers=2, fT_h=10, spatial_layers=2)
         torch.manual_seed(655)
         full = diffusion_models("NsDiff_spatial", dict(net, **fx), train_model_select="NsDiff_model").to(device).eval()
