@@ -305,9 +305,15 @@ int mlp_fwd(mpv_ctx* ctx, int D, int M, const float* X, const float* W0, const f
     const long long tiles = ((rows + 15) / 16 + MLP_WAVES - 1) / MLP_WAVES;              // 16-token tiles, MLP_WAVES of them per workgroup pass
     const long long per_cu = std::max<long long>(1, std::min<long long>(2, (long long)ctx->max_lds / (long long)lds));
     const int grid = (int)std::min<long long>(tiles, per_cu * ctx->cu_count);
+    const bool two_tiles = !(getenv("MPV_DTS_MLP_TILES") && atoi(getenv("MPV_DTS_MLP_TILES")) == 1);       // (A/B aid: 1 = the one-tile kernel)
 #define DTS_MLP(DT_, MT_)                                                                              \
     do {                                                                                               \
-        if (f16) {                                                                                     \
+        if (f16 && two_tiles && (DT_) % 2 == 0) {                                                      \
+            if (int rc = set_lds(ctx, dts_mlp_fwd_h2_kernel<(DT_) % 2 ? 2 : (DT_), MT_>, lds)) return rc; \
+            const long long pairs = (((rows + 15) / 16 + 1) / 2 + MLP_WAVES - 1) / MLP_WAVES;         \
+            const int grid2 = (int)std::min<long long>(pairs, per_cu * ctx->cu_count);                \
+            hipLaunchKernelGGL((dts_mlp_fwd_h2_kernel<(DT_) % 2 ? 2 : (DT_), MT_>), dim3(grid2), dim3(64 * MLP_WAVES), lds, ctx->stream, a); \
+        } else if (f16) {                                                                              \
             if (int rc = set_lds(ctx, dts_mlp_fwd_h_kernel<DT_, MT_>, lds)) return rc;                 \
             hipLaunchKernelGGL((dts_mlp_fwd_h_kernel<DT_, MT_>), dim3(grid), dim3(64 * MLP_WAVES), lds, ctx->stream, a); \
         } else {                                                                                       \
@@ -336,9 +342,15 @@ int mlp_bwd(mpv_ctx* ctx, int D, int M, const float* G, const float* U, const fl
     const long long tiles = ((rows + 15) / 16 + MLP_WAVES - 1) / MLP_WAVES;
     const long long per_cu = std::max<long long>(1, std::min<long long>(2, (long long)ctx->max_lds / (long long)lds));
     const int grid = (int)std::min<long long>(tiles, per_cu * ctx->cu_count);
+    const bool two_tiles = getenv("MPV_DTS_MLPB_TILES") && atoi(getenv("MPV_DTS_MLPB_TILES")) == 2;       // measured slower (331 vs 304 us, profiles/r04/c3_mlp_two_tiles.txt): opt-in
 #define DTS_MLPB(DT_, MT_)                                                                                           \
     do {                                                                                                            \
-        if (f16) {                                                                                                  \
+        if (f16 && two_tiles && (DT_) % 2 == 0) {                                                                   \
+            if (int rc = set_lds(ctx, dts_mlp_bwd_h2_kernel<(DT_) % 2 ? 2 : (DT_), MT_>, lds)) return rc;           \
+            const long long pairs = (((rows + 15) / 16 + 1) / 2 + MLP_WAVES - 1) / MLP_WAVES;                      \
+            const int grid2 = (int)std::min<long long>(pairs, per_cu * ctx->cu_count);                             \
+            hipLaunchKernelGGL((dts_mlp_bwd_h2_kernel<(DT_) % 2 ? 2 : (DT_), MT_>), dim3(grid2), dim3(64 * MLP_WAVES), lds, ctx->stream, a); \
+        } else if (f16) {                                                                                           \
             if (int rc = set_lds(ctx, dts_mlp_bwd_h_kernel<DT_, MT_>, lds)) return rc;                              \
             hipLaunchKernelGGL((dts_mlp_bwd_h_kernel<DT_, MT_>), dim3(grid), dim3(64 * MLP_WAVES), lds, ctx->stream, a); \
         } else {                                                                                                    \

@@ -970,6 +970,146 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_fwd_h_kernel(const Mlp
     }
 }
 
+// Round 4: the same fused MLP with TWO 16-token tiles per wave iteration.  The one-tile kernel re-reads both weight matrices from LDS for every tile --
+// 128 ds_read_b128 (128 KB) per 192 MFMAs -- and with eight waves on one LDS port that is 8192 LDS cycles against 6144 matrix-pipe cycles per SIMD: it
+// is LDS-bound.  Two tiles share every weight fragment (half the LDS bytes per MFMA) and give the wave two independent chains; the hidden units are
+// formed in blocks of HB2 = 2 tiles so that both tiles' blocks fit the register file.
+constexpr int MLP_HB2 = 2;
+template <int DT, int MT>
+__global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_fwd_h2_kernel(const MlpArgs p) {
+    constexpr int D = 16 * DT, M = 16 * MT, KSH = D + 8, MSH = M + 8, NTK = 2;
+    static_assert(DT % 2 == 0 && MT % 2 == 0, "the two-tile kernel is written for the 16x16x32 products");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    _Float16* W0h = reinterpret_cast<_Float16*>(ldsb);     // [M][KSH]
+    _Float16* W0l = W0h + M * KSH;
+    _Float16* W2h = W0l + M * KSH;                          // [D][MSH]
+    _Float16* W2l = W2h + D * MSH;
+    float* red = reinterpret_cast<float*>(W2l + D * MSH);  // [MLP_WAVES][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    float s0, s2;
+    mlp_stage_weights<DT, MT>(p.W0, p.W2, W0h, W0l, W2h, W2l, red, s0, s2);
+    __syncthreads();
+    const float i0 = 1.0f / s0, i2 = 1.0f / s2;
+    constexpr int HB = MLP_HB2;
+    f32x4 lw[DT], lb[DT];
+#pragma unroll
+    for (int s = 0; s < DT; ++s) {
+        lw[s] = *reinterpret_cast<const f32x4*>(p.lnw + mlp_col<true>(s, g));
+        lb[s] = *reinterpret_cast<const f32x4*>(p.lnb + mlp_col<true>(s, g));
+    }
+    const long long n_tiles = (p.rows + 15) / 16, n_pairs = (n_tiles + NTK - 1) / NTK;
+    const long long pair0 = (long long)blockIdx.x * MLP_WAVES + wave, pstep = (long long)gridDim.x * MLP_WAVES;
+    for (long long pair = pair0; pair < n_pairs; pair += pstep) {
+        asm volatile("" ::: "memory");        // the weight fragments are re-read from LDS every pair
+        long long tok[NTK];
+        bool live[NTK];
+        ah4 xh[NTK][DT], xl[NTK][DT];
+        float ix[NTK];
+#pragma unroll
+        for (int t = 0; t < NTK; ++t) {
+            tok[t] = (pair * NTK + t) * 16 + r16;
+            live[t] = tok[t] < p.rows;
+            const float* xr = p.X + (live[t] ? tok[t] : 0) * (long long)D;
+            f32x4 xb[DT];
+            float sum = 0.0f;
+#pragma unroll
+            for (int s = 0; s < DT; ++s) {
+                xb[s] = live[t] ? *reinterpret_cast<const f32x4*>(xr + mlp_col<true>(s, g)) : f32x4{0, 0, 0, 0};
+                sum += (xb[s][0] + xb[s][1]) + (xb[s][2] + xb[s][3]);
+            }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum / (float)D;
+            float q = 0.0f;
+#pragma unroll
+            for (int s = 0; s < DT; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xb[s][e] -= mean;
+                    q += xb[s][e] * xb[s][e];
+                }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
+#pragma unroll
+            for (int s = 0; s < DT; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xb[s][e] = xb[s][e] * rstd * lw[s][e] + lb[s][e];
+            const float sx = token_scale<DT>(xb);
+            ix[t] = i0 / sx;
+#pragma unroll
+            for (int s = 0; s < DT; ++s) attn_split4(xb[s][0] * sx, xb[s][1] * sx, xb[s][2] * sx, xb[s][3] * sx, xh[t][s], xl[t][s]);
+        }
+        f32x4 out[NTK][DT];
+#pragma unroll
+        for (int t = 0; t < NTK; ++t)
+#pragma unroll
+            for (int mt = 0; mt < DT; ++mt) out[t][mt] = f32x4{0, 0, 0, 0};
+#pragma unroll 1
+        for (int hb = 0; hb < MT; hb += HB) {
+            f32x4 u[NTK][HB];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                const int nt = hb + j;
+                f32x4 acc[NTK];
+#pragma unroll
+                for (int t = 0; t < NTK; ++t) acc[t] = f32x4{0, 0, 0, 0};
+                const int wo = (16 * nt + r16) * KSH + 8 * g;
+#pragma unroll
+                for (int s = 0; s < DT / 2; ++s) {
+                    const ah8 ah = *reinterpret_cast<const ah8*>(W0h + wo + 32 * s), al = *reinterpret_cast<const ah8*>(W0l + wo + 32 * s);
+#pragma unroll
+                    for (int t = 0; t < NTK; ++t) DTS_MMH3_32(acc[t], ah, al, ah8_of(xh[t][2 * s], xh[t][2 * s + 1]), ah8_of(xl[t][2 * s], xl[t][2 * s + 1]));
+                }
+                const f32x4 b0v = *reinterpret_cast<const f32x4*>(p.b0 + 16 * nt + 4 * g);
+#pragma unroll
+                for (int t = 0; t < NTK; ++t) {
+                    acc[t] = acc[t] * ix[t] + b0v;
+                    if (p.U && live[t]) *reinterpret_cast<f32x4*>(p.U + tok[t] * (long long)M + 16 * nt + 4 * g) = acc[t];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t][e] = gelu_f(acc[t][e]);
+                    u[t][j] = acc[t];
+                }
+            }
+            ah4 uh[NTK][HB], ul[NTK][HB];
+            float iu[NTK];
+#pragma unroll
+            for (int t = 0; t < NTK; ++t) {
+                const float su = token_scale<HB>(u[t]);
+#pragma unroll
+                for (int j = 0; j < HB; ++j) attn_split4(u[t][j][0] * su, u[t][j][1] * su, u[t][j][2] * su, u[t][j][3] * su, uh[t][j], ul[t][j]);
+                iu[t] = i2 / su;
+            }
+#pragma unroll
+            for (int mt = 0; mt < DT; ++mt) {
+#pragma unroll
+                for (int j = 0; j < HB; j += 2) {
+                    const int wo = (16 * mt + r16) * MSH + 16 * (hb + j) + 8 * g;
+                    const ah8 ah = *reinterpret_cast<const ah8*>(W2h + wo), al = *reinterpret_cast<const ah8*>(W2l + wo);
+#pragma unroll
+                    for (int t = 0; t < NTK; ++t) {
+                        f32x4 part = {0, 0, 0, 0};
+                        DTS_MMH3_32(part, ah, al, ah8_of(uh[t][j], uh[t][j + 1]), ah8_of(ul[t][j], ul[t][j + 1]));
+                        out[t][mt] += part * iu[t];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTK; ++t) {
+            if (live[t]) {
+#pragma unroll
+                for (int mt = 0; mt < DT; ++mt) {
+                    const int n0 = 16 * mt + 4 * g;
+                    f32x4 v = out[t][mt] + *reinterpret_cast<const f32x4*>(p.b2 + n0);
+                    v += *reinterpret_cast<const f32x4*>(p.X + tok[t] * (long long)D + n0);
+                    *reinterpret_cast<f32x4*>(p.Y + tok[t] * (long long)D + n0) = v;
+                }
+            }
+        }
+    }
+}
+
 template <int DT, int MT>
 __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_bwd_h_kernel(const MlpBwdArgs p) {
     constexpr int D = 16 * DT, M = 16 * MT, KSH = D + 8, MSH = M + 8;
@@ -1134,6 +1274,162 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_bwd_h_kernel(const Mlp
         } else if (live) {
 #pragma unroll
             for (int mt = 0; mt < DT; ++mt) *reinterpret_cast<f32x4*>(p.Y + tok * (long long)D + 16 * mt + 4 * g) = out[mt];
+        }
+    }
+}
+
+
+// The input-gradient mirror with two 16-token tiles per wave iteration (see dts_mlp_fwd_h2_kernel): every W2^T / W0^T fragment read from LDS serves both tiles.
+template <int DT, int MT>
+__global__ __launch_bounds__(64 * MLP_WAVES) void dts_mlp_bwd_h2_kernel(const MlpBwdArgs p) {
+    constexpr int D = 16 * DT, M = 16 * MT, KSH = D + 8, MSH = M + 8, NTK = 2, HB = MLP_HB2;
+    static_assert(DT % 2 == 0 && MT % 2 == 0, "the two-tile kernel is written for the 16x16x32 products");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    _Float16* W2h = reinterpret_cast<_Float16*>(ldsb);     // [M][KSH]   W2^T
+    _Float16* W2l = W2h + M * KSH;
+    _Float16* W0h = W2l + M * KSH;                          // [D][MSH]   W0^T
+    _Float16* W0l = W0h + D * MSH;
+    float* red = reinterpret_cast<float*>(W0l + D * MSH);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    float s2, s0;
+    mlp_stage_weights<DT, MT>(p.W2T, p.W0T, W2h, W2l, W0h, W0l, red, s2, s0);
+    __syncthreads();
+    const float i2 = 1.0f / s2, i0 = 1.0f / s0;
+    const long long n_tiles = (p.rows + 15) / 16, n_pairs = (n_tiles + NTK - 1) / NTK;
+    const long long pair0 = (long long)blockIdx.x * MLP_WAVES + wave, pstep = (long long)gridDim.x * MLP_WAVES;
+    for (long long pair = pair0; pair < n_pairs; pair += pstep) {
+        asm volatile("" ::: "memory");
+        long long tok[NTK];
+        bool live[NTK];
+        ah4 gh[NTK][DT], gl[NTK][DT];
+        float ig[NTK];
+#pragma unroll
+        for (int t = 0; t < NTK; ++t) {
+            tok[t] = (pair * NTK + t) * 16 + r16;
+            live[t] = tok[t] < p.rows;
+            const float* gr = p.G + (live[t] ? tok[t] : 0) * (long long)D;
+            f32x4 gb[DT];
+#pragma unroll
+            for (int s = 0; s < DT; ++s) gb[s] = live[t] ? *reinterpret_cast<const f32x4*>(gr + mlp_col<true>(s, g)) : f32x4{0, 0, 0, 0};
+            const float sg = token_scale<DT>(gb);                     // gradients carry the batch normaliser (1e-9 at full size): the token's own power of two
+            ig[t] = i2 / sg;
+#pragma unroll
+            for (int s = 0; s < DT; ++s) attn_split4(gb[s][0] * sg, gb[s][1] * sg, gb[s][2] * sg, gb[s][3] * sg, gh[t][s], gl[t][s]);
+        }
+        f32x4 out[NTK][DT];
+#pragma unroll
+        for (int t = 0; t < NTK; ++t)
+#pragma unroll
+            for (int mt = 0; mt < DT; ++mt) out[t][mt] = f32x4{0, 0, 0, 0};
+#pragma unroll 1
+        for (int hb = 0; hb < MT; hb += HB) {
+            f32x4 uc[NTK][HB], e[NTK][HB];
+#pragma unroll
+            for (int t = 0; t < NTK; ++t)
+#pragma unroll
+                for (int j = 0; j < HB; ++j)
+                    uc[t][j] = live[t] ? *reinterpret_cast<const f32x4*>(p.U + tok[t] * (long long)M + 16 * (hb + j) + 4 * g) : f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                const int nt = hb + j;
+                f32x4 acc[NTK];
+#pragma unroll
+                for (int t = 0; t < NTK; ++t) acc[t] = f32x4{0, 0, 0, 0};
+                const int wo = (16 * nt + r16) * KSH + 8 * g;
+#pragma unroll
+                for (int s = 0; s < DT / 2; ++s) {
+                    const ah8 ah = *reinterpret_cast<const ah8*>(W2h + wo + 32 * s), al = *reinterpret_cast<const ah8*>(W2l + wo + 32 * s);
+#pragma unroll
+                    for (int t = 0; t < NTK; ++t) DTS_MMH3_32(acc[t], ah, al, ah8_of(gh[t][2 * s], gh[t][2 * s + 1]), ah8_of(gl[t][2 * s], gl[t][2 * s + 1]));
+                }
+#pragma unroll
+                for (int t = 0; t < NTK; ++t) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[t][q] = acc[t][q] * ig[t] * gelu_grad_f(uc[t][j][q]);
+                    e[t][j] = acc[t];
+                }
+            }
+            ah4 eh[NTK][HB], el[NTK][HB];
+            float ie[NTK];
+#pragma unroll
+            for (int t = 0; t < NTK; ++t) {
+                const float se = token_scale<HB>(e[t]);
+#pragma unroll
+                for (int j = 0; j < HB; ++j) attn_split4(e[t][j][0] * se, e[t][j][1] * se, e[t][j][2] * se, e[t][j][3] * se, eh[t][j], el[t][j]);
+                ie[t] = i0 / se;
+            }
+#pragma unroll
+            for (int mt = 0; mt < DT; ++mt) {
+#pragma unroll
+                for (int j = 0; j < HB; j += 2) {
+                    const int wo = (16 * mt + r16) * MSH + 16 * (hb + j) + 8 * g;
+                    const ah8 ah = *reinterpret_cast<const ah8*>(W0h + wo), al = *reinterpret_cast<const ah8*>(W0l + wo);
+#pragma unroll
+                    for (int t = 0; t < NTK; ++t) {
+                        f32x4 part = {0, 0, 0, 0};
+                        DTS_MMH3_32(part, ah, al, ah8_of(eh[t][j], eh[t][j + 1]), ah8_of(el[t][j], el[t][j + 1]));
+                        out[t][mt] += part * ie[t];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTK; ++t) {
+            if (p.lnx) {                                                 // fused LayerNorm backward, as in the one-tile kernel
+                f32x4 lx[DT], old[DT];
+#pragma unroll
+                for (int mt = 0; mt < DT; ++mt) {
+                    lx[mt] = live[t] ? *reinterpret_cast<const f32x4*>(p.lnx + tok[t] * (long long)D + 16 * mt + 4 * g) : f32x4{0, 0, 0, 0};
+                    old[mt] = live[t] ? *reinterpret_cast<const f32x4*>(p.Y + tok[t] * (long long)D + 16 * mt + 4 * g) : f32x4{0, 0, 0, 0};
+                }
+                float sum = 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < DT; ++mt) sum += (lx[mt][0] + lx[mt][1]) + (lx[mt][2] + lx[mt][3]);
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float mean = sum / (float)D;
+                float q = 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < DT; ++mt)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        lx[mt][c] -= mean;
+                        q += lx[mt][c] * lx[mt][c];
+                    }
+                q += __shfl_xor(q, 16);
+                q += __shfl_xor(q, 32);
+                const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
+                float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < DT; ++mt) {
+                    const f32x4 gw = *reinterpret_cast<const f32x4*>(p.lng + 16 * mt + 4 * g);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        lx[mt][c] *= rstd;                               // xhat
+                        out[t][mt][c] *= gw[c];
+                        m1 += out[t][mt][c];
+                        m2 += out[t][mt][c] * lx[mt][c];
+                    }
+                }
+                m1 += __shfl_xor(m1, 16);
+                m1 += __shfl_xor(m1, 32);
+                m2 += __shfl_xor(m2, 16);
+                m2 += __shfl_xor(m2, 32);
+                m1 /= (float)D;
+                m2 /= (float)D;
+                if (live[t]) {
+#pragma unroll
+                    for (int mt = 0; mt < DT; ++mt) {
+                        f32x4 v;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = old[mt][c] + rstd * (out[t][mt][c] - m1 - lx[mt][c] * m2);
+                        *reinterpret_cast<f32x4*>(p.Y + tok[t] * (long long)D + 16 * mt + 4 * g) = v;
+                    }
+                }
+            } else if (live[t]) {
+#pragma unroll
+                for (int mt = 0; mt < DT; ++mt) *reinterpret_cast<f32x4*>(p.Y + tok[t] * (long long)D + 16 * mt + 4 * g) = out[t][mt];
+            }
         }
     }
 }
