@@ -4,7 +4,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <cmath>
+#include <algorithm>
 #include "nst_gemm.h"
+#include "stg_down_mfma.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
@@ -106,6 +109,61 @@ int main() {
         hipLaunchKernelGGL(fill_f16, dim3(1536 * 512 / 256), dim3(256), 0, 0, Wh, 1536LL * 512, 4u, 12000.0f);
         hipLaunchKernelGGL(fill_f16, dim3(1536 * 512 / 256), dim3(256), 0, 0, Wl, 1536LL * 512, 5u, 4.0f);
         CK(hipDeviceSynchronize());
+    }
+    // the "downsampling" products on their own kernel (csrc/stg_down_mfma.h) against the general one: time and the largest difference of the outputs
+    if (getenv("GEMM_DOWN")) {
+        struct S3 { long long M; int N, K; const char* name; } sh3[] = {
+            {25600, 80, 1600, "down T200"}, {25600, 160, 3200, "down cat"}, {25600, 80, 800, "down T100"}, {25600, 80, 3200, "N 80 K 3200"},
+            {76800, 80, 1600, "nss 12 win"}, {76800, 160, 3200, "nss 12 win"}, {25500, 72, 1596, "ragged"}, {130, 20, 48, "tiny"}};
+        float* Y2;
+        CK(hipMalloc(&Y2, 76800LL * 160 * 4));
+        if (getenv("GEMM_DOWN_PROBE")) {                  // where does a stage of the K = 3200 product go?  GEMM_DOWN_PROBE=5: N = 80, =10: N = 160
+            const bool wide = atoi(getenv("GEMM_DOWN_PROBE")) == 10;
+            const int Np = wide ? 160 : 80;
+            NstGemmHArgs a{X, 3200, Wh, Wl, 1.0f / 8192.0f, bias, nullptr, Np, Y2, Np, 25600, Np, 3200, 0, 3200};
+#define PROBE_RUN_NT(NT_, P_) do { \
+            const int lds = (2 * 4 * (16 * NT_ * 32 + DN_PAD) + DN_WAVES * 4 * (16 * DN_MT * 32 + DN_PAD)) * 2; \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stg_down_h3_kernel<NT_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); \
+            hipLaunchKernelGGL((stg_down_h3_kernel<NT_, P_>), dim3(200), dim3(64 * DN_WAVES), lds, 0, a); \
+            (void)hipEventRecord(e0, 0); \
+            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((stg_down_h3_kernel<NT_, P_>), dim3(200), dim3(64 * DN_WAVES), lds, 0, a); \
+            (void)hipEventRecord(e1, 0); CK(hipEventSynchronize(e1)); float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); \
+            printf("N=%d probe %2d: %.1f us\n", Np, P_, ms * 100); } while (0)
+#define PROBE_RUN(P_) do { if (wide) PROBE_RUN_NT(10, P_); else PROBE_RUN_NT(5, P_); } while (0)
+            PROBE_RUN(0); PROBE_RUN(1); PROBE_RUN(2); PROBE_RUN(4); PROBE_RUN(8); PROBE_RUN(12); PROBE_RUN(14); PROBE_RUN(13); PROBE_RUN(11);
+            return 0;
+        }
+        for (const S3& s : sh3) {
+            const int ldw = (s.K + 31) & ~31;
+            CK(hipMemset(Wh, 0, 1536 * 512 * 2)); CK(hipMemset(Wl, 0, 1536 * 512 * 2));                 // columns K..ldw of a weight row are zero
+            for (int n = 0; n < s.N; ++n) {
+                hipLaunchKernelGGL(fill_f16, dim3((s.K + 255) / 256), dim3(256), 0, 0, Wh + (size_t)n * ldw, (long long)s.K, 40u + n, 12000.0f);
+                hipLaunchKernelGGL(fill_f16, dim3((s.K + 255) / 256), dim3(256), 0, 0, Wl + (size_t)n * ldw, (long long)s.K, 900u + n, 4.0f);
+            }
+            NstGemmHArgs a{X, s.K, Wh, Wl, 1.0f / 8192.0f, bias, nullptr, s.N, Y, s.N, s.M, s.N, s.K, 0, ldw};
+            NstGemmHArgs b = a;
+            b.Y = Y2;
+            const float tl = runlite<0>(a, 10);
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            stg_down_h3_launch(b, 0);
+            (void)hipEventRecord(e0, 0);
+            for (int i = 0; i < 10; ++i) stg_down_h3_launch(b, 0);
+            (void)hipEventRecord(e1, 0);
+            CK(hipEventSynchronize(e1));
+            float td = 0;
+            (void)hipEventElapsedTime(&td, e0, e1);
+            td /= 10;
+            std::vector<float> h1((size_t)s.M * s.N), h2((size_t)s.M * s.N);
+            CK(hipMemcpy(h1.data(), Y, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), Y2, h2.size() * 4, hipMemcpyDeviceToHost));
+            double worst = 0, big = 0;
+            for (size_t i = 0; i < h1.size(); ++i) { worst = std::max(worst, (double)fabsf(h1[i] - h2[i])); big = std::max(big, (double)fabsf(h1[i])); }
+            const double mb = (double)s.M * (s.K + s.N) * 4 / 1e6;
+            printf("%-12s M=%6lld N=%4d K=%4d: general %.1f us (%.2f TB/s) | down kernel %.1f us (%.2f TB/s) | max |diff| %.3g of max |y| %.3g\n", s.name, s.M, s.N, s.K,
+                   tl * 1e3, mb / tl / 1e3, td * 1e3, mb / td / 1e3, worst, big);
+        }
+        return 0;
     }
     // DiffSTG at BASELINE configs[4] (4 windows x 6400 node rows per launch; C = Td_h c_out, k = T + 1 convolutions as [rows][c_out T] x [c_out T][C])
     if (getenv("GEMM_STG")) {

@@ -21,6 +21,7 @@
 #include "chain_common.h"
 #include "nst_gemm.h"
 #include "stg_tcn_mfma.h"
+#include "stg_down_mfma.h"
 
 namespace {
 
@@ -654,7 +655,8 @@ constexpr int STG_KSPLIT_MAX = 4;                       // partial buffers carve
 // split products (MPV_STG_KSPLIT=0: as many ways as it takes to give the chip 3 workgroups per CU, at most 4; the graph-conv product sums the partial
 // tensors as it loads them, fixed order) average 84.9 us per launch against 75.8 us unsplit on the same box (8.64 against 8.83 windows/s) -- alone on the
 // device the long-K products are concurrency-bound (1.6-2.4 TB/s from 200-400 workgroups), inside the step the neighbouring launches' tails fill the
-// chip anyway.  Off unless MPV_STG_KSPLIT is set (n >= 2: that many ways; 0: the automatic rule).
+// chip anyway.  Off unless MPV_STG_KSPLIT is set (n >= 2: that many ways; 0: the automatic rule).  (The automatic rule also rounds badly: 200 tiles x 4
+// ways = 800 workgroups on 2 x 256 slots is two rounds.  Superseded by the products' own kernel, stg_down_mfma.h, which gemm() picks when unsplit.)
 int down_ksplit(mpv_ctx* ctx, const StgEngine& e, const float* W, int K, int N, long long rows) {
     static const int forced = getenv("MPV_STG_KSPLIT") ? atoi(getenv("MPV_STG_KSPLIT")) : 1;
     if (e.d.gemm == MPV_GEMM_F32 || e.split.find(W) == e.split.end() || K % 4 != 0 || N % 4 != 0) return 1;
@@ -672,7 +674,8 @@ int gemm(mpv_ctx* ctx, const StgEngine& e, const float* X, long long ldx, const 
         // two-term f16 split on the f16 matrix pipe, fp32-equivalent: the k = T+1 convolutions and the graph-conv Linear maps
         NstGemmHArgs a{X, ldx, sp->second.h, sp->second.l, sp->second.inv_scale, bias, r1, ldy, Y, ldy, rows, N, K, relu, sp->second.ldw};
         a.ksplit = ksplit; a.ypart = ypart; a.xparts = xparts; a.xpart = xpart; a.xbias = xbias;
-        nst_gemm_h3_launch(a, ctx->stream);
+        if (stg_down_fits(a)) stg_down_h3_launch(a, ctx->stream);            // long K, N <= 160: X streamed straight into the MFMA operands (stg_down_mfma.h)
+        else nst_gemm_h3_launch(a, ctx->stream);
         MPV_HIP_TRY(ctx, hipGetLastError());
         return MPV_OK;
     }
