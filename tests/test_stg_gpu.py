@@ -44,6 +44,27 @@ def test_ugnet_forward_matches_reference(z, tag, gemm):
 
 
 @pytest.mark.parametrize("tag", ["tiny", "ddpm", "c5"])
+def test_downsampling_kernel_forced_on_small_shapes(z, tag, monkeypatch):
+    """csrc/stg_down_mfma.h takes the k = T + 1 "downsampling" products only at K >= 512 by itself; MPV_STG_DOWN=1 sends every product with
+    N <= 160 and no epilogue through it (K down to 24, N not a multiple of 16, row counts that leave most of a 128-row block empty), =0 none.
+    Both against the reference's fixtures, and against each other far below the tolerance (two fp32-equivalent split-f16 kernels)."""
+    m, net, V = build(z, tag, gemm_mode="f16x3")
+    ctx = m.native_context()
+    ctx.stg_set_graph(T(z["edge_%s" % tag]), V)
+    x, xm = T(z["x_%s" % tag]).to(dev()), T(z["xm_%s" % tag]).to(dev())
+    t = net["diffusion_steps"] // 2
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MPV_STG_DOWN", mode)
+        out[mode] = ctx.stg_forward(x, xm, t).clone()
+        err = rel_err(out[mode], z["eps_%s_t%d" % (tag, t)])
+        print("DiffSTG UGnet %s MPV_STG_DOWN=%s rel err %.3e" % (tag, mode, err))
+        assert err < RTOL
+    monkeypatch.delenv("MPV_STG_DOWN")
+    assert rel_err(out["1"], out["0"].cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["tiny", "ddpm", "c5"])
 def test_evaluation_step_matches_reference(z, tag):
     """DiffSTG.evaluation_step (parallel graph copies, sequential passes, cosine / linear time pairs, DDIM with the DDPM last
     step) with the reference's recorded normal draws injected in their order."""
