@@ -293,7 +293,21 @@ typedef struct {
  *    20 upsampling.weight [co][co][1][T+1] (ConvTranspose2d: [in][out])  21 upsampling.bias  22 shortcut.weight [co][ci] | NULL  23 shortcut.bias | NULL
  * kind 1: Downsample conv (1,3) stride 2 pad 1: w[0] weight [c][c][1][3], w[1] bias.   kind 2: Upsample ConvTranspose (1,4) stride 2 pad 1:
  *    w[0] weight [c][c][1][4] ([in][out]), w[1] bias.
- * push: the step's output is appended to the skip stack (down path); pop: the block concatenates the popped skip behind its input. */
+ * push: the step's output is appended to the skip stack (down path); pop: the block concatenates the popped skip behind its input.
+ *
+ * Round 4 (additive: no layout change): the other layers models/layer/gnn_conv.py:4-28 can put into a ResidualBlock's SpatialBlock, as further
+ * residual-block kinds.  Everything but w[12..19] is as for kind 0; C = Td_h co; restated from torch_geometric's published definitions (unpinned):
+ * kind MPV_STG_RES_SAGE_MEAN  SAGEConv(aggr="mean"): out_i = lin_l(mean_{j->i} x_j) + lin_r(x_i)
+ * kind MPV_STG_RES_SUM        GraphConv(aggr="add") / SAGEConv(aggr="add" | "sum"): out_i = lin_rel(sum_{j->i} x_j) + lin_root(x_i)
+ *      both: w[12] lin_l | lin_rel .weight [C][C]   w[13] its bias [C] | NULL   w[14] lin_r | lin_root .weight [C][C] | NULL (root_weight=False)
+ * kind MPV_STG_RES_GCN        GCNConv (add_self_loops, symmetric normalisation by in-degree + 1):  w[12] lin.weight [C][C]   w[13] bias [C] | NULL
+ * kind MPV_STG_RES_GAT        GATConv(heads=H, concat=True, add_self_loops=True), eval mode:  w[12] lin.weight [C][C] (row h D + d: head h)
+ *      w[13] bias [C] | NULL   w[14] att_src [H][C/H]   w[15] att_dst [H][C/H]   w[16] -> two floats { H, negative_slope }
+ * The block applies ReLU behind the layer (SpatialBlock.forward, DiffSTG/ugnet.py:36-46) in every kind. */
+#define MPV_STG_RES_SAGE_MEAN 10
+#define MPV_STG_RES_SUM 11
+#define MPV_STG_RES_GCN 12
+#define MPV_STG_RES_GAT 13
 typedef struct {
     int32_t kind, c_in, c_out, T, pop, push;
     const float* w[24];

@@ -27,22 +27,22 @@ NET = "model.diffussion_model."          # (sic) NsDiff_net.py:255
 
 def ugnet(sd: Dict[str, torch.Tensor], net_param: dict, y_t, y0hat, gx, t: torch.Tensor, edge_index):
     """UGnet.forward (ugnet.py:257-292): y_t, y0hat, gx [N, T, F], t [1] -> (eps, sigma) [N, T, F]."""
-    td_h, d_h = net_param["Td_h"], net_param["d_h"]
+    td_h, d_h, gp = net_param["Td_h"], net_param["d_h"], net_param.get("gnn_param")
     x = torch.cat((y_t, y0hat, gx), dim=-1).unsqueeze(2).transpose(1, 3)             # (N, 3F, 1, T)   :262-263
     xx = F.conv2d(x, sd[NET + "x_proj.weight"], sd[NET + "x_proj.bias"])
     temb = STG.time_embedding(t, d_h)
     hs = [xx]
     for kind, p in STG._steps(sd, NET + "down."):
-        xx = STG.residual_block(sd, p, xx, temb, edge_index, td_h) if kind == "res" else \
+        xx = STG.residual_block(sd, p, xx, temb, edge_index, td_h, gp) if kind == "res" else \
             F.conv2d(xx, sd[p + "weight"], sd[p + "bias"], stride=(1, 2), padding=(0, 1))
         hs.append(xx)
-    xx = STG.residual_block(sd, NET + "middle.res1.", xx, temb, edge_index, td_h)
-    xx = STG.residual_block(sd, NET + "middle.res2.", xx, temb, edge_index, td_h)
+    xx = STG.residual_block(sd, NET + "middle.res1.", xx, temb, edge_index, td_h, gp)
+    xx = STG.residual_block(sd, NET + "middle.res2.", xx, temb, edge_index, td_h, gp)
     for kind, p in STG._steps(sd, NET + "up."):
         if kind == "conv":
             xx = F.conv_transpose2d(xx, sd[p + "weight"], sd[p + "bias"], stride=(1, 2), padding=(0, 1))
         else:
-            xx = STG.residual_block(sd, p, torch.cat((xx, hs.pop()), dim=1), temb, edge_index, td_h)
+            xx = STG.residual_block(sd, p, torch.cat((xx, hs.pop()), dim=1), temb, edge_index, td_h, gp)
     e = F.conv2d(xx, sd[NET + "out.0.weight"], sd[NET + "out.0.bias"])
     e = F.linear(e, sd[NET + "out.1.weight"], sd[NET + "out.1.bias"])               # Linear(T, T) over the time axis
     h = e.squeeze(2).transpose(1, 2)                                                 # (N, T, d_h)    :289

@@ -95,4 +95,4 @@ def test_mirror_loads_reference_state_dict_strictly(z):
     plan = m._plan()
     assert tuple(plan.shape) == (net["inference_diffusion_steps"], 6) and plan.dtype == torch.float64
     with pytest.raises(NotImplementedError):
-        diffusion_models("DiffSTG", dict(net, gnn_name="GCNConv"))
+        diffusion_models("DiffSTG", dict(net, gnn_name="PNAConv"))             # (no native kernel; SAGE / Graph / GCN / GAT have: test_gnn_variants.py)

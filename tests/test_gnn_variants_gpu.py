@@ -1,0 +1,107 @@
+"""GPU parity (-m gpu) of the graph-convolution variants of a SpatialBlock (SAGEConv mean / add, GraphConv, GCNConv, GATConv; reference
+models/layer/gnn_conv.py:4-28) through the C ABI, in DiffSTG's and NsDiff_spatial's UGnet, against the CPU oracle's restatements (UNPINNED:
+torch_geometric is absent, no reference fixture contains these layers).  Tolerance 1e-4, elementwise, as for the gated layer."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffstg_oracle as O
+from test_gnn_variants import VARIANTS
+from test_gpu_parity import dev, rel_err
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+RTOL = 1e-4
+
+
+def seeded(model, seed):
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if ".spatial.gnn." in name:
+                p.copy_(torch.randn_like(p) * (0.5 if p.dim() > 1 else 0.2))          # biases and attention vectors away from their zero / xavier init
+    return model
+
+
+def with_self_loop(edge):
+    """The fixture's graph + one self loop and one parallel edge: GCN / GAT replace input self loops by one per node, sums count parallel edges."""
+    extra = torch.tensor([[2, int(edge[0, 0])], [2, int(edge[1, 0])]], dtype=edge.dtype)
+    return torch.cat((edge, extra), dim=1)
+
+
+@pytest.mark.parametrize("gemm", ["f16x3", "f32"])
+@pytest.mark.parametrize("name,param", VARIANTS)
+def test_diffstg_ugnet_with_the_variant_matches_the_oracle(name, param, gemm):
+    from conftest import GOLDEN
+    from mpv_amd.models.models import diffusion_models
+    from test_diffstg_oracle import case
+    z = np.load(GOLDEN / "diffstg_cases.npz")
+    for tag in ("tiny", "ddpm"):
+        net, V = case(z, tag)
+        net = dict(net, gnn_name=name, gnn_param=param)
+        torch.manual_seed(5)
+        m = seeded(diffusion_models("DiffSTG", dict(net, device=dev(), gemm_mode=gemm)), 7).to(dev()).eval()
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        edge = with_self_loop(T(z["edge_%s" % tag]))
+        ctx = m.native_context()
+        ctx.stg_set_graph(edge, V)
+        x, xm = T(z["x_%s" % tag]), T(z["xm_%s" % tag])
+        for t in (1, net["diffusion_steps"]):
+            want = O.ugnet(sd, net, x, torch.tensor([float(t)]), xm, O.duplicate_edge_index(x.shape[0] // V, edge, V))
+            err = rel_err(ctx.stg_forward(x.to(dev()), xm.to(dev()), t), want)
+            print("DiffSTG UGnet %s %s %s t=%d (%s) rel err %.3e" % (name, param.get("aggr", ""), tag, t, gemm, err))
+            assert err < RTOL
+
+
+@pytest.mark.parametrize("name,param", [VARIANTS[0], VARIANTS[3], VARIANTS[4]])
+def test_diffstg_evaluation_step_with_the_variant_matches_the_oracle(name, param):
+    """The whole sampler (graph copies, DDIM / DDPM plan, the oracle's draws replayed in order) on a SAGEConv / GCNConv / GATConv network."""
+    from conftest import GOLDEN
+    from mpv_amd.models.models import diffusion_models
+    from test_diffstg_oracle import case
+    z = np.load(GOLDEN / "diffstg_cases.npz")
+    net, V = case(z, "tiny")
+    net = dict(net, gnn_name=name, gnn_param=param)
+    torch.manual_seed(5)
+    m = seeded(diffusion_models("DiffSTG", dict(net, device=dev())), 9).to(dev()).eval()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    batch, edge = T(z["batch_tiny"]), T(z["edge_tiny"])
+    g, draws = torch.Generator().manual_seed(31), []
+
+    def noise(shape):
+        draws.append(torch.randn(shape, generator=g))
+        return draws[-1]
+
+    want = O.evaluation_step(sd, net, batch, edge, noise)
+    data = types.SimpleNamespace(x=batch, edge_index=edge, num_nodes=V)
+    outs, _ = m.evaluation_step(data, noise=torch.cat([d.reshape(-1) for d in draws]))
+    err = rel_err(outs, want)
+    print("DiffSTG evaluation_step %s rel err %.3e" % (name, err))
+    assert tuple(outs.shape) == tuple(want.shape) and err < RTOL
+
+
+@pytest.mark.parametrize("name,param", VARIANTS)
+def test_nsdiff_spatial_ugnet_with_the_variant_matches_the_oracle(name, param):
+    from conftest import GOLDEN
+    from oracle import nsdiff_spatial_oracle as NSS
+    from mpv_amd.models.models import diffusion_models
+    from test_nsdiff_spatial_oracle import case
+    z = np.load(GOLDEN / "nsdiff_spatial_cases.npz")
+    net, V = case(z, "f2")
+    net = dict(net, gnn_name=name, gnn_param=param)
+    torch.manual_seed(5)
+    m = seeded(diffusion_models("NsDiff_spatial", dict(net, device=dev()), train_model_select="NsDiff_model"), 13).to(dev()).eval()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    edge = with_self_loop(T(z["edge_f2"]))
+    ctx = m.native_context()
+    ctx.nss_set_graph(edge, V)
+    y, y0, gx = (T(z["%s_f2" % k]) for k in ("y", "y0", "gx"))
+    pe = NSS.duplicate_edge_index(y.shape[0] // V, edge, V)
+    for t in (0, net["diffusion_steps"] - 1):
+        eps, sig = ctx.nss_forward(y.to(dev()), y0.to(dev()), gx.to(dev()), t)
+        we, ws = NSS.ugnet(sd, net, y, y0, gx, torch.tensor([t]), pe)
+        e1, e2 = rel_err(eps, we), rel_err(sig, ws)
+        print("NsDiff_spatial UGnet %s t=%d: eps rel err %.3e, sigma rel err %.3e" % (name, t, e1, e2))
+        assert e1 < RTOL and e2 < RTOL

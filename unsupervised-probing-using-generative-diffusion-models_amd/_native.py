@@ -553,14 +553,10 @@ class Context:
                 tensors = [m.tcn1.conv.weight, m.tcn1.conv.bias,
                            m.tcn1.shortcut.weight if m.tcn1.shortcut is not None else None, m.tcn1.shortcut.bias if m.tcn1.shortcut is not None else None,
                            m.t_conv.weight, m.t_conv.bias, m.tcn2.conv.weight, m.tcn2.conv.bias, m.norm.weight, m.norm.bias,
-                           m.downsampling.weight, m.downsampling.bias, g.lin_key.weight, g.lin_key.bias, g.lin_query.weight, g.lin_query.bias,
-                           g.lin_value.weight, g.lin_value.bias,
-                           g.lin_skip.weight if g.lin_skip is not None else torch.zeros_like(g.lin_key.weight),
-                           g.bias if g.bias is not None else torch.zeros_like(g.lin_key.bias),
-                           m.upsampling.weight, m.upsampling.bias]
+                           m.downsampling.weight, m.downsampling.bias] + list(g.native_tensors()) + [m.upsampling.weight, m.upsampling.bias]
                 has_sc = not isinstance(m.shortcut, torch.nn.Identity)
                 tensors += [m.shortcut.weight if has_sc else None, m.shortcut.bias if has_sc else None]
-                arr[i].kind, arr[i].c_in, arr[i].c_out, arr[i].T = 0, m.c_in, m.c_out, m.T
+                arr[i].kind, arr[i].c_in, arr[i].c_out, arr[i].T = int(g.native_kind()), m.c_in, m.c_out, m.T      # 0 gated, 10.. the other layers
                 arr[i].pop, arr[i].push = int(st["pop"]), int(st["push"])
             else:
                 c = m.conv.weight.shape[0]

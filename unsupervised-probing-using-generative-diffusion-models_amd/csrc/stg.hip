@@ -261,6 +261,74 @@ __global__ void stg_gate_kernel(const float* __restrict__ kqvs, const float* __r
     out[i] = fmaxf(a, 0.0f);
 }
 
+// ---- the other graph convolutions of models/layer/gnn_conv.py:4-28 (round 4; restated from torch_geometric's published definitions, unpinned) ------
+// The Linear maps commute with the aggregation, so each layer is ONE product ar [N][NG] = z W^T (gemm(), like the gated layer's four maps) and one
+// gather over the incoming edges in edge order.  MODE 1 SAGEConv(aggr = "mean"): relu(lin_l(mean_j x_j) + lin_r(x_i)) -- ar = (W_l x | W_r x), bias =
+// lin_l.bias; a node without incoming edges aggregates 0.  MODE 2 GraphConv / SAGEConv(aggr = "add"): the sum instead of the mean.  MODE 3 GCNConv:
+// relu(sum_j (d_i d_j)^-1/2 W x_j + b) over the incoming edges and ONE self loop per node (self loops of the input are replaced by it), d = in-degree
+// without self loops + 1 (gcn_norm with add_remaining_self_loops, unit edge weights).
+template <int MODE>
+__global__ void stg_aggr_kernel(const float* __restrict__ ar, int NG, const float* __restrict__ bias, const int* __restrict__ row_ptr,
+                                const int* __restrict__ col_idx, const int* __restrict__ deg /* in-degree without self loops */, int V, int C,
+                                long long n, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // node*C + ch
+    if (i >= n) return;
+    const int ch = (int)(i % C);
+    const long long node = i / C;
+    const int v = (int)(node % V);
+    const long long base = node - v;
+    const int e0 = row_ptr[v], e1 = row_ptr[v + 1];
+    float a = 0.0f;
+    if (MODE == 3) {
+        const float di = 1.0f / sqrtf((float)(deg[v] + 1));
+        for (int e = e0; e < e1; ++e) {
+            const int j = col_idx[e];
+            if (j == v) continue;                                                // (a self loop of the input is replaced by the one added here)
+            const float dj = 1.0f / sqrtf((float)(deg[j] + 1));
+            a += (dj * di) * ar[(base + j) * NG + ch];
+        }
+        a += (di * di) * ar[node * NG + ch];                                     // the self loop (appended behind the edges)
+    } else {
+        for (int e = e0; e < e1; ++e) a += ar[(base + col_idx[e]) * NG + ch];
+        if (MODE == 1) a = a / (float)max(e1 - e0, 1);
+        a += ar[node * NG + C + ch];                                             // root weight (zeros when the layer has none)
+    }
+    out[i] = fmaxf(a + bias[ch], 0.0f);
+}
+
+// GATConv(heads = H, concat = True, add_self_loops = True), eval mode (no attention dropout): ar = (x' = W x [C = H D] | s_src [H] | s_dst [H]) with
+// s_src[j][h] = <x'_j[h], att_src[h]> (folded into the product as H extra weight rows att_src[h]^T W_h, likewise s_dst);
+// alpha_ij = softmax_j leaky_relu(s_src[j] + s_dst[i]) over the incoming edges (self loops in the input dropped) and one self loop;
+// out_i = relu(sum_j alpha_ij x'_j + bias).  Softmax as torch_geometric.utils.softmax: exp(e - max) / (sum + 1e-16).
+__global__ void stg_gat_kernel(const float* __restrict__ ar, int NG, const float* __restrict__ bias, const int* __restrict__ row_ptr,
+                               const int* __restrict__ col_idx, int V, int C, int H, float slope, long long n, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // node*C + ch
+    if (i >= n) return;
+    const int ch = (int)(i % C), h = ch / (C / H);
+    const long long node = i / C;
+    const int v = (int)(node % V);
+    const long long base = node - v;
+    const int e0 = row_ptr[v], e1 = row_ptr[v + 1];
+    const float sd = ar[node * NG + C + H + h];
+    auto score = [&](long long j) { const float t = ar[j * NG + C + h] + sd; return t > 0.0f ? t : slope * t; };
+    const float self = score(node);
+    float m = self;
+    for (int e = e0; e < e1; ++e)
+        if (col_idx[e] != v) m = fmaxf(m, score(base + col_idx[e]));
+    float den = 0.0f, a = 0.0f;
+    for (int e = e0; e < e1; ++e) {
+        if (col_idx[e] == v) continue;
+        const long long j = base + col_idx[e];
+        const float w = expf(score(j) - m);
+        den += w;
+        a += w * ar[j * NG + ch];
+    }
+    const float ws = expf(self - m);
+    den += ws;
+    a += ws * ar[node * NG + ch];
+    out[i] = fmaxf(a / (den + 1e-16f) + bias[ch], 0.0f);
+}
+
 // ---- block output: up [N][co*T] + shortcut(x) ---------------------------------------------------------------------------------------
 __global__ void stg_res_out_kernel(const float* __restrict__ up, const float* __restrict__ src1, int c1, const float* __restrict__ src2, int c2,
                                    const float* __restrict__ ws, const float* __restrict__ bs, int co, int T, long long n, float* out) {
@@ -568,6 +636,8 @@ struct TcnFrag {                                     // matrix-pipe TCN (stg_tcn
 };
 struct Step {
     int kind = 0, c_in = 0, c_out = 0, T = 0, pop = 0, push = 0;
+    int gnn = 0, ng = 0, heads = 1;                  // graph convolution of a residual block: 0 gated, 1 SAGE mean, 2 sum, 3 GCN, 4 GAT; columns of its product
+    float slope = 0.2f;
     ResW r{};
     const float *cw = nullptr, *cb = nullptr;        // down / up sample conv
     TcnFrag f{};
@@ -857,12 +927,21 @@ int unet(mpv_ctx* ctx, StgEngine& e, long long N, int t, const float** out_cur) 
             const int ks = down_ksplit(ctx, e, s.r.wdown, co * s.T, C, N);
             if (ks > 1) {
                 STG_TRY(gemm(ctx, e, e.hn, (long long)co * s.T, s.r.wdown, nullptr, co * s.T, C, N, e.z, C, 0, nullptr, ks, (long long)N * C));
-                STG_TRY(gemm(ctx, e, e.z, C, s.r.wg, s.r.bg4, C, 4 * C, N, e.kqvs, 4 * C, 0, nullptr, 1, 0, ks, (long long)N * C, s.r.bdown));
+                STG_TRY(gemm(ctx, e, e.z, C, s.r.wg, s.r.bg4, C, s.ng, N, e.kqvs, s.ng, 0, nullptr, 1, 0, ks, (long long)N * C, s.r.bdown));
             } else {
                 STG_TRY(gemm(ctx, e, e.hn, (long long)co * s.T, s.r.wdown, s.r.bdown, co * s.T, C, N, e.z, C));
-                STG_TRY(gemm(ctx, e, e.z, C, s.r.wg, s.r.bg4, C, 4 * C, N, e.kqvs, 4 * C));
+                STG_TRY(gemm(ctx, e, e.z, C, s.r.wg, s.r.bg4, C, s.ng, N, e.kqvs, s.ng));
             }
-            hipLaunchKernelGGL(stg_gate_kernel, g1d(N * C), dim3(256), 0, st, e.kqvs, s.r.gbias, e.graph, e.graph + e.V + 1, e.V, C, N * C, e.sp);
+            const int* rp = e.graph;
+            const int* ci_ = e.graph + e.V + 1;
+            const int* dg_ = ci_ + std::max(e.E, 1);
+            switch (s.gnn) {
+                case 0: hipLaunchKernelGGL(stg_gate_kernel, g1d(N * C), dim3(256), 0, st, e.kqvs, s.r.gbias, rp, ci_, e.V, C, N * C, e.sp); break;
+                case 1: hipLaunchKernelGGL(stg_aggr_kernel<1>, g1d(N * C), dim3(256), 0, st, e.kqvs, s.ng, s.r.gbias, rp, ci_, dg_, e.V, C, N * C, e.sp); break;
+                case 2: hipLaunchKernelGGL(stg_aggr_kernel<2>, g1d(N * C), dim3(256), 0, st, e.kqvs, s.ng, s.r.gbias, rp, ci_, dg_, e.V, C, N * C, e.sp); break;
+                case 3: hipLaunchKernelGGL(stg_aggr_kernel<3>, g1d(N * C), dim3(256), 0, st, e.kqvs, s.ng, s.r.gbias, rp, ci_, dg_, e.V, C, N * C, e.sp); break;
+                default: hipLaunchKernelGGL(stg_gat_kernel, g1d(N * C), dim3(256), 0, st, e.kqvs, s.ng, s.r.gbias, rp, ci_, e.V, C, s.heads, s.slope, N * C, e.sp); break;
+            }
             MPV_HIP_TRY(ctx, hipGetLastError());
             // up-sampling product with the block's shortcut added in its epilogue: the block input itself (identity) or the 1x1
             // convolution the TCN kernel left in e.up
@@ -945,12 +1024,23 @@ int load_engine(mpv_ctx* ctx, const std::string& who, int mode, const mpv_stg_de
         const mpv_stg_step& s = steps[i];
         Step st;
         st.kind = s.kind; st.c_in = s.c_in; st.c_out = s.c_out; st.T = s.T; st.pop = s.pop; st.push = s.push;
+        if (s.kind >= MPV_STG_RES_SAGE_MEAN && s.kind <= MPV_STG_RES_GAT) { st.gnn = s.kind - MPV_STG_RES_SAGE_MEAN + 1; st.kind = 0; }
+        else if (s.kind < 0 || s.kind > 2) { delete e; return mpv_fail(ctx, MPV_EINVAL, who + ": unknown step kind"); }
         if (s.c_in < 1 || s.c_out < 1 || s.T < 2 || ((s.c_out * s.T) & 3) || ((Td * s.c_out) & 3)) { delete e; return mpv_fail(ctx, MPV_EINVAL, who + ": bad step shape"); }
         std::vector<size_t>& o = offs[i];
-        if (s.kind == 0) {
+        if (st.kind == 0) {
             const int ci = s.c_in, co = s.c_out, Ts = s.T, C = Td * co;
-            for (int k : {0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21})
+            for (int k : {0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 20, 21})
                 if (!s.w[k]) { delete e; return mpv_fail(ctx, MPV_EINVAL, who + ": NULL tensor in a residual block"); }
+            if (st.gnn == 0)
+                for (int k : {13, 14, 15, 16, 17, 18, 19})
+                    if (!s.w[k]) { delete e; return mpv_fail(ctx, MPV_EINVAL, who + ": NULL tensor in a residual block"); }
+            if (st.gnn == 4) {
+                if (!s.w[14] || !s.w[15] || !s.w[16]) { delete e; return mpv_fail(ctx, MPV_EINVAL, who + ": GATConv needs att_src, att_dst and {heads, negative_slope}"); }
+                st.heads = (int)s.w[16][0];
+                st.slope = s.w[16][1];
+                if (st.heads < 1 || C % st.heads != 0 || (float)st.heads != s.w[16][0]) { delete e; return mpv_fail(ctx, MPV_EINVAL, who + ": GATConv heads must divide the channels"); }
+            }
             auto mid = [&](const float* w, int o_, int i_) {            // [o][i][3][3] -> middle row [o][i][3]
                 std::vector<float> m((size_t)o_ * i_ * 3);
                 for (int a = 0; a < o_ * i_; ++a)
@@ -998,12 +1088,30 @@ int load_engine(mpv_ctx* ctx, const std::string& who, int mode, const mpv_stg_de
                         }
                 }
             o.push_back(putv(wd)); o.push_back(putv(bd));
-            std::vector<float> wg((size_t)4 * C * C), bg((size_t)4 * C, 0.0f);
-            for (int part = 0; part < 4; ++part) {
-                std::memcpy(&wg[(size_t)part * C * C], s.w[12 + 2 * part], sizeof(float) * C * C);   // key.w, query.w, value.w at 12, 14, 16; skip.w at 18
-                if (part < 3) std::memcpy(&bg[(size_t)part * C], s.w[13 + 2 * part], sizeof(float) * C);
+            // the graph convolution's Linear maps as ONE weight matrix [ng][C] (+ a bias per product column, + the bias added behind the aggregation)
+            const int H = st.heads, D = C / H;
+            st.ng = st.gnn == 0 ? 4 * C : (st.gnn == 3 ? C : (st.gnn == 4 ? (C + 2 * H + 3) & ~3 : 2 * C));
+            std::vector<float> wg((size_t)st.ng * C, 0.0f), bg((size_t)st.ng, 0.0f), gb((size_t)C, 0.0f);
+            if (st.gnn == 0) {
+                for (int part = 0; part < 4; ++part) {
+                    std::memcpy(&wg[(size_t)part * C * C], s.w[12 + 2 * part], sizeof(float) * C * C);   // key.w, query.w, value.w at 12, 14, 16; skip.w at 18
+                    if (part < 3) std::memcpy(&bg[(size_t)part * C], s.w[13 + 2 * part], sizeof(float) * C);
+                }
+                std::memcpy(gb.data(), s.w[19], sizeof(float) * C);
+            } else {
+                std::memcpy(wg.data(), s.w[12], sizeof(float) * C * C);                               // lin_l / lin_rel / lin .weight
+                if (s.w[13]) std::memcpy(gb.data(), s.w[13], sizeof(float) * C);                      // lin_l.bias / lin_rel.bias / bias: added behind the aggregation
+                if ((st.gnn == 1 || st.gnn == 2) && s.w[14]) std::memcpy(&wg[(size_t)C * C], s.w[14], sizeof(float) * C * C);   // lin_r / lin_root .weight
+                if (st.gnn == 4)
+                    for (int side = 0; side < 2; ++side)                                               // rows C + side H + h: att[h]^T W_h (float64 sums)
+                        for (int h = 0; h < H; ++h)
+                            for (int k = 0; k < C; ++k) {
+                                double acc = 0.0;
+                                for (int d = 0; d < D; ++d) acc += (double)s.w[14 + side][(size_t)h * D + d] * (double)s.w[12][((size_t)h * D + d) * C + k];
+                                wg[((size_t)C + (size_t)side * H + h) * C + k] = (float)acc;
+                            }
             }
-            o.push_back(putv(wg)); o.push_back(putv(bg)); o.push_back(put(s.w[19], C));
+            o.push_back(putv(wg)); o.push_back(putv(bg)); o.push_back(putv(gb));
             // upsampling ConvTranspose2d(co, co, (1, T+1), pad Td/2): row o*T + t, column j*co + i  <-  w[i][o][t - j + pad]
             std::vector<float> wu((size_t)co * Ts * C, 0.0f), bu((size_t)co * Ts);
             for (int oc = 0; oc < co; ++oc)
@@ -1099,7 +1207,7 @@ int load_engine(mpv_ctx* ctx, const std::string& who, int mode, const mpv_stg_de
             if (st.kind != 0) continue;
             const size_t C = (size_t)Td * st.c_out, CT = (size_t)st.c_out * st.T;
             add(st.r.wdown, offs[i][10], C, CT);
-            add(st.r.wg, offs[i][12], 4 * C, C);
+            add(st.r.wg, offs[i][12], (size_t)st.ng, C);
             add(st.r.wup, offs[i][15], CT, C);
         }
         if (!host16.empty()) {
@@ -1129,9 +1237,14 @@ int set_graph(mpv_ctx* ctx, StgEngine& e, const char* who, int32_t n_nodes, int6
     MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (e.graph) (void)hipFree(e.graph);
     e.graph = nullptr;
-    if (hipMalloc(&e.graph, sizeof(int) * (size_t)(n_nodes + 1 + std::max<int64_t>(n_edges, 1))) != hipSuccess) return mpv_fail(ctx, MPV_ENOMEM, who);
+    std::vector<int> deg(n_nodes, 0);                                  // in-degree without self loops (GCNConv's normalisation: + 1 for the loop it adds)
+    for (int64_t k = 0; k < n_edges; ++k)
+        if (edge_src[k] != edge_dst[k]) ++deg[edge_dst[k]];
+    const size_t n_col = (size_t)std::max<int64_t>(n_edges, 1);
+    if (hipMalloc(&e.graph, sizeof(int) * ((size_t)n_nodes + 1 + n_col + (size_t)n_nodes)) != hipSuccess) return mpv_fail(ctx, MPV_ENOMEM, who);
     MPV_HIP_TRY(ctx, hipMemcpy(e.graph, row_ptr.data(), sizeof(int) * (n_nodes + 1), hipMemcpyHostToDevice));
     if (n_edges) MPV_HIP_TRY(ctx, hipMemcpy(e.graph + n_nodes + 1, col.data(), sizeof(int) * n_edges, hipMemcpyHostToDevice));
+    MPV_HIP_TRY(ctx, hipMemcpy(e.graph + n_nodes + 1 + n_col, deg.data(), sizeof(int) * n_nodes, hipMemcpyHostToDevice));
     e.V = n_nodes;
     e.E = (int)n_edges;
     return MPV_OK;

@@ -1,6 +1,6 @@
 """Weight holders of DiffSTG's UGnet (mirrors reference DiffSTG/ugnet.py:55-250 in module / parameter NAMES and shapes, so a
-reference checkpoint loads strictly; the gated graph convolution holds the parameters of torch_geometric's ResGatedGraphConv:
-lin_key / lin_query / lin_value (with bias), lin_skip (no bias), bias).  Nothing here computes: the network runs in HIP kernels
+reference checkpoint loads strictly; the graph convolution of a block is one of the holders of models/layer/gnn_conv.py, which carry
+torch_geometric's parameter names).  Nothing here computes: the network runs in HIP kernels
 (csrc/stg.hip) behind mpv_stg_*.  `layout()` describes the block sequence to the native loader."""
 from __future__ import annotations
 
@@ -11,24 +11,13 @@ import torch
 import torch.nn as nn
 
 
-class ResGatedGraphConv(nn.Module):
-    def __init__(self, in_channels, out_channels, root_weight=True, bias=True, **kwargs):
-        super().__init__()
-        if kwargs:
-            raise ValueError("unsupported ResGatedGraphConv options: {}".format(sorted(kwargs)))
-        self.lin_key = nn.Linear(in_channels, out_channels)
-        self.lin_query = nn.Linear(in_channels, out_channels)
-        self.lin_value = nn.Linear(in_channels, out_channels)
-        self.lin_skip = nn.Linear(in_channels, out_channels, bias=False) if root_weight else None
-        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+from ...layer.gnn_conv import ResGatedGraphConv, gnn_conv      # noqa: F401  (ResGatedGraphConv: the name older callers import from here)
 
 
 class SpatialBlock(nn.Module):
     def __init__(self, c_in, c_out, gnn_name, gnn_param):
         super().__init__()
-        if gnn_name != "ResGatedGraphConv":
-            raise NotImplementedError("the native DiffSTG path implements gnn_name='ResGatedGraphConv' (every shipped config); got {!r}".format(gnn_name))
-        self.gnn = ResGatedGraphConv(c_in, c_out, **(gnn_param or {}))
+        self.gnn = gnn_conv(gnn_name, c_in, c_out, gnn_param)      # reference ugnet.py:37-39
 
 
 class TcnBlock(nn.Module):
