@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MPV_ABI_VERSION 3
+#define MPV_ABI_VERSION 4
 
 #define MPV_OK 0
 #define MPV_EINVAL (-1)   /* bad argument / unsupported shape            */
@@ -450,6 +450,10 @@ typedef struct mpv_nst_desc {
                                          mpv_nst_set_graph, and ConvTranspose2d back to seq_len steps before the decoder cross-attends to it
                                          (NsDiff/mu_backbone.py:186-340, called at NsDiff_model.py:744).  0: the plain Model.               */
     int32_t spatial_layers;
+    int32_t spatial_gnn;              /* ABI v4.  The graph convolution of the spatial layers (f_gnn_name): 0 ResGatedGraphConv, or MPV_STG_RES_SAGE_MEAN /
+                                         _SUM / _GCN / _GAT with the same 8 tensor slots per layer as mpv_stg_step.w[12..19] (NULL where the kind has none). */
+    int32_t spatial_heads;            /* GATConv heads (f_gnn_param["heads"]); otherwise ignored                                         */
+    float spatial_slope;              /* GATConv negative_slope                                                                            */
 } mpv_nst_desc;
 /* With fT_h > 0 the tensor list continues: downsampling.{weight [D][D][1][seq_len+1], bias [D]}; per spatial layer spatial_encoder.N.gnn.
  * {lin_key,lin_query,lin_value}.{weight [C][C], bias [C]}, lin_skip.weight [C][C], bias [C] (C = fT_h D; torch_geometric's ResGatedGraphConv

@@ -153,13 +153,13 @@ def spatial_stage(sd: Tensors, cfg, enc: torch.Tensor, edge_index: torch.Tensor,
     padding (0, fT_h // 2)) along time, reshape to [rows, fT_h * D], `spatial_layers` x relu(gnn(x, edge_index)), ConvTranspose2d back.
     The graph convolution is torch_geometric's ResGatedGraphConv (models/layer/gnn_conv.py:18-19; package absent): the restatement of
     oracle/diffstg_oracle.py, unpinned.  enc [rows, S, D], rows = whole graphs (edge_index addresses rows)."""
-    from oracle.diffstg_oracle import res_gated_graph_conv
+    from oracle.diffstg_oracle import graph_conv          # the layer f_gnn_name selected, told apart by its parameter names (f_gnn_param: aggr, heads, ...)
     p = cfg.fT_h // 2
     h = enc.unsqueeze(2).transpose(1, 3)                                                       # [rows, D, 1, S]
     h = F.conv2d(h, sd["downsampling.weight"], sd["downsampling.bias"], padding=(0, p)).transpose(1, 3).squeeze(2)      # [rows, fT_h, D]
     s = h.reshape(h.shape[0], -1)
     for i in range(cfg.spatial_layers):
-        s = torch.relu(res_gated_graph_conv(sd, "spatial_encoder.{}.gnn.".format(i), s, edge_index))
+        s = torch.relu(graph_conv(sd, "spatial_encoder.{}.gnn.".format(i), s, edge_index, getattr(cfg, "f_gnn_param", None)))
     feat = s.reshape(h.shape[0], cfg.fT_h, -1)
     u = feat.unsqueeze(2).transpose(1, 3)                                                      # [rows, D, 1, fT_h]
     out = F.conv_transpose2d(u, sd["upsampling.weight"], sd["upsampling.bias"], padding=(0, p)).transpose(1, 3).squeeze(2)   # [rows, S, D]

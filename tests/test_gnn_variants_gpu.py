@@ -105,3 +105,29 @@ def test_nsdiff_spatial_ugnet_with_the_variant_matches_the_oracle(name, param):
         e1, e2 = rel_err(eps, we), rel_err(sig, ws)
         print("NsDiff_spatial UGnet %s t=%d: eps rel err %.3e, sigma rel err %.3e" % (name, t, e1, e2))
         assert e1 < RTOL and e2 < RTOL
+
+
+@pytest.mark.parametrize("name,param", VARIANTS)
+def test_model_spatial_with_the_variant_matches_the_oracle(name, param):
+    """f(x) of NsDiff_spatial with f_gnn_name / f_gnn_param (reference NsDiff/mu_backbone.py:224): the graph stage of csrc/nst.hip on the same
+    product + gather as the UGnet's blocks (csrc/graph_aggr.h)."""
+    from oracle import ns_transformer_oracle as NO
+    from test_gnn_variants import holder_state
+    from test_nst_spatial_gpu import CASES, edges, f_only
+    kw, V, pairs = CASES["small"]
+    cfg = NO.config(**kw)
+    cfg.f_gnn_name, cfg.f_gnn_param = name, param
+    sd = {k: v for k, v in NO.random_spatial_state(cfg, seed=21).items() if ".gnn." not in k}
+    C = cfg.fT_h * cfg.d_model
+    for i in range(cfg.spatial_layers):
+        _, layer = holder_state(name, param, C, 40 + i)
+        sd.update({"spatial_encoder.%d.gnn.%s" % (i, k[2:]): v * (0.3 if v.dim() > 1 else 1.0) for k, v in layer.items()})
+    edge = with_self_loop(edges(pairs))
+    m = f_only(cfg, sd, f_gnn_name=name, f_gnn_param=param)
+    x = torch.randn(V, cfg.seq_len, cfg.dataset_nf, generator=torch.Generator().manual_seed(2)).cumsum(1) * 0.3
+    pred, full = m.cond_pred_model(x.to(dev()), None, edge)
+    want_pred, want_full = NO.forward_spatial(sd, cfg, x, edge)
+    feat = NO.spatial_stage(sd, cfg, NO.intermediates(sd, cfg, x)["enc_out"], edge, return_features=True)[1]
+    e_feat, e_full = rel_err(m.native_context().nst_debug("spatial", V), feat), rel_err(full, want_full)
+    print("Model_spatial %s: graph features %.3e, output %.3e" % (name, e_feat, e_full))
+    assert e_feat < RTOL and e_full < RTOL and rel_err(pred, want_pred) < RTOL

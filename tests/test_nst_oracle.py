@@ -156,5 +156,8 @@ def test_spatial_holder_names_tensor_list_and_model_wiring():
     assert isinstance(f_only.cond_pred_model, H.Model_spatial) and getattr(f_only, "model", None) is None
     with pytest.raises(NotImplementedError, match="fT_h"):
         diffusion_models("NsDiff_spatial", dict(base), train_model_select="pretrain_f")
-    with pytest.raises(NotImplementedError, match="ResGatedGraphConv"):
-        H.Model_spatial(types.SimpleNamespace(**vars(cfg), f_gnn_name="GCNConv"))
+    with pytest.raises(NotImplementedError, match="no native kernel"):
+        H.Model_spatial(types.SimpleNamespace(**vars(cfg), f_gnn_name="PNAConv"))
+    gcn = H.Model_spatial(types.SimpleNamespace(**vars(cfg), f_gnn_name="GCNConv"))         # round 4: SAGE / Graph / GCN / GAT layers are native too
+    f2, t2 = gcn.native_weight_list()
+    assert f2["spatial_gnn"] == 12 and len(t2) == len(tensors) and sum(t is None for t in t2) == 6 * 2 and "spatial_encoder.0.gnn.lin.weight" in gcn.state_dict()

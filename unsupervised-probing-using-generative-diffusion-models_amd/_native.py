@@ -15,7 +15,7 @@ import torch
 PKG = Path(__file__).resolve().parent
 import os
 LIB_PATH = Path(os.environ.get("MPV_LIB", PKG / "libmpv_hip.so"))   # MPV_LIB: kernel-variant experiments only
-ABI_VERSION = 3
+ABI_VERSION = 4
 HIDDEN = 128
 MAX_NF = 4
 COEF_COLS = 20
@@ -97,7 +97,8 @@ class NssSampleShape(C.Structure):
 class NstDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("enc_in", "c_out", "seq_len", "label_len", "pred_len", "d_model", "n_heads", "d_ff", "e_layers", "d_layers",
                                           "activation", "p_layers")] + [("p_hidden", C.c_int32 * 4), ("latent", C.c_int32), ("pe_rows", C.c_int32),
-                                                                   ("fT_h", C.c_int32), ("spatial_layers", C.c_int32)]
+                                                                   ("fT_h", C.c_int32), ("spatial_layers", C.c_int32),
+                                                                   ("spatial_gnn", C.c_int32), ("spatial_heads", C.c_int32), ("spatial_slope", C.c_float)]
 
 
 class SigmaDesc(C.Structure):
@@ -481,9 +482,9 @@ class Context:
                 for i, h in enumerate(v):
                     d.p_hidden[i] = int(h)
             else:
-                setattr(d, k, int(v))
-        keep = [_host_f32(t) for t in tensors]
-        arr = (_F * len(keep))(*[_fptr(t) for t in keep])
+                setattr(d, k, float(v) if k == "spatial_slope" else int(v))
+        keep = [None if t is None else _host_f32(t) for t in tensors]       # (None: a slot the graph-convolution kind does not use)
+        arr = (_F * len(keep))(*[None if t is None else _fptr(t) for t in keep])
         self._check(self.lib.mpv_nst_load(self._h, C.byref(d), arr, len(keep)), "mpv_nst_load")
         self.nst = d
         self._nst_graph = None

@@ -25,6 +25,7 @@
 #include "mpv_common.h"
 
 #include "nst_gemm.h"
+#include "graph_aggr.h"
 
 namespace {
 
@@ -493,7 +494,7 @@ struct EncLayer { AttnW att; FfnW ffn; NormW n1, n2; };
 struct DecLayer { AttnW self, cross; FfnW ffn; NormW n1, n2, n3; };
 // Model_spatial (NsDiff/mu_backbone.py:186-340): one gated graph convolution over the fT_h x d_model features of a (window, node) row --
 // the four Linear maps as ONE [4C][C] product (key | query | value | skip; the skip map has no bias), then the gather over incoming edges
-struct SpatialLayer { Mat w4; const float* b4; const float* bias; };
+struct SpatialLayer { Mat w4; const float* b4; const float* bias; };       // (w4: the layer's [ng][C] product -- 4 C columns for the gated layer)
 
 struct NstEngine {
     mpv_nst_desc d{};
@@ -513,7 +514,7 @@ struct NstEngine {
     std::vector<SpatialLayer> sp;
     int gV = 0;                                               // the graph (CSR by target node, incoming edges in edge order), mpv_nst_set_graph
     long long gE = 0;
-    int *row_ptr = nullptr, *col_idx = nullptr;
+    int *row_ptr = nullptr, *col_idx = nullptr, *deg = nullptr;
     float *sp_a = nullptr, *sp_b = nullptr, *sp_kqvs = nullptr;
     _Float16* blob16 = nullptr;
     int gemm_mode = MPV_GEMM_F16X3;
@@ -533,6 +534,7 @@ void nst_engine_destroy(NstEngine* e) {
     if (e->ws) (void)hipFree(e->ws);
     if (e->row_ptr) (void)hipFree(e->row_ptr);
     if (e->col_idx) (void)hipFree(e->col_idx);
+    if (e->deg) (void)hipFree(e->deg);
     delete e;
 }
 
@@ -667,10 +669,12 @@ int forward_pass(mpv_ctx* ctx, NstEngine& e, const float* series, int V, long lo
         const int C = d.fT_h * D;
         NST_TRY(gemm(ctx, e, enc_out, (long long)S * D, e.wdown, 0, e.bdown, nullptr, 0, e.sp_a, C, B, C, 0));         // downsampling: [B][S D] -> [B][fT_h D]
         float *cur = e.sp_a, *nxt = e.sp_b;
+        const int gnn = d.spatial_gnn ? d.spatial_gnn - MPV_STG_RES_SAGE_MEAN + 1 : 0, H = std::max(d.spatial_heads, 1), ng = graph_conv_ng(gnn, C, H);
         for (const SpatialLayer& l : e.sp) {
-            NST_TRY(gemm(ctx, e, cur, C, l.w4, 0, l.b4, nullptr, 0, e.sp_kqvs, 4 * C, B, 4 * C, 0));
+            NST_TRY(gemm(ctx, e, cur, C, l.w4, 0, l.b4, nullptr, 0, e.sp_kqvs, ng, B, ng, 0));
             const long long n4 = B * (C / 4);
-            hipLaunchKernelGGL(nst_gate_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ctx->stream, e.sp_kqvs, l.bias, e.row_ptr, e.col_idx, e.gV, C / 4, n4, nxt);
+            if (gnn == 0) hipLaunchKernelGGL(nst_gate_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ctx->stream, e.sp_kqvs, l.bias, e.row_ptr, e.col_idx, e.gV, C / 4, n4, nxt);
+            else graph_aggr_launch(gnn, ctx->stream, e.sp_kqvs, ng, l.bias, e.row_ptr, e.col_idx, e.deg, e.gV, C, H, d.spatial_slope, B, nxt);
             MPV_HIP_TRY(ctx, hipGetLastError());
             std::swap(cur, nxt);
         }
@@ -730,8 +734,19 @@ int mpv_nst_load(mpv_ctx* ctx, const mpv_nst_desc* d, const float* const* t, int
     const int n_proj = 2 + 2 * d->p_layers;
     const int expect = 4 + 16 * d->e_layers + 2 + 26 * d->d_layers + 4 + 2 * n_proj + (d->latent ? 8 : 0) + (d->fT_h > 0 ? 4 + 8 * d->spatial_layers : 0);
     if (n_tensors != expect) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: expected " + std::to_string(expect) + " tensors, got " + std::to_string(n_tensors));
-    for (int i = 0; i < n_tensors; ++i)
-        if (!t[i]) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: tensor " + std::to_string(i) + " is NULL");
+    const int sp_first = expect - (d->fT_h > 0 ? 2 + 8 * d->spatial_layers : 0), sp_end = expect - 2;            // the graph layers' slots
+    if (d->spatial_gnn != 0 && (d->fT_h <= 0 || d->spatial_gnn < MPV_STG_RES_SAGE_MEAN || d->spatial_gnn > MPV_STG_RES_GAT))
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: spatial_gnn must be 0 or one of MPV_STG_RES_SAGE_MEAN .. MPV_STG_RES_GAT (with fT_h > 0)");
+    if (d->spatial_gnn == MPV_STG_RES_GAT && (d->spatial_heads < 1 || (d->fT_h * D) % d->spatial_heads != 0))
+        return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: GATConv heads must divide fT_h d_model");
+    for (int i = 0; i < n_tensors; ++i) {
+        bool optional = false;
+        if (d->spatial_gnn != 0 && i >= sp_first && i < sp_end) {                  // kinds other than the gated layer use a prefix of the 8 slots
+            const int slot = (i - sp_first) % 8;
+            optional = slot >= 1 && !(d->spatial_gnn == MPV_STG_RES_GAT && (slot == 2 || slot == 3));
+        }
+        if (!t[i] && !optional) return mpv_fail(ctx, MPV_EINVAL, "mpv_nst_load: tensor " + std::to_string(i) + " is NULL");
+    }
     DeviceGuard dg(ctx->device);
     MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     nst_engine_destroy(ctx->nst);
@@ -860,16 +875,13 @@ int mpv_nst_load(mpv_ctx* ctx, const mpv_nst_desc* d, const float* const* t, int
             o_bdown = put(b.data(), b.size());
             k += 2;
         }
+        const int gnn = d->spatial_gnn ? d->spatial_gnn - MPV_STG_RES_SAGE_MEAN + 1 : 0, H = std::max(d->spatial_heads, 1), ng = graph_conv_ng(gnn, C, H);
         for (SpO& o : spo) {
-            std::vector<float> w((size_t)4 * C * C), b((size_t)4 * C, 0.0f);
-            for (int part = 0; part < 3; ++part) {
-                std::memcpy(&w[(size_t)part * C * C], t[k + 2 * part], sizeof(float) * C * C);
-                std::memcpy(&b[(size_t)part * C], t[k + 2 * part + 1], sizeof(float) * C);
-            }
-            std::memcpy(&w[(size_t)3 * C * C], t[k + 6], sizeof(float) * C * C);
-            o.w4 = put_mat(w.data(), (size_t)4 * C, C);
+            std::vector<float> w, b, gb;
+            graph_conv_pack(gnn, C, H, &t[k], w, b, gb);      // the 8 slots of the layer (include/mpv_hip.h): one [ng][C] product, its bias, the bias behind the gather
+            o.w4 = put_mat(w.data(), (size_t)ng, C);
             o.b4 = put(b.data(), b.size());
-            o.bias = put(t[k + 7], C);
+            o.bias = put(gb.data(), gb.size());
             k += 8;
         }
         {
@@ -944,13 +956,19 @@ int mpv_nst_set_graph(mpv_ctx* ctx, int32_t n_nodes, int64_t n_edges, const int6
     for (int64_t i = 0; i < n_edges; ++i) ci[(size_t)fill[(size_t)edge_dst[i]]++] = (int)edge_src[i];       // stable: edge order within a target
     DeviceGuard dg(ctx->device);
     MPV_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int> indeg((size_t)n_nodes, 0);                       // in-degree without self loops (GCNConv's normalisation)
+    for (int64_t i = 0; i < n_edges; ++i)
+        if (edge_src[i] != edge_dst[i]) ++indeg[(size_t)edge_dst[i]];
     if (e.row_ptr) (void)hipFree(e.row_ptr);
     if (e.col_idx) (void)hipFree(e.col_idx);
-    e.row_ptr = e.col_idx = nullptr;
+    if (e.deg) (void)hipFree(e.deg);
+    e.row_ptr = e.col_idx = e.deg = nullptr;
     e.gV = 0;
-    if (hipMalloc(&e.row_ptr, sizeof(int) * rp.size()) != hipSuccess || hipMalloc(&e.col_idx, sizeof(int) * std::max<size_t>(1, ci.size())) != hipSuccess)
+    if (hipMalloc(&e.row_ptr, sizeof(int) * rp.size()) != hipSuccess || hipMalloc(&e.col_idx, sizeof(int) * std::max<size_t>(1, ci.size())) != hipSuccess ||
+        hipMalloc(&e.deg, sizeof(int) * indeg.size()) != hipSuccess)
         return mpv_fail(ctx, MPV_ENOMEM, "mpv_nst_set_graph: graph buffers");
     MPV_HIP_TRY(ctx, hipMemcpy(e.row_ptr, rp.data(), sizeof(int) * rp.size(), hipMemcpyHostToDevice));
+    MPV_HIP_TRY(ctx, hipMemcpy(e.deg, indeg.data(), sizeof(int) * indeg.size(), hipMemcpyHostToDevice));
     if (!ci.empty()) MPV_HIP_TRY(ctx, hipMemcpy(e.col_idx, ci.data(), sizeof(int) * ci.size(), hipMemcpyHostToDevice));
     e.gV = n_nodes;
     e.gE = n_edges;

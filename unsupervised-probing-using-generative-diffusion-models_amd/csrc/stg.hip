@@ -22,6 +22,7 @@
 #include "nst_gemm.h"
 #include "stg_tcn_mfma.h"
 #include "stg_down_mfma.h"
+#include "graph_aggr.h"
 
 namespace {
 
@@ -259,74 +260,6 @@ __global__ void stg_gate_kernel(const float* __restrict__ kqvs, const float* __r
     }
     a = (a + kqvs[node * 4 * C + 3 * C + ch]) + bias[ch];
     out[i] = fmaxf(a, 0.0f);
-}
-
-// ---- the other graph convolutions of models/layer/gnn_conv.py:4-28 (round 4; restated from torch_geometric's published definitions, unpinned) ------
-// The Linear maps commute with the aggregation, so each layer is ONE product ar [N][NG] = z W^T (gemm(), like the gated layer's four maps) and one
-// gather over the incoming edges in edge order.  MODE 1 SAGEConv(aggr = "mean"): relu(lin_l(mean_j x_j) + lin_r(x_i)) -- ar = (W_l x | W_r x), bias =
-// lin_l.bias; a node without incoming edges aggregates 0.  MODE 2 GraphConv / SAGEConv(aggr = "add"): the sum instead of the mean.  MODE 3 GCNConv:
-// relu(sum_j (d_i d_j)^-1/2 W x_j + b) over the incoming edges and ONE self loop per node (self loops of the input are replaced by it), d = in-degree
-// without self loops + 1 (gcn_norm with add_remaining_self_loops, unit edge weights).
-template <int MODE>
-__global__ void stg_aggr_kernel(const float* __restrict__ ar, int NG, const float* __restrict__ bias, const int* __restrict__ row_ptr,
-                                const int* __restrict__ col_idx, const int* __restrict__ deg /* in-degree without self loops */, int V, int C,
-                                long long n, float* out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // node*C + ch
-    if (i >= n) return;
-    const int ch = (int)(i % C);
-    const long long node = i / C;
-    const int v = (int)(node % V);
-    const long long base = node - v;
-    const int e0 = row_ptr[v], e1 = row_ptr[v + 1];
-    float a = 0.0f;
-    if (MODE == 3) {
-        const float di = 1.0f / sqrtf((float)(deg[v] + 1));
-        for (int e = e0; e < e1; ++e) {
-            const int j = col_idx[e];
-            if (j == v) continue;                                                // (a self loop of the input is replaced by the one added here)
-            const float dj = 1.0f / sqrtf((float)(deg[j] + 1));
-            a += (dj * di) * ar[(base + j) * NG + ch];
-        }
-        a += (di * di) * ar[node * NG + ch];                                     // the self loop (appended behind the edges)
-    } else {
-        for (int e = e0; e < e1; ++e) a += ar[(base + col_idx[e]) * NG + ch];
-        if (MODE == 1) a = a / (float)max(e1 - e0, 1);
-        a += ar[node * NG + C + ch];                                             // root weight (zeros when the layer has none)
-    }
-    out[i] = fmaxf(a + bias[ch], 0.0f);
-}
-
-// GATConv(heads = H, concat = True, add_self_loops = True), eval mode (no attention dropout): ar = (x' = W x [C = H D] | s_src [H] | s_dst [H]) with
-// s_src[j][h] = <x'_j[h], att_src[h]> (folded into the product as H extra weight rows att_src[h]^T W_h, likewise s_dst);
-// alpha_ij = softmax_j leaky_relu(s_src[j] + s_dst[i]) over the incoming edges (self loops in the input dropped) and one self loop;
-// out_i = relu(sum_j alpha_ij x'_j + bias).  Softmax as torch_geometric.utils.softmax: exp(e - max) / (sum + 1e-16).
-__global__ void stg_gat_kernel(const float* __restrict__ ar, int NG, const float* __restrict__ bias, const int* __restrict__ row_ptr,
-                               const int* __restrict__ col_idx, int V, int C, int H, float slope, long long n, float* out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // node*C + ch
-    if (i >= n) return;
-    const int ch = (int)(i % C), h = ch / (C / H);
-    const long long node = i / C;
-    const int v = (int)(node % V);
-    const long long base = node - v;
-    const int e0 = row_ptr[v], e1 = row_ptr[v + 1];
-    const float sd = ar[node * NG + C + H + h];
-    auto score = [&](long long j) { const float t = ar[j * NG + C + h] + sd; return t > 0.0f ? t : slope * t; };
-    const float self = score(node);
-    float m = self;
-    for (int e = e0; e < e1; ++e)
-        if (col_idx[e] != v) m = fmaxf(m, score(base + col_idx[e]));
-    float den = 0.0f, a = 0.0f;
-    for (int e = e0; e < e1; ++e) {
-        if (col_idx[e] == v) continue;
-        const long long j = base + col_idx[e];
-        const float w = expf(score(j) - m);
-        den += w;
-        a += w * ar[j * NG + ch];
-    }
-    const float ws = expf(self - m);
-    den += ws;
-    a += ws * ar[node * NG + ch];
-    out[i] = fmaxf(a / (den + 1e-16f) + bias[ch], 0.0f);
 }
 
 // ---- block output: up [N][co*T] + shortcut(x) ---------------------------------------------------------------------------------------
@@ -935,13 +868,8 @@ int unet(mpv_ctx* ctx, StgEngine& e, long long N, int t, const float** out_cur) 
             const int* rp = e.graph;
             const int* ci_ = e.graph + e.V + 1;
             const int* dg_ = ci_ + std::max(e.E, 1);
-            switch (s.gnn) {
-                case 0: hipLaunchKernelGGL(stg_gate_kernel, g1d(N * C), dim3(256), 0, st, e.kqvs, s.r.gbias, rp, ci_, e.V, C, N * C, e.sp); break;
-                case 1: hipLaunchKernelGGL(stg_aggr_kernel<1>, g1d(N * C), dim3(256), 0, st, e.kqvs, s.ng, s.r.gbias, rp, ci_, dg_, e.V, C, N * C, e.sp); break;
-                case 2: hipLaunchKernelGGL(stg_aggr_kernel<2>, g1d(N * C), dim3(256), 0, st, e.kqvs, s.ng, s.r.gbias, rp, ci_, dg_, e.V, C, N * C, e.sp); break;
-                case 3: hipLaunchKernelGGL(stg_aggr_kernel<3>, g1d(N * C), dim3(256), 0, st, e.kqvs, s.ng, s.r.gbias, rp, ci_, dg_, e.V, C, N * C, e.sp); break;
-                default: hipLaunchKernelGGL(stg_gat_kernel, g1d(N * C), dim3(256), 0, st, e.kqvs, s.ng, s.r.gbias, rp, ci_, e.V, C, s.heads, s.slope, N * C, e.sp); break;
-            }
+            if (s.gnn == 0) hipLaunchKernelGGL(stg_gate_kernel, g1d(N * C), dim3(256), 0, st, e.kqvs, s.r.gbias, rp, ci_, e.V, C, N * C, e.sp);
+            else graph_aggr_launch(s.gnn, st, e.kqvs, s.ng, s.r.gbias, rp, ci_, dg_, e.V, C, s.heads, s.slope, N, e.sp);
             MPV_HIP_TRY(ctx, hipGetLastError());
             // up-sampling product with the block's shortcut added in its epilogue: the block input itself (identity) or the 1x1
             // convolution the TCN kernel left in e.up
@@ -1089,28 +1017,9 @@ int load_engine(mpv_ctx* ctx, const std::string& who, int mode, const mpv_stg_de
                 }
             o.push_back(putv(wd)); o.push_back(putv(bd));
             // the graph convolution's Linear maps as ONE weight matrix [ng][C] (+ a bias per product column, + the bias added behind the aggregation)
-            const int H = st.heads, D = C / H;
-            st.ng = st.gnn == 0 ? 4 * C : (st.gnn == 3 ? C : (st.gnn == 4 ? (C + 2 * H + 3) & ~3 : 2 * C));
-            std::vector<float> wg((size_t)st.ng * C, 0.0f), bg((size_t)st.ng, 0.0f), gb((size_t)C, 0.0f);
-            if (st.gnn == 0) {
-                for (int part = 0; part < 4; ++part) {
-                    std::memcpy(&wg[(size_t)part * C * C], s.w[12 + 2 * part], sizeof(float) * C * C);   // key.w, query.w, value.w at 12, 14, 16; skip.w at 18
-                    if (part < 3) std::memcpy(&bg[(size_t)part * C], s.w[13 + 2 * part], sizeof(float) * C);
-                }
-                std::memcpy(gb.data(), s.w[19], sizeof(float) * C);
-            } else {
-                std::memcpy(wg.data(), s.w[12], sizeof(float) * C * C);                               // lin_l / lin_rel / lin .weight
-                if (s.w[13]) std::memcpy(gb.data(), s.w[13], sizeof(float) * C);                      // lin_l.bias / lin_rel.bias / bias: added behind the aggregation
-                if ((st.gnn == 1 || st.gnn == 2) && s.w[14]) std::memcpy(&wg[(size_t)C * C], s.w[14], sizeof(float) * C * C);   // lin_r / lin_root .weight
-                if (st.gnn == 4)
-                    for (int side = 0; side < 2; ++side)                                               // rows C + side H + h: att[h]^T W_h (float64 sums)
-                        for (int h = 0; h < H; ++h)
-                            for (int k = 0; k < C; ++k) {
-                                double acc = 0.0;
-                                for (int d = 0; d < D; ++d) acc += (double)s.w[14 + side][(size_t)h * D + d] * (double)s.w[12][((size_t)h * D + d) * C + k];
-                                wg[((size_t)C + (size_t)side * H + h) * C + k] = (float)acc;
-                            }
-            }
+            st.ng = graph_conv_ng(st.gnn, C, st.heads);
+            std::vector<float> wg, bg, gb;
+            graph_conv_pack(st.gnn, C, st.heads, &s.w[12], wg, bg, gb);
             o.push_back(putv(wg)); o.push_back(putv(bg)); o.push_back(putv(gb));
             // upsampling ConvTranspose2d(co, co, (1, T+1), pad Td/2): row o*T + t, column j*co + i  <-  w[i][o][t - j + pad]
             std::vector<float> wu((size_t)co * Ts * C, 0.0f), bu((size_t)co * Ts);

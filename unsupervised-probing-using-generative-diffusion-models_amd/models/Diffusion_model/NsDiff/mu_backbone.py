@@ -178,22 +178,19 @@ class Model(nn.Module):
 
 
 class SpatialBlock(nn.Module):
-    """Holder of one graph convolution of Model_spatial (reference :43-51): `gnn` carries torch_geometric's ResGatedGraphConv parameter names
-    (lin_key / lin_query / lin_value with bias, bias-free lin_skip, bias)."""
+    """Holder of one graph convolution of Model_spatial (reference :43-51): `gnn` is the holder `gnn_conv` builds for f_gnn_name / f_gnn_param
+    (models/layer/gnn_conv.py: torch_geometric's parameter names)."""
 
     def __init__(self, c_in, c_out, gnn_name="ResGatedGraphConv", gnn_param=None):
         super().__init__()
-        if gnn_name != "ResGatedGraphConv":
-            raise NotImplementedError("Model_spatial's graph convolution is built for gnn_name='ResGatedGraphConv' (got {!r})".format(gnn_name))
+        from ...layer.gnn_conv import gnn_conv
         if c_in != c_out:
             raise ValueError("SpatialBlock keeps the feature width")
-        self.gnn = _Named(lin_key=nn.Linear(c_in, c_out), lin_query=nn.Linear(c_in, c_out), lin_value=nn.Linear(c_in, c_out),
-                          lin_skip=nn.Linear(c_in, c_out, bias=False))
-        self.gnn.bias = nn.Parameter(torch.zeros(c_out))
+        self.gnn = gnn_conv(gnn_name, c_in, c_out, gnn_param)
 
     def tensors(self):
-        g = self.gnn
-        return [g.lin_key.weight, g.lin_key.bias, g.lin_query.weight, g.lin_query.bias, g.lin_value.weight, g.lin_value.bias, g.lin_skip.weight, g.bias]
+        """The layer's 8 slots of the C ABI (None where its kind has no tensor)."""
+        return list(self.gnn.native_tensors())
 
 
 class Model_spatial(Model):
@@ -221,7 +218,9 @@ class Model_spatial(Model):
         for blk in self.spatial_encoder:
             t += blk.tensors()
         t += [self.upsampling.weight, self.upsampling.bias]
-        return dict(fields, fT_h=self.fT_h, spatial_layers=self.spatial_layers), t
+        g = self.spatial_encoder[0].gnn if self.spatial_layers else None
+        return dict(fields, fT_h=self.fT_h, spatial_layers=self.spatial_layers, spatial_gnn=g.native_kind() if g is not None else 0,
+                    spatial_heads=getattr(g, "heads", 1), spatial_slope=getattr(g, "negative_slope", 0.2)), t
 
     def _run_graph(self, x_enc, edge_index):
         if x_enc.dim() != 3 or x_enc.shape[1] != self.seq_len or x_enc.shape[2] != self.enc_in:
