@@ -131,3 +131,45 @@ def test_model_spatial_with_the_variant_matches_the_oracle(name, param):
     e_feat, e_full = rel_err(m.native_context().nst_debug("spatial", V), feat), rel_err(full, want_full)
     print("Model_spatial %s: graph features %.3e, output %.3e" % (name, e_feat, e_full))
     assert e_feat < RTOL and e_full < RTOL and rel_err(pred, want_pred) < RTOL
+
+
+@pytest.mark.parametrize("name,param", [VARIANTS[0], VARIANTS[4]])
+def test_uncertainty_ews_on_a_model_directory_with_the_variant(name, param, tmp_path, monkeypatch):
+    """The harness end to end on a DiffSTG model directory whose YAML names SAGEConv / GATConv (gnn_param through the YAML round trip), against
+    the oracle driven window by window on the same draws."""
+    import networkx as nx
+    from conftest import GOLDEN
+    from mpv_amd.evaluation_and_analysis import diffusion_model_uncertainy as H
+    from mpv_amd.models.models import diffusion_models
+    from test_diffstg_oracle import case
+    from test_gpu_parity import _reseed_after
+    from test_harness_families_gpu import _write_dir
+    z = np.load(GOLDEN / "diffstg_cases.npz")
+    net, V = case(z, "tiny")
+    net = dict(net, gnn_name=name, gnn_param=param, noise_source="torch_cpu")
+    torch.manual_seed(5)
+    m = seeded(diffusion_models("DiffSTG", dict(net, device="cpu")), 17)
+    with torch.no_grad():
+        m.scaler_mean.fill_(0.9)
+        m.scaler_std.fill_(0.7)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    _write_dir(tmp_path / "m", "DiffSTG", net, sd, {"windows": net["T_h"], "pred_len": net["T_p"], "sampling_t": 0.1, "interval_step": 9})
+    g = nx.Graph()
+    g.add_nodes_from(range(V))
+    g.add_edges_from([(int(a), int(b)) for a, b in z["edge_tiny"].T if a < b])
+    nx.write_graphml(g, tmp_path / "g.graphml")
+    series = torch.cumsum(torch.randn(40, V, generator=torch.Generator().manual_seed(3)) * 0.2, dim=0) + 1.0
+    torch.save({"ys_dynamic": series, "ts_dynamic": torch.arange(40) * 0.1, "tp_values": torch.zeros(1)}, tmp_path / "biomass_x.pt")
+    _reseed_after(monkeypatch, H, "load_model_from_dir", 12)
+    res = H.uncertainty_ews(model_save_file=tmp_path / "m", data_file=tmp_path / "biomass_x.pt", dynamic_type="biomass",
+                            graph_file=tmp_path / "g.graphml", device=dev(), save_nsdiff_g=False, infer_params={"noise_source": "torch_cpu"})
+    graph = H.load_diffstg_graph(tmp_path / "g.graphml")
+    mean, std = sd["scaler_mean"], sd["scaler_std"]
+    torch.manual_seed(12)
+    want = []
+    for w in range((40 - net["T_h"]) // 9 + 1):
+        x = (series[9 * w: 9 * w + net["T_h"]].t().unsqueeze(-1) - mean) / std
+        outs = O.evaluation_step(sd, net, x, graph.edge_index, lambda shape: torch.randn(shape))[:, -net["T_p"]:]
+        want.append(float((outs * std + mean).var(dim=-1, unbiased=False).mean()))
+    print("DiffSTG (%s) harness curve" % name, res["ews"], want)
+    np.testing.assert_allclose(np.array(res["ews"], dtype=np.float64), np.array(want), rtol=1e-4)
