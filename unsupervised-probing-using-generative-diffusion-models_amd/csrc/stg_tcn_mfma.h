@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void stg_tcn_mfma_kernel(const TcnMArgs p) {
     }
     const int offsb = 2 * P1 + 8 * (g < G1 ? g : G1 - 1);             // block shortcut: the current-time tap only (K = cip1 <= 32: one chunk)
     const int cq = p.cip1 >> 2;                                       // channel quads of the x image
+    const unsigned xr_magic = 0xFFFFFFFFu / (unsigned)XR + 1u;        // i / XR = umulhi(i, xr_magic) for the i < 2^16 this kernel sees
     float lw[4], lb[4], b2v[4], sbv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -130,6 +131,50 @@ __global__ __launch_bounds__(256) void stg_tcn_mfma_kernel(const TcnMArgs p) {
         const int t0 = (int)(item - n * p.nseg) * p.tseg, t1 = min(T, t0 + p.tseg), tl = t1 - t0;
         __syncthreads();                                              // (the previous item is done with the images; first item: tvs is written)
         // ---- stage x[t0 - 4 .. ) transposed: thread -> (channel quad, time step); zeros before the row starts, after t1 and in padded channels ----
+        // Round 4 (late): the 16 loads of a thread's batch are UNCONDITIONAL on clamped addresses and the zeroing is a select where the value is
+        // split (a guarded load is an exec-mask branch of its own with a full wait behind it: 44 branches and ~500 vector instructions per batch
+        // before), item -> (quad, step) by a multiply-high instead of a division, a quad's four channels one base + stride T (the first source's
+        // channel count is a multiple of 4 in every UGnet this engine builds; otherwise, and in the probe builds, the previous loop below).
+        if (!TCN_PROBE && (p.c1 & 3) == 0) {
+            const int nitems = cq * XR;
+            const float* rb1 = p.src1 + (size_t)n * p.c1 * T;          // (uniform)
+            const float* rb2 = p.c2 ? p.src2 + (size_t)n * p.c2 * T : rb1;
+            const int wf = __builtin_amdgcn_readfirstlane(tid & ~63);   // this wave's first thread: a batch slot none of its lanes fills is skipped (uniform)
+            for (int i0 = tid; i0 < nitems; i0 += 256 * TCN_BATCH) {
+                float v[TCN_BATCH][4];
+                int keep[TCN_BATCH], wo[TCN_BATCH];
+#pragma unroll
+                for (int u = 0; u < TCN_BATCH; ++u) {
+                    keep[u] = 0; wo[u] = -1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[u][j] = 0.0f;
+                    if (wf + (i0 - tid) + 256 * u >= nitems) continue;
+                    const int i = min(i0 + 256 * u, nitems - 1);
+                    const int q = (int)__umulhi((unsigned)i, xr_magic), row = i - q * XR, t = t0 - 4 + row;
+                    const int c0 = min(4 * q, ci - 1);                   // (a padded quad reads the last real channel and keeps nothing)
+                    const bool from1 = c0 < p.c1;
+                    const float* base = from1 ? rb1 + (size_t)c0 * T : rb2 + (size_t)(c0 - p.c1) * T;
+                    const int lim = (from1 ? p.c1 : ci) - 1 - c0;        // channels of this source behind c0
+                    const int tc = min(max(t, 0), T - 1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[u][j] = base[(size_t)min(j, lim) * T + tc];
+                    keep[u] = (i0 + 256 * u < nitems && t >= 0 && t < t1) ? min(ci - 4 * q, 4) : 0;      // leading channels of the quad that are real
+                    wo[u] = i0 + 256 * u < nitems ? row * P1 + 4 * q : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < TCN_BATCH; ++u) {
+                    if (wf + (i0 - tid) + 256 * u >= nitems) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[u][j] = j < keep[u] ? v[u][j] : 0.0f;
+                    th4 hi, lo;
+                    tcn_split4(v[u], hi, lo);
+                    if (wo[u] >= 0) {
+                        *reinterpret_cast<th4*>(xh + wo[u]) = hi;
+                        *reinterpret_cast<th4*>(xl + wo[u]) = lo;
+                    }
+                }
+            }
+        } else
         for (int i0 = tid; i0 < cq * XR; i0 += 256 * TCN_BATCH) {    // TCN_BATCH thread items' loads are issued before the first LDS write
             float v[TCN_BATCH][4];
 #pragma unroll
