@@ -364,6 +364,176 @@ __global__ __launch_bounds__(256, 4) void nst_attn_kernel(const AttnArgs p) {
     }
 }
 
+// Round 4: the same kernel on the f16 matrix pipe (gemm mode f16x3): K and V^T are staged as two-term f16 planes (hi = 11 significant bits, lo = x - hi,
+// split ONCE per chunk for the four waves that share it), the pre-scaled Q fragments are split once per kernel, P is split where it leaves the
+// softmax -- its S^T accumulator layout (rows = keys 4 g + r, column = query) IS the B operand of v_mfma_f32_16x16x16_f16, no LDS round trip.  Per
+// (query tile, key tile) and 16 head columns: 3 MFMAs of 16x16x16 for q.k and 3 for p.v where the fp32 pipe needs 4 + 4 of 16x16x4 at four times the
+// cycles each; softmax, running maximum, de-stationary factors and the output are fp32 as before.
+typedef _Float16 ah4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void attn_split4(const v4f& v, ah4& hi, ah4& lo) {
+    float h[4], l[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        h[c] = __uint_as_float(__float_as_uint(v[c]) & 0xFFFFE000u);
+        l[c] = v[c] - h[c];
+    }
+    typedef __fp16 pk2 __attribute__((ext_vector_type(2)));
+    const pk2 h01 = __builtin_amdgcn_cvt_pkrtz(h[0], h[1]), h23 = __builtin_amdgcn_cvt_pkrtz(h[2], h[3]);
+    const pk2 l01 = __builtin_amdgcn_cvt_pkrtz(l[0], l[1]), l23 = __builtin_amdgcn_cvt_pkrtz(l[2], l[3]);
+    hi = ah4{(_Float16)h01[0], (_Float16)h01[1], (_Float16)h23[0], (_Float16)h23[1]};
+    lo = ah4{(_Float16)l01[0], (_Float16)l01[1], (_Float16)l23[0], (_Float16)l23[1]};
+}
+#define NST_MMH(acc, a, b) (acc) = __builtin_amdgcn_mfma_f32_16x16x16f16((a), (b), (acc), 0, 0, 0)
+#ifndef AH_KC
+#define AH_KC 64                        // keys per chunk of the split-f16 kernel
+#endif
+#ifndef AH_WGS
+#define AH_WGS 4
+#endif
+
+template <int E>
+__global__ __launch_bounds__(256, AH_WGS) void nst_attn_h_kernel(const AttnArgs p) {
+    constexpr int KLD = E + 8, VLD = AH_KC + 8, ES = E / 16;              // halves per row: 16 rows x two 8-byte pieces of a fragment read cover all 64 banks
+    extern __shared__ __attribute__((aligned(16))) unsigned char ah_smem[];
+    _Float16* Kh = reinterpret_cast<_Float16*>(ah_smem);                  // [AH_KC][KLD]
+    _Float16* Kl = Kh + AH_KC * KLD;
+    _Float16* Vh = Kl + AH_KC * KLD;                                      // transposed: [E][VLD]
+    _Float16* Vl = Vh + E * VLD;
+    float* Dl = reinterpret_cast<float*>(Vl + E * VLD);                   // [AH_KC]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y;
+    const long long b = blockIdx.z;
+    const int q0 = blockIdx.x * A_QT;
+    const float qs = p.scale * LOG2E * (p.tau ? p.tau[b] : 1.0f);
+    const float ds = p.scale * LOG2E;
+    const int qt0 = q0 + wave * 16, qrow = qt0 + lq;
+    const bool live = qt0 < p.L;                                          // (wave-uniform)
+    ah4 qh[ES], ql[ES];
+    v4f o[ES];                                                            // O^T tiles: d = 16 dt + 4 g + r, column = query
+    {
+        const int qclamp = qrow < p.L ? qrow : p.L - 1;
+        const float* qp = p.Q + ((size_t)b * p.L + qclamp) * p.ldq + (size_t)h * E + 4 * g;
+#pragma unroll
+        for (int s = 0; s < ES; ++s) {
+            attn_split4(*reinterpret_cast<const v4f*>(qp + 16 * s) * qs, qh[s], ql[s]);
+            o[s] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
+    float m_run = -INFINITY, l_run = 0.0f;
+    const int s_end = p.causal ? min(p.S, q0 + A_QT) : p.S;
+    for (int k0 = 0; k0 < s_end; k0 += AH_KC) {
+        const int n_kt = min(AH_KC / 16, (s_end - k0 + 15) >> 4);
+        const int w_kt = !live ? 0 : (p.causal ? max(0, min(n_kt, ((qt0 + 15 - k0) >> 4) + 1)) : n_kt);
+        __syncthreads();                // previous chunk fully consumed
+        {
+            constexpr int NST = AH_KC * (E / 4) / 256;
+            const int n_st = n_kt * 16 * (E / 4);
+            v4f kr[NST], vr[NST];
+#pragma unroll
+            for (int j = 0; j < NST; ++j) {
+                const int i = min(tid + 256 * j, n_st - 1);              // (unconditional loads: a spare thread repeats the last piece)
+                const int key = i / (E / 4), e4 = (i % (E / 4)) * 4;
+                const int src = k0 + key < p.S ? k0 + key : p.S - 1;
+                kr[j] = *reinterpret_cast<const v4f*>(p.K + ((size_t)b * p.S + src) * p.ldk + (size_t)h * E + e4);
+                vr[j] = *reinterpret_cast<const v4f*>(p.V + ((size_t)b * p.S + src) * p.ldv + (size_t)h * E + e4);
+            }
+#pragma unroll
+            for (int j = 0; j < NST; ++j) {
+                const int i = tid + 256 * j;
+                if (i < n_st) {
+                    const int key = i / (E / 4), e4 = (i % (E / 4)) * 4;
+                    ah4 hi, lo;
+                    attn_split4(kr[j], hi, lo);
+                    *reinterpret_cast<ah4*>(Kh + key * KLD + e4) = hi;
+                    *reinterpret_cast<ah4*>(Kl + key * KLD + e4) = lo;
+                    attn_split4(vr[j], hi, lo);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        Vh[(e4 + c) * VLD + key] = hi[c];
+                        Vl[(e4 + c) * VLD + key] = lo[c];
+                    }
+                }
+            }
+        }
+        if (tid < AH_KC) Dl[tid] = (p.delta && k0 + tid < p.S) ? p.delta[(size_t)b * p.S + k0 + tid] * ds : 0.0f;
+        __syncthreads();
+        // S^T tiles: rows = keys (16 kt + 4 g + r), column = query
+        v4f sc[AH_KC / 16];
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < AH_KC / 16; ++kt) {
+            if (kt >= w_kt) continue;
+            v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            const int ko = (kt * 16 + lq) * KLD + 4 * g;
+#pragma unroll
+            for (int s = 0; s < ES; ++s) {
+                const ah4 kh = *reinterpret_cast<const ah4*>(Kh + ko + 16 * s), kl = *reinterpret_cast<const ah4*>(Kl + ko + 16 * s);
+                NST_MMH(acc, kl, qh[s]);
+                NST_MMH(acc, kh, ql[s]);
+                NST_MMH(acc, kh, qh[s]);
+            }
+            const v4f dl = *reinterpret_cast<const v4f*>(Dl + kt * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + kt * 16 + 4 * g + r;
+                float v = acc[r] + dl[r];
+                if (key >= p.S || (p.causal && key > qrow)) v = -INFINITY;
+                acc[r] = v;
+                cmax = fmaxf(cmax, v);
+            }
+            sc[kt] = acc;
+        }
+        if (w_kt > 0) {
+            float cm = cmax;
+            cm = fmaxf(cm, __shfl_xor(cm, 16));
+            cm = fmaxf(cm, __shfl_xor(cm, 32));
+            const float m_new = fmaxf(m_run, cm);
+            const float alpha = exp2f(m_run - m_new);                   // (every live query sees key 0 in chunk 0, so m_new is finite)
+            m_run = m_new;
+            float psum = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < AH_KC / 16; ++kt) {
+                if (kt >= w_kt) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f(sc[kt][r] - m_new);
+                    sc[kt][r] = e;
+                    psum += e;
+                }
+            }
+            psum += __shfl_xor(psum, 16);
+            psum += __shfl_xor(psum, 32);
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < ES; ++dt) o[dt] *= alpha;
+        }
+        // O^T[d][query] += V^T[d][key] P^T[key][query]
+#pragma unroll
+        for (int kt = 0; kt < AH_KC / 16; ++kt) {
+            if (kt >= w_kt) continue;
+            ah4 ph, pl;
+            attn_split4(sc[kt], ph, pl);
+#pragma unroll
+            for (int dt = 0; dt < ES; ++dt) {
+                const int vo = (dt * 16 + lq) * VLD + kt * 16 + 4 * g;
+                const ah4 vh = *reinterpret_cast<const ah4*>(Vh + vo), vl = *reinterpret_cast<const ah4*>(Vl + vo);
+                NST_MMH(o[dt], vl, ph);
+                NST_MMH(o[dt], vh, pl);
+                NST_MMH(o[dt], vh, ph);
+            }
+        }
+    }
+    if (qrow < p.L) {
+        const float inv = 1.0f / l_run;
+        float* op = p.O + ((size_t)b * p.L + qrow) * p.ldo + (size_t)h * E + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < ES; ++dt) *reinterpret_cast<v4f*>(op + 16 * dt) = o[dt] * inv;
+    }
+}
+template <int E>
+constexpr size_t nst_attn_h_lds() { return 2 * sizeof(_Float16) * ((size_t)AH_KC * (E + 8) + (size_t)E * (AH_KC + 8)) + sizeof(float) * AH_KC; }
+
 // ---------------------------------------------------------------------------------------------------------------------
 // LayerNorm over d_model (one wave per row), and the output head
 // ---------------------------------------------------------------------------------------------------------------------
@@ -616,6 +786,22 @@ int attention(mpv_ctx* ctx, const NstEngine& e, const float* Q, long long ldq, c
     const int H = e.d.n_heads, E = e.d.d_model / H;
     AttnArgs a{Q, ldq, K, ldk, V, ldv, e.tau_v, delta, O, (long long)e.d.d_model, L, S, causal, 1.0f / sqrtf((float)E)};
     const dim3 grid((unsigned)((L + A_QT - 1) / A_QT), (unsigned)H, (unsigned)B);
+    static const bool attn_f32 = getenv("MPV_NST_ATTN_F32") && atoi(getenv("MPV_NST_ATTN_F32")) != 0;      // (A/B aid: the fp32-pipe kernel in f16x3 mode too)
+    if (e.gemm_mode != MPV_GEMM_F32 && !attn_f32) {                  // two-term f16 products, fp32-equivalent (like the Linear layers of this mode)
+#define NST_ATTN_H(E_)                                                                                                                        \
+    do {                                                                                                                                      \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(nst_attn_h_kernel<E_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                           (int)nst_attn_h_lds<E_>());                                                       \
+        (void)attr;                                                                                                                           \
+        hipLaunchKernelGGL(nst_attn_h_kernel<E_>, grid, dim3(256), nst_attn_h_lds<E_>(), ctx->stream, a);                                     \
+    } while (0)
+        if (E == 64) NST_ATTN_H(64);
+        else if (E == 32) NST_ATTN_H(32);
+        else NST_ATTN_H(16);
+#undef NST_ATTN_H
+        MPV_HIP_TRY(ctx, hipGetLastError());
+        return MPV_OK;
+    }
     if (E == 64) hipLaunchKernelGGL(nst_attn_kernel<64>, grid, dim3(256), 0, ctx->stream, a);
     else if (E == 32) hipLaunchKernelGGL(nst_attn_kernel<32>, grid, dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL(nst_attn_kernel<16>, grid, dim3(256), 0, ctx->stream, a);
