@@ -3,8 +3,10 @@ through the C ABI (mpv_nst_load / mpv_nst_forward) against oracle/ns_transformer
 
 PARITY UNPINNED: the oracle restates the torch-timeseries==0.1.10 layers the reference imports (package absent, no network), so
 these tests pin the HIP kernels to the restatement -- wiring, Projector, statistics and de-normalisation are the reference's own
-lines (NsDiff/mu_backbone.py:12-183) -- not to a run of the reference.  Tolerance 1e-4 elementwise (exact-fp32 matrix products;
-what differs is summation order in LayerNorm / softmax / the k-split of the GEMMs)."""
+lines (NsDiff/mu_backbone.py:12-183) -- not to a run of the reference.  Tolerance 1e-4 elementwise in both gemm modes: "f32" runs the Linear
+layers and the attention on the exact-fp32 matrix pipe, "f16x3" (default) runs both as two-term f16 splits with fp32 accumulation
+(nst_gemm_h3_kernel, and since round 4 nst_attn_h_kernel at head widths 16 / 32 / 64, causal and not); what differs from the restatement is
+summation order in LayerNorm / softmax / the k-split of the products."""
 import pytest
 import torch
 
